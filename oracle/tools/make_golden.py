@@ -1,0 +1,202 @@
+"""Generate tests/golden/*.npz by running THE REFERENCE ITSELF (imported from /root/reference through
+oracle/tools/ref_shims.py) on CPU, in the build container.  TEST INFRASTRUCTURE.
+
+    python oracle/tools/make_golden.py            # writes tests/golden/, prints oracle-vs-reference deltas
+
+Only data is written: inputs (demo-frame tensors exactly as the reference's DemoDataset produces them)
+and the reference's outputs.  Weights are the seeded state_dict of vi_depth_completion_amd.synthetic
+(seed 1234), loaded through the reference's own `state.update(..); load_state_dict` path
+(network_run.py:319-323, main.py:256-259), so they are regenerated, not stored.
+"""
+import argparse
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+from oracle.tools import ref_shims          # noqa: E402
+from oracle import vidc_oracle as O          # noqa: E402
+from vi_depth_completion_amd import synthetic as S   # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SEED = 1234
+DEMO_FRAMES = ("000000", "000068", "000085")
+PROBES = 64
+
+
+def probe(t, tag):
+    """mean, std (float64) and PROBES seeded flat samples of a tensor."""
+    f = t.detach().reshape(-1)
+    idx = (S.uniform01(SEED, "probe." + tag, (PROBES,)).double() * f.numel()).long().clamp_(max=f.numel() - 1)
+    return {"mean": float(f.double().mean()), "std": float(f.double().std()), "idx": idx.numpy(), "val": f[idx].numpy().copy()}
+
+
+def flat(d, prefix, out):
+    for k, v in d.items():
+        out[prefix + "." + k] = np.asarray(v)
+
+
+def extreme_gravities():
+    """three synthetic tilts for the warp alone: roll 30 deg, roll 60 deg + pitch, near-180 deg (degenerate branch)."""
+    gs = []
+    for roll, pitch in ((30.0, 0.0), (60.0, 15.0), (179.0, 0.0)):
+        r, p = np.deg2rad(roll), np.deg2rad(pitch)
+        g = np.array([np.sin(r) * np.cos(p), np.cos(r) * np.cos(p), np.sin(p)])
+        gs.append(g / np.linalg.norm(g))
+    return torch.tensor(np.stack(gs), dtype=torch.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=GOLD)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.set_grad_enabled(False)
+    ref = ref_shims.load_reference()
+
+    # ---- build the reference pipeline exactly like main.py:347 does -------------------------------------
+    rargs = argparse.Namespace(save="", enable_multi_gpu=0, learning_rate=1e-4, batch_size=1, enriched_samples=200,
+                               dataset_type="demo")
+    run = ref.RunDepthCompletion(rargs, None, None, ref.ModifiedFPN, use_gravity=True)
+    sn, dc = run.surface_normal_cnn, run.cnn
+    sn_sd = S.seeded_state_dict(sn.state_dict(), SEED)
+    dc_sd = S.seeded_state_dict(dc.state_dict(), SEED)
+    for m, sd in ((sn, sn_sd), (dc, dc_sd)):
+        st = m.state_dict()
+        st.update(sd)
+        m.load_state_dict(st)
+    ref_shims.FixedPlaneMask.id_map = S.plane_id_map(240, 320)
+    run.load_plane_extraction_network_from_file("unused.yaml")
+    run.eval_mode()
+    # key/shape manifest so the product modules can be checked without the reference
+    np.savez_compressed(os.path.join(args.out, "state_dict_manifest.npz"),
+                        sn_keys=np.array(list(sn.state_dict().keys())),
+                        sn_shapes=np.array([str(tuple(v.shape)) for v in sn.state_dict().values()]),
+                        dc_keys=np.array(list(dc.state_dict().keys())),
+                        dc_shapes=np.array([str(tuple(v.shape)) for v in dc.state_dict().values()]))
+
+    warp = sn.warp_2dof_alignment
+    intr = O.Intrinsics(warp.fx, warp.fy, warp.cx, warp.cy)
+    assert (intr.W, intr.H) == (int(warp.W), int(warp.H)) == (320, 240)
+
+    ds = ref.DemoDataset(os.path.join(ref_shims.REFERENCE_ROOT, "demo_dataset"))
+    ds.color_files = sorted(ds.color_files)
+    items = {f[6:12]: ds[i] for i, f in enumerate(ds.color_files)}
+
+    # ---- (1) warp-only vectors: 8 demo gravities + 3 extreme tilts --------------------------------------
+    g_all = torch.cat([torch.stack([items[k]["gravity"] for k in sorted(items)]), extreme_gravities()])
+    a_demo = torch.stack([items[k]["aligned_direction"] for k in sorted(items)])
+    a_all = torch.cat([a_demo, torch.tensor([[0.0, 1.0, 0.0]]).repeat(3, 1)])
+    n = g_all.shape[0]
+    img = S.uniform01(SEED, "warp.image", (1, 3, 240, 320)).repeat(n, 1, 1, 1)
+    nmap = S.normal01(SEED, "warp.normalmap", (1, 3, 240, 320)).float().repeat(n, 1, 1, 1)
+    H_ref, y_ref = warp.warp_with_gravity_center_aligned(img, g_all, a_all)
+    _, z_ref = warp.inverse_warp_normal_image_with_gravity_center_aligned(nmap, g_all, a_all)
+    H_or, y_or = O.warp_forward(img, g_all, a_all, intr)
+    _, z_or = O.warp_inverse_normals(nmap, g_all, a_all, intr)
+    ok = torch.isfinite(y_ref).flatten(1).all(1) & torch.isfinite(z_ref).flatten(1).all(1)
+    print("warp: finite cases", ok.tolist())
+    print("warp: oracle-vs-reference  H %.2e  fwd %.2e  inv %.2e" % (
+        (H_or - H_ref)[ok].abs().max(), (y_or - y_ref)[ok].abs().max(), (z_or - z_ref)[ok].abs().max()))
+    np.savez_compressed(os.path.join(args.out, "warp_cases.npz"),
+                        gravity=g_all.numpy(), aligned=a_all.numpy(), finite=ok.numpy(), H=H_ref.numpy(),
+                        fwd_full_case0=y_ref[0].numpy(), fwd_full_case9=y_ref[9].numpy(),
+                        inv_full_case0=z_ref[0].numpy(), inv_full_case9=z_ref[9].numpy(),
+                        fwd_sum=y_ref.double().flatten(1).sum(1).numpy(), inv_sum=z_ref.double().flatten(1).sum(1).numpy(),
+                        fwd_abs_sum=y_ref.double().abs().flatten(1).sum(1).numpy(),
+                        inv_abs_sum=z_ref.double().abs().flatten(1).sum(1).numpy(),
+                        fx=warp.fx, fy=warp.fy, cx=warp.cx, cy=warp.cy)
+
+    # ---- (2) whole-path vectors --------------------------------------------------------------------------
+    taps = {}
+
+    def hook(name):
+        def fn(mod, inp, out):
+            taps[name] = out.detach().clone()
+        return fn
+
+    for li in range(1, 5):
+        getattr(sn.resnet_pyramids, "layer%d" % li).register_forward_hook(hook("sn.x%d" % li))
+        getattr(sn, "feature%d_upsamping" % li).register_forward_hook(hook("sn.z%d" % li))
+        getattr(dc, "feature%d_upsamping" % li).register_forward_hook(hook("dc.z%d" % li))
+        for bb in ("rgb", "normal", "depth"):
+            getattr(getattr(dc, "resnet_" + bb), "layer%d" % li).register_forward_hook(hook("dc.%s.x%d" % (bb, li)))
+    sn.feature_concat.register_forward_hook(hook("sn.normal_raw"))
+    dc.feature_concat[2].register_forward_hook(hook("dc.head_lowres"))
+    sn.register_forward_hook(hook("normals"))
+    dc.register_forward_pre_hook(lambda mod, inp: taps.__setitem__("enriched", inp[2].detach().clone()))
+
+    plane_calls = []
+    orig_extract = ref.extract_plane_images_from_normal_image
+
+    def traced_extract(normal_image, mask, depth, homo):
+        r = orig_extract(normal_image, mask, depth, homo)
+        plane_calls.append(r[1].detach().clone())
+        return r
+
+    ref.extract_plane_images_from_normal_image = traced_extract
+
+    cases = [("demo_" + k, {kk: (v.unsqueeze(0) if torch.is_tensor(v) else [v]) for kk, v in items[k].items()},
+              1000 + int(k)) for k in DEMO_FRAMES]
+    cases.append(("synthetic_f0", S.synthetic_batch(1, 240, 320, SEED), 999))
+    for name, batch, npseed in cases:
+        taps.clear()
+        plane_calls.clear()
+        np.random.seed(npseed)
+        depth_ref = run._call_cnn(batch)
+        # oracle on the same inputs / same numpy stream
+        np.random.seed(npseed)
+        otaps = {}
+        depth_or = O.call_cnn(sn_sd, dc_sd, batch, [S.plane_id_map(240, 320)], intr, 200, rng=np.random, taps=otaps)
+        dn = (otaps["normals"] - taps["normals"]).abs().max().item()
+        dd = (depth_or - depth_ref).abs().max().item()
+        dpl = (otaps["plane_depth"][0, 0] - plane_calls[0]).abs().max().item()
+        den = (otaps["enriched"] - taps["enriched"]).abs().max().item()
+        print("%s: oracle-vs-reference  normals %.2e  plane_depth %.2e  enriched %.2e  depth %.2e   (depth mean %.3f std %.3f)" % (
+            name, dn, dpl, den, dd, depth_ref.mean(), depth_ref.std()))
+        # teacher-forced stages (each oracle stage fed the reference's own inputs)
+        d_tf = O.depth_completion_forward(dc_sd, batch["image"], taps["normals"], taps["enriched"])
+        print("    teacher-forced depth net: %.2e" % (d_tf - depth_ref).abs().max().item())
+
+        out = {"np_seed": npseed, "gravity": batch["gravity"][0].numpy(), "aligned": batch["aligned_direction"][0].numpy()}
+        sd_img = batch["sparse_depth"][0, 0]
+        rr, cc = torch.nonzero(sd_img, as_tuple=True)
+        out["sparse_rc"] = torch.stack([rr, cc], 1).numpy().astype(np.int32)
+        out["sparse_val"] = sd_img[rr, cc].numpy()
+        if name.startswith("demo_"):
+            out["image_u8"] = (batch["image"][0] * 255.0).round().permute(1, 2, 0).to(torch.uint8).numpy()
+            assert torch.equal(torch.from_numpy(out["image_u8"]).permute(2, 0, 1).float().div(255), batch["image"][0])
+        out["normals"] = taps["normals"][0].numpy()
+        out["depth"] = depth_ref[0, 0].numpy()
+        pd = plane_calls[0]
+        rr, cc = torch.nonzero(pd, as_tuple=True)
+        out["plane_depth_nnz"] = int(len(rr))
+        out["plane_depth_sum"] = float(pd.double().sum())
+        out["plane_depth_f16"] = pd.to(torch.float16).numpy()          # coarse copy for diagnostics
+        en = taps["enriched"][0, 0]
+        rr, cc = torch.nonzero(en, as_tuple=True)
+        out["enriched_rc"] = torch.stack([rr, cc], 1).numpy().astype(np.int32)
+        out["enriched_val"] = en[rr, cc].numpy()
+        for t in otaps["plane_trace"]:
+            p = "plane%d" % t["cls"]
+            out[p + ".hyp_idx"] = t["hyp_idx"].astype(np.int32)
+            out[p + ".n_bar"] = t["n_bar"].numpy()
+            out[p + ".scalars"] = np.array([t["n_inl"], t["mean_angle"], float(t["accepted"]), t["offset"],
+                                            t["n_off_inl"], float(t["valid"])], dtype=np.float64)
+        out["enrich.nnz"] = otaps["enrich_trace"][0]["nnz"]
+        out["enrich.sub"] = otaps["enrich_trace"][0]["sub"].astype(np.int32)
+        for k, v in taps.items():
+            if k not in ("normals", "enriched"):
+                flat(probe(v, k), "probe." + k, out)
+        np.savez_compressed(os.path.join(args.out, name + ".npz"), **out)
+    print("golden vectors written to", args.out)
+
+
+if __name__ == "__main__":
+    main()

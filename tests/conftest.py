@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def seeded_weights():
+    """Seeded SN + DC state_dicts (seed 1234) on CPU, built from the committed key/shape manifest."""
+    import numpy as np
+    import torch
+    from vi_depth_completion_amd import synthetic as S
+
+    man = np.load(os.path.join(GOLDEN, "state_dict_manifest.npz"))
+
+    def build(prefix):
+        shapes = {k: torch.empty(eval(s), device="meta") for k, s in zip(man[prefix + "_keys"], man[prefix + "_shapes"])}
+        return S.seeded_state_dict(shapes, 1234)
+
+    return {"sn": build("sn"), "dc": build("dc")}

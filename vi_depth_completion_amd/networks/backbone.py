@@ -1,0 +1,99 @@
+"""ResNet-101 feature pyramid: parameter containers + layer program.
+
+Mirrors the *parameter layout* (state_dict keys and shapes) of the reference's two identical
+`ResNetPyramids` classes (networks/surface_normal.py:10-55, networks/depth_completion.py:16-65),
+which in turn borrow `layer1..layer4` from torchvision's resnet101 (Bottleneck [3,4,23,3], stride on
+the 3x3 conv) with `layer1[0].conv1` / `layer1[0].downsample[0]` rewired to 128 input channels.
+
+Nothing here computes: `emit()` appends fused conv+BN+ReLU ops to an engine `Program`, which the HIP
+engine executes (vi_depth_completion_amd/engine.py).
+"""
+import collections
+
+import torch
+import torch.nn as nn
+
+STAGE_BLOCKS = {101: (3, 4, 23, 3), 50: (3, 4, 6, 3)}
+STAGE_PLANES = (64, 128, 256, 512)
+
+
+def _conv(cin, cout, k, stride=1, padding=0, bias=False):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=padding, bias=bias)
+
+
+class Bottleneck(nn.Module):
+    """1x1 -> 3x3(stride) -> 1x1(x4) residual block; attribute names are the checkpoint keys."""
+
+    def __init__(self, cin, planes, stride, project):
+        super().__init__()
+        self.conv1 = _conv(cin, planes, 1)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = _conv(planes, planes, 3, stride, 1)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = _conv(planes, planes * 4, 1)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.stride = stride
+        if project:
+            self.downsample = nn.Sequential(_conv(cin, planes * 4, 1, stride), nn.BatchNorm2d(planes * 4))
+        else:
+            self.downsample = None
+
+    def emit(self, prog, x, prefix):
+        t = prog.conv(x, prefix + "conv1", bn=prefix + "bn1", relu=True)
+        t = prog.conv(t, prefix + "conv2", bn=prefix + "bn2", relu=True, stride=self.stride, padding=1)
+        if self.downsample is not None:
+            idn = prog.conv(x, prefix + "downsample.0", bn=prefix + "downsample.1", stride=self.stride)
+        else:
+            idn = x
+        # relu(bn3(conv3(t)) + identity), fused in the conv epilogue
+        return prog.conv(t, prefix + "conv3", bn=prefix + "bn3", residual=idn, relu_after_residual=True)
+
+
+def _stage(cin, planes, blocks, stride):
+    mods = [Bottleneck(cin, planes, stride, project=True)]
+    mods += [Bottleneck(planes * 4, planes, 1, project=False) for _ in range(blocks - 1)]
+    return nn.Sequential(*mods)
+
+
+class ResNetPyramids(nn.Module):
+    def __init__(self, in_channels=3, pretrained=True, resnet_arch=101):
+        super().__init__()
+        del pretrained  # no network, no ImageNet weights: parameters always come from load_state_dict
+        self.channel = in_channels
+        self.conv1 = nn.Sequential(collections.OrderedDict([
+            ("conv1_1", _conv(in_channels, 64, 3, 2, 1)),
+            ("relu1_1", nn.ReLU(inplace=True)),
+            ("conv1_2", _conv(64, 64, 3, 1, 1)),
+            ("bn_2", nn.BatchNorm2d(64)),
+            ("relu1_2", nn.ReLU(inplace=True)),
+            ("conv1_3", _conv(64, 128, 3, 1, 1)),
+            ("bn1_3", nn.BatchNorm2d(128)),
+            ("relu1_3", nn.ReLU(inplace=True)),
+        ]))
+        self.bn1 = nn.BatchNorm2d(128)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        blocks = STAGE_BLOCKS[resnet_arch]
+        cin = 128
+        for i, (planes, n) in enumerate(zip(STAGE_PLANES, blocks)):
+            setattr(self, "layer%d" % (i + 1), _stage(cin, planes, n, 1 if i == 0 else 2))
+            cin = planes * 4
+
+    def emit(self, prog, x, prefix, x_is_nchw=True):
+        """x: Program tensor (B,H,W,Cin). Returns the four pyramid levels x1..x4."""
+        p = prefix + "conv1."
+        t = prog.stem_conv(x, p + "conv1_1", relu=True, x_is_nchw=x_is_nchw)          # no BN (reference quirk)
+        t = prog.conv(t, p + "conv1_2", bn=p + "bn_2", relu=True, padding=1)
+        # conv1_3 -> bn1_3 -> relu -> bn1 -> relu: two affines fused in one epilogue
+        t = prog.conv(t, p + "conv1_3", bn=p + "bn1_3", relu=True, padding=1, bn2=prefix + "bn1", relu2=True)
+        t = prog.maxpool(t)
+        outs = []
+        for li in range(1, 5):
+            stage = getattr(self, "layer%d" % li)
+            for bi, blk in enumerate(stage):
+                t = blk.emit(prog, t, "%slayer%d.%d." % (prefix, li, bi))
+            outs.append(t)
+        return outs
+
+    def forward(self, x):  # pragma: no cover - the pyramid only runs inside an engine Program
+        raise RuntimeError("ResNetPyramids runs only as part of a HIP engine program (no eager/CPU path)")
