@@ -1,0 +1,216 @@
+/*
+ * vidc.h -- C ABI of libvidc.so: the MI355X (gfx950) depth-completion inference path.
+ *
+ * This is the drop-in boundary for the reference's per-frame hot path
+ * (MARSLab-UMN/vi_depth_completion, main.py:261-298 `RunDepthCompletion._call_cnn` and the three
+ * callables it drives).  The reference has no native code on this path -- it is ~1500 ATen calls per
+ * frame -- so every entry point below cites the *Python* interface it replaces (file:line relative to
+ * the reference root).  Plain pointers and sizes only; no torch types; no exceptions cross this ABI.
+ *
+ * Conventions
+ *   - all tensors are fp32 device memory unless stated; "NHWC" = [B][H][W][ld] with `ld` >= C the
+ *     channel stride (so a tensor can be a channel slice of a wider concat buffer); "NCHW" is dense.
+ *   - every launcher takes the hipStream_t to enqueue on, allocates nothing, never synchronises,
+ *     and is re-entrant.  Scratch memory is supplied by the caller (`*_workspace_bytes`).
+ *   - return value: 0 = ok, <0 = vidc_status; vidc_last_error() gives a thread-local message.
+ */
+#ifndef VIDC_H
+#define VIDC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vidc_stream_t; /* hipStream_t */
+
+enum vidc_status {
+    VIDC_OK = 0,
+    VIDC_ERR_NULL = -1,      /* null pointer argument          */
+    VIDC_ERR_SHAPE = -2,     /* unsupported / inconsistent dims */
+    VIDC_ERR_HIP = -3,       /* HIP runtime error               */
+    VIDC_ERR_STATE = -4      /* bad handle / call order         */
+};
+
+int vidc_version(void);               /* ABI version, currently 1 */
+const char* vidc_last_error(void);    /* thread-local, never NULL */
+int vidc_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2-DoF gravity-aligned warp        (networks/warping_2dof_alignment.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Per-sample geometry record, VIDC_WARP_PARAMS floats per sample:
+ *   [0..8] Cg_H_C  [9..17] Cg_R_C  [18..26] Cg_H_C^-1 (= K R^T K^-1)  [27] px_min [28] py_min [29] kw [30] kh [31] 0 */
+#define VIDC_WARP_PARAMS 32
+
+/* Replaces _build_homography (:35-58) + the corner-bbox / kw,kh block (:124-140, :229-243).
+ * gravity, aligned: [B][3].  K_inv: 9 floats (row-major, the fp32 cast of numpy's fp64 inverse, :15,:20). */
+int vidc_warp2dof_params(const float* gravity, const float* aligned, int B, float fx, float fy, float cx, float cy,
+                         const float* K_inv, int W, int H, float* params, vidc_stream_t stream);
+
+/* Replaces warp_with_gravity_center_aligned (:108-156): y[b,c,Y,X] = bilinear(x[b,c], H^-1 (X/kw+px_min, Y/kh+py_min, 1)),
+ * zero padding; align_corners selects grid_sample's convention (0 = what the oracle/reference do on torch>=1.3).
+ * x, y: NCHW [B][C][H][W]. */
+int vidc_warp2dof_fwd(const float* x, const float* params, float* y, int B, int C, int H, int W, float cx, float cy,
+                      int align_corners, vidc_stream_t stream);
+
+/* Replaces inverse_warp_normal_image_with_gravity_center_aligned (:216-255) fused with the bmm by R^T (:253)
+ * and, if normalize != 0, F.normalize(z, dim=1) (networks/surface_normal.py:170).  x, z: NCHW [B][3][H][W]. */
+int vidc_warp2dof_inv_rot_norm(const float* x, const float* params, float* z, int B, int H, int W, float cx, float cy,
+                               int align_corners, int normalize, vidc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * conv + BN + ReLU stacks           (networks/surface_normal.py:10-145, networks/depth_completion.py:16-147)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* OIHW -> packed [G][Cout][KH][KW][Cin] (K-contiguous rows for the implicit GEMM), one group per call. */
+int vidc_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, vidc_stream_t stream);
+
+enum vidc_conv_flags {
+    VIDC_RELU1 = 1,        /* relu after the first affine                                     */
+    VIDC_AFFINE2 = 2,      /* second per-channel affine (bn1_3 -> relu -> bn1, surface_normal.py:41-43) */
+    VIDC_RELU2 = 4,        /* relu after the second affine                                    */
+    VIDC_RESIDUAL = 8,     /* += residual (Bottleneck identity)                               */
+    VIDC_RELU3 = 16,       /* relu after the residual add                                     */
+    VIDC_ACCUM = 32        /* y += result (z1+z2+z3+z4, surface_normal.py:168)                */
+};
+
+/* Fused nn.Conv2d(+bias) -> BatchNorm2d(eval) -> ReLU [-> BatchNorm2d -> ReLU] [+ identity -> ReLU].
+ * Implicit GEMM on fp32 MFMA: M = B*Ho*Wo, N = Cout, K = KH*KW*Cin.  Cin % 32 == 0, Cout % 32 == 0.
+ * `groups` independent convolutions of identical shape run in one launch (the three ResNet-101 pyramids of
+ * ModifiedFPN, depth_completion.py:155-157); group g uses x + g*x_gs, w + g*w_gs, y + g*y_gs, ... */
+typedef struct vidc_conv_desc {
+    const float* x;        /* NHWC input,  channel stride ldx                         */
+    const float* w;        /* packed weights [Cout][KH*KW*Cin]                        */
+    float* y;              /* NHWC output, channel stride ldy                         */
+    const float* scale1;   /* [Cout] gamma/sqrt(var+eps)            (1 if no BN)      */
+    const float* shift1;   /* [Cout] beta - mean*scale + bias*scale (bias if no BN)   */
+    const float* scale2;   /* [Cout] or NULL                                          */
+    const float* shift2;
+    const float* residual; /* NHWC, channel stride ldr, or NULL                       */
+    float* workspace;      /* split-K partials: splitk*groups*M*Cout floats, or NULL  */
+    int32_t B, H, W, Cin, ldx;
+    int32_t Ho, Wo, Cout, ldy, ldr;
+    int32_t KH, KW, stride, pad;
+    int32_t flags;         /* vidc_conv_flags                                         */
+    int32_t groups;
+    int64_t x_gs, w_gs, y_gs, r_gs, p_gs;   /* per-group element strides (p_gs: scale/shift) */
+    int32_t tile;          /* vidc_conv_tile, or VIDC_TILE_AUTO                       */
+    int32_t splitk;        /* >= 1                                                    */
+} vidc_conv_desc;
+
+enum vidc_conv_tile { VIDC_TILE_AUTO = 0, VIDC_TILE_128x128 = 1, VIDC_TILE_128x64 = 2, VIDC_TILE_64x128 = 3,
+                      VIDC_TILE_64x64 = 4, VIDC_TILE_32x128 = 5, VIDC_TILE_32x64 = 6, VIDC_TILE_COUNT = 7 };
+
+int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream);
+size_t vidc_conv2d_workspace_bytes(const vidc_conv_desc* d);
+/* Fills d->tile / d->splitk with the heuristic choice for this shape on the current device. */
+int vidc_conv2d_plan(vidc_conv_desc* d);
+
+/* Stem conv 3x3 stride 2 pad 1, Cin in {1,3}, no BN, optional ReLU (conv1_1, surface_normal.py:17-18).
+ * x: NCHW [B][Cin][H][W] -> y: NHWC [B][Ho][Wo][ldy].  w: OIHW as in the checkpoint. */
+int vidc_stem_conv3x3s2(const float* x, const float* w_oihw, float* y, int B, int Cin, int H, int W, int Cout, int ldy,
+                        int relu, vidc_stream_t stream);
+
+/* nn.MaxPool2d(3, 2, 1) on NHWC (surface_normal.py:44). */
+int vidc_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, vidc_stream_t stream);
+
+enum vidc_up_flags { VIDC_UP_RELU = 1, VIDC_UP_ACCUM = 2 };
+/* nn.UpsamplingBilinear2d(size) == bilinear, align_corners=True, on NHWC (surface_normal.py:88 ...). */
+int vidc_upsample_bilinear_ac(const float* x, float* y, int B, int h, int w, int C, int ldx, int H, int W, int ldy,
+                              int flags, vidc_stream_t stream);
+
+/* Prediction head tail: 1x1 conv Cin -> Cout (Cout <= 4) with zero padding `pad` (the reference's
+ * Conv2d(192,1,1,1,1), depth_completion.py:144, pads a 1x1 conv -> 62x82 map whose border equals the bias),
+ * then UpsamplingBilinear2d(size=(H,W)) and optional ReLU.  x: NHWC [B][h][w][ldx]; lowres: scratch NCHW
+ * [B][Cout][h+2pad][w+2pad]; y: NCHW [B][Cout][H][W]. */
+int vidc_head_conv1x1_upsample(const float* x, const float* w, const float* bias, float* lowres, float* y, int B, int h,
+                               int w_in, int Cin, int ldx, int Cout, int pad, int H, int W, int relu, vidc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * plane block                        (main.py:29-190, 277-297)
+ * ---------------------------------------------------------------------------------------------- */
+
+#define VIDC_MAX_HYP 300          /* num_hypotheses, main.py:38,68 */
+#define VIDC_PLANE_RECORD 16
+/* A plane "slot" = one plane id of one image of the batch: int32[4] = {image index b, plane id, offset into hyp_pix,
+ * n_hyp}.  Every stage below is ONE launch over all slots (the reference loops in Python, main.py:147-182,279-283).
+ * Per-slot result record (VIDC_PLANE_RECORD floats):
+ *   [0..2] n_bar  [3] plane offset d  [4] n_inliers (normal RANSAC)  [5] mean |angle| in degrees  [6] accepted (<= 20 deg)
+ *   [7] n_pts (sparse depths on the inliers)  [8] mean_depth  [9] n_offset_inliers
+ *   [10] 1 = depth written, 0 = plane failed the validity tests, -1 = n_pts > VIDC_MAX_HYP (needs the host permutation
+ *        of main.py:78; not done on device)  [11] n projected pixels  [12] best hypothesis row */
+
+/* mean_normal_ranasc (main.py:38-62) + the inlier write-back of main.py:157 + the 20-degree acceptance test (:162).
+ * normals: NCHW [B][3][HW] unit normals; ids: [B][HW] uint8 plane-id maps; hyp_pix: flat pixel indices of the
+ * hypothesis normals of every slot, concatenated (the host draws np.random.permutation exactly like main.py:43);
+ * inlier_mask: [n_slots][HW] uint8 out; counts: [n_slots][VIDC_MAX_HYP] int32 scratch; records: [n_slots][16] out. */
+int vidc_plane_ransac_normal(const float* normals, const uint8_t* ids, const int32_t* slots, int n_slots,
+                             const int32_t* hyp_pix, int HW, uint8_t* inlier_mask, int32_t* counts, float* records,
+                             vidc_stream_t stream);
+
+/* plane_offset_ransac (main.py:68-101) with the point cloud of main.py:171-173: points homo*depth on
+ * inlier_mask & depth>0 (row-major order), hypotheses d_j = -n.P_j (all points, n_pts <= VIDC_MAX_HYP, :76-77),
+ * inliers |d_j + n.P| < 0.1, d = -mean(n.P over the best hypothesis' inliers).  homo: [B][HW][3]; depth: [B][HW]. */
+int vidc_plane_offset(const float* homo, const float* depth, const int32_t* slots, int n_slots, const uint8_t* inlier_mask,
+                      int HW, float* records, vidc_stream_t stream);
+
+/* generate_depth_from_plane (main.py:110-127) -- the normal->depth plane projection: depth = -d/(n.homo) on
+ * mask & |n.homo| > 1e-3; the plane is dropped when > 5% of its values exceed 10*mean_depth, any exceeds 10 m or any
+ * is negative; otherwise the values are written into plane_depth [B][HW] (pre-initialised with the sparse depth). */
+int vidc_plane_project_depth(const float* homo, const int32_t* slots, int n_slots, const uint8_t* inlier_mask, int HW,
+                             float* records, float* plane_depth, vidc_stream_t stream);
+
+/* main.py:186-187 (the original sparse depths override the plane depths) fused with the count the enrichment needs
+ * (main.py:287-289): plane_depth[p] = depth[p] where depth[p] > 0; nnz_out[b] = #(plane_depth[b] > 0). */
+int vidc_plane_finalize(const float* depth, float* plane_depth, int B, int HW, int32_t* nnz_out, vidc_stream_t stream);
+
+/* main.py:290-294: for image b the sub[k]-th nonzeros (row-major, like torch.nonzero) of plane_depth[b] are copied
+ * into enriched[b] (a clone of the sparse depth).  sub: sorted unique indices drawn on the host with
+ * np.unique(np.random.randint(...)); image b owns sub[sub_offsets[b] .. sub_offsets[b+1]). */
+int vidc_enrich_scatter(const float* plane_depth, const int32_t* sub, const int32_t* sub_offsets, int B, int HW,
+                        float* enriched, vidc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * programs: a whole network (or the whole frame) as one native call / one hipGraph
+ * ---------------------------------------------------------------------------------------------- */
+
+enum vidc_op_kind { VIDC_OP_CONV = 1, VIDC_OP_STEM = 2, VIDC_OP_MAXPOOL = 3, VIDC_OP_UPSAMPLE = 4, VIDC_OP_HEAD = 5,
+                    VIDC_OP_WARP_PARAMS = 6, VIDC_OP_WARP_FWD = 7, VIDC_OP_WARP_INV = 8, VIDC_OP_COPY = 9 };
+
+typedef struct vidc_generic_args {   /* arguments of the non-conv launchers, in declaration order */
+    const void* p[6];
+    int32_t i[16];
+    float f[8];
+} vidc_generic_args;
+
+typedef struct vidc_op {
+    int32_t kind;      /* vidc_op_kind */
+    int32_t stream_id; /* 0..VIDC_MAX_STREAMS-1: ops on different ids may overlap (fork/join by events) */
+    int32_t wait_mask; /* bit s set: wait for everything previously issued on stream id s */
+    int32_t reserved;
+    union {
+        vidc_conv_desc conv;
+        vidc_generic_args g;
+    } u;
+} vidc_op;
+
+#define VIDC_MAX_STREAMS 4
+
+typedef struct vidc_program vidc_program;
+int vidc_program_create(const vidc_op* ops, int n_ops, vidc_program** out);
+int vidc_program_run(vidc_program* p, vidc_stream_t stream);          /* eager: one launch per op            */
+int vidc_program_capture(vidc_program* p, vidc_stream_t stream);      /* records a hipGraph of the program    */
+int vidc_program_launch(vidc_program* p, vidc_stream_t stream);       /* replays the captured graph           */
+/* Times `iters` back-to-back executions with hipEvents on `stream`; ms_out[0] = average ms per execution,
+ * and (if per_op_ms != NULL, eager mode) per-op average durations. */
+int vidc_program_time(vidc_program* p, vidc_stream_t stream, int iters, int use_graph, float* ms_out, float* per_op_ms);
+int vidc_program_destroy(vidc_program* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDC_H */

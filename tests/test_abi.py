@@ -1,0 +1,87 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/vidc.h declares;
+host-side logic that needs no GPU (conv planning, RNG draws, program recording)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from vi_depth_completion_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L.build()
+    return L.lib()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "vidc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vidc_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.vidc_version() == 1
+    assert lib.vidc_last_error() is not None
+
+
+def test_struct_layout_matches_header():
+    # vidc_conv_desc: 9 pointers, 16 int32, 5 int64, 2 int32  (natural alignment)
+    assert C.sizeof(L.ConvDesc) == 9 * 8 + 16 * 4 + 5 * 8 + 2 * 4
+    assert C.sizeof(L.GenericArgs) == 6 * 8 + 16 * 4 + 8 * 4
+    assert C.sizeof(L.Op) == 16 + max(C.sizeof(L.ConvDesc), C.sizeof(L.GenericArgs))
+
+
+def test_error_reporting_without_gpu(lib):
+    assert lib.vidc_conv2d_bn_act(None, None) == -1
+    assert b"null" in lib.vidc_last_error()
+    d = L.ConvDesc()
+    d.x = d.w = d.y = d.scale1 = d.shift1 = 8
+    d.B, d.H, d.W, d.Cin, d.ldx, d.Ho, d.Wo, d.Cout, d.ldy = 1, 8, 8, 48, 48, 8, 8, 64, 64
+    d.KH = d.KW = d.stride = d.groups = d.splitk = 1
+    assert lib.vidc_conv2d_bn_act(C.byref(d), None) == -2
+    assert b"Cin" in lib.vidc_last_error()
+
+
+@pytest.mark.parametrize("M,N,K", [(4800, 768, 6912), (80, 3072, 27648), (300, 256, 2304), (19200, 64, 576), (4800, 64, 128)])
+def test_conv_plan_is_sane(lib, M, N, K):
+    d = L.ConvDesc()
+    d.B, d.Ho, d.Wo, d.Cout, d.Cin, d.KH, d.KW, d.groups = 1, 1, M, N, K, 1, 1, 1
+    assert lib.vidc_conv2d_plan(C.byref(d)) == 0
+    assert 1 <= d.tile < 7 and d.splitk >= 1
+    bm, bn = [int(v) for v in L.TILE_NAMES[d.tile].split("x")]
+    wgs = -(-M // bm) * -(-N // bn) * d.splitk
+    assert wgs >= min(64, (M // 32) * (N // 64))        # the planner must not leave most of the 256 CUs idle
+    if d.splitk > 1:
+        assert lib.vidc_conv2d_workspace_bytes(C.byref(d)) == d.splitk * M * N * 4
+
+
+def test_rng_draws_follow_reference_order():
+    """draw_normal_hypotheses / draw_enrichment consume np.random exactly like main.py:43 and :292."""
+    from vi_depth_completion_amd import plane, synthetic as S
+    ids = S.plane_id_map(240, 320)
+    np.random.seed(3)
+    slots, hyp = plane.draw_normal_hypotheses([ids])
+    np.random.seed(3)
+    flat = ids.reshape(-1)
+    exp = []
+    for cls in (1, 2):
+        pix = np.flatnonzero(flat == cls)
+        exp.append(pix[np.random.permutation(np.r_[0:len(pix)])[0:300]])
+    assert slots.tolist() == [[0, 1, 0, 300], [0, 2, 300, 300]]
+    assert np.array_equal(hyp, np.concatenate(exp))
+    np.random.seed(4)
+    sub, offs = plane.draw_enrichment([1000, 0, 50], 200)
+    np.random.seed(4)
+    e0 = np.unique(np.random.randint(0, 1000, size=200))
+    e2 = np.unique(np.random.randint(0, 50, size=50))
+    assert offs.tolist() == [0, len(e0), len(e0), len(e0) + len(e2)]
+    assert np.array_equal(sub, np.concatenate([e0, e2]))
+    # background-only map: no slots (main.py:135-137)
+    s2, h2 = plane.draw_normal_hypotheses([np.zeros((240, 320), np.uint8)])
+    assert s2.shape == (0, 4) and h2.size == 0

@@ -1,0 +1,350 @@
+"""GPU parity tests: the HIP path (through libvidc.so's C ABI) against the CPU oracle and the golden vectors.
+
+Tolerances (fp32 path, north_star: <= 1e-3 RMSE on the depth map):
+  * single kernels vs torch-CPU fp32:   2e-4 abs on O(1) data with K <= 4608 (fp32 summation-order noise)
+  * warp vs oracle on pure-noise images: 1e-3 abs max, 2e-5 mean (sampling positions differ by ~1e-4 px;
+    the images have unit gradient per pixel, real images are far smoother)
+  * networks vs oracle / golden:        normals 2e-4 abs max, depth RMSE <= 1e-4 (bar: 1e-3), max 1e-3
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vidc_oracle as O
+from vi_depth_completion_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda"
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# warp
+# ---------------------------------------------------------------------------------------------------------
+def _warp_inputs(golden_dir):
+    w = np.load(os.path.join(golden_dir, "warp_cases.npz"))
+    g, a = torch.from_numpy(w["gravity"]), torch.from_numpy(w["aligned"])
+    n = g.shape[0]
+    img = S.uniform01(1234, "warp.image", (1, 3, 240, 320)).repeat(n, 1, 1, 1)
+    nmap = S.normal01(1234, "warp.normalmap", (1, 3, 240, 320)).float().repeat(n, 1, 1, 1)
+    return w, g, a, img, nmap
+
+
+@pytest.mark.parametrize("align_corners", [False, True])
+def test_warp_forward_and_inverse(golden_dir, align_corners):
+    from vi_depth_completion_amd.networks.warping_2dof_alignment import Warping2DOFAlignment
+    w, g, a, img, nmap = _warp_inputs(golden_dir)
+    intr = O.Intrinsics(float(w["fx"]), float(w["fy"]), float(w["cx"]), float(w["cy"]))
+    wp = Warping2DOFAlignment(float(w["fx"]), float(w["fy"]), float(w["cx"]), float(w["cy"]), align_corners=align_corners)
+    H_or, y_or = O.warp_forward(img, g, a, intr, align_corners)
+    _, z_or = O.warp_inverse_normals(nmap, g, a, intr, align_corners)
+    H_hip, y_hip = wp.warp_with_gravity_center_aligned(img.to(DEV), g.to(DEV), a.to(DEV))
+    _, z_hip = wp.inverse_warp_normal_image_with_gravity_center_aligned(nmap.to(DEV), g.to(DEV), a.to(DEV))
+    assert (H_hip.cpu() - H_or).abs().max() <= 2e-5 * H_or.abs().max()
+    dy, dz = (y_hip.cpu() - y_or).abs(), (z_hip.cpu() - z_or).abs()
+    # the three extreme tilts (cases 8..10) magnify coordinate rounding; demo gravities are tight
+    assert dy[:8].max() < 1e-3 and dy[:8].mean() < 2e-5, (dy[:8].max(), dy[:8].mean())
+    assert dz[:8].max() < 3e-3 and dz[:8].mean() < 6e-5, (dz[:8].max(), dz[:8].mean())
+    assert dy.mean() < 1e-4 and dz.mean() < 3e-4
+    if not align_corners:   # golden vectors produced by the reference itself
+        for case in (0, 9):
+            assert np.abs(y_hip[case].cpu().numpy() - w["fwd_full_case%d" % case]).mean() < 1e-4
+            assert np.abs(z_hip[case].cpu().numpy() - w["inv_full_case%d" % case]).mean() < 3e-4
+        assert np.allclose(y_hip.double().flatten(1).sum(1).cpu().numpy(), w["fwd_sum"], rtol=1e-4, atol=2.0)
+    # 3-D input form (warping_2dof_alignment.py:110-112,153-154)
+    _, y3 = wp.warp_with_gravity_center_aligned(img[:2, 0].to(DEV), g[:2].to(DEV), a[:2].to(DEV))
+    assert y3.shape == (2, 240, 320) and torch.equal(y3, y_hip[:2, 0])
+
+
+def test_warp_identity_and_normalize():
+    """g == a -> identity rotation: forward warp reproduces the image (interior), inverse returns unit normals."""
+    from vi_depth_completion_amd.networks.warping_2dof_alignment import Warping2DOFAlignment
+    wp = Warping2DOFAlignment(202.0, 202.0, 159.5, 119.5, align_corners=True)
+    img = S.uniform01(7, "id.image", (2, 3, 240, 320)).to(DEV)
+    g = torch.tensor([[0.0, 1.0, 0.0], [0.0, 1.0, 0.0]], device=DEV)
+    Hm, y = wp.warp_with_gravity_center_aligned(img, g, g)
+    assert (Hm - torch.eye(3, device=DEV)).abs().max() < 1e-5
+    assert (y[..., 2:-2, 2:-2] - img[..., 2:-2, 2:-2]).abs().max() < 2e-3   # bbox scale kw=320/319 resamples slightly
+    _, z = wp.inverse_warp_normal_image_with_gravity_center_aligned(img, g, g, normalize=True)
+    n = z.norm(dim=1)
+    assert ((n - 1).abs() < 1e-5).float().mean() > 0.98
+
+
+# ---------------------------------------------------------------------------------------------------------
+# conv + BN + ReLU (fp32 MFMA implicit GEMM) vs torch CPU
+# ---------------------------------------------------------------------------------------------------------
+def _conv_case(seed, B, H, W, cin, cout, k, stride, groups=1):
+    x = S.normal01(seed, "x", (B, groups * cin, H, W)).float()
+    w = [S.normal01(seed, "w%d" % g, (cout, cin, k, k), scale=float(np.sqrt(2.0 / (cin * k * k)))).float() for g in range(groups)]
+    s1 = S.uniform01(seed, "s1", (groups, cout)) + 0.5
+    b1 = S.normal01(seed, "b1", (groups, cout)).float() * 0.1
+    return x, w, s1, b1
+
+
+def _ref_conv(x, w, s1, b1, k, stride, pad, groups):
+    cin = x.shape[1] // groups
+    outs = []
+    for g in range(groups):
+        y = F.conv2d(x[:, g * cin:(g + 1) * cin], w[g], None, stride, pad)
+        outs.append(y * s1[g].view(1, -1, 1, 1) + b1[g].view(1, -1, 1, 1))
+    return torch.cat(outs, 1)
+
+
+CONV_SHAPES = [
+    # B, H, W, cin, cout, k, stride, groups
+    (1, 60, 80, 128, 64, 1, 1, 1),      # layer1[0].conv1
+    (1, 60, 80, 64, 64, 3, 1, 1),       # layer1 3x3
+    (1, 60, 80, 128, 128, 3, 2, 1),     # layer2[0].conv2 (stride on the 3x3)
+    (1, 60, 80, 256, 512, 1, 2, 1),     # layer2[0].downsample
+    (1, 15, 20, 256, 1024, 1, 1, 3),    # layer3 1x1, three pyramids grouped
+    (2, 15, 20, 256, 256, 3, 1, 3),     # layer3 3x3 grouped, batch 2
+    (1, 8, 10, 512, 512, 3, 1, 1),      # layer4 3x3, M=80
+    (1, 8, 10, 1024, 192, 1, 1, 1),     # Cout=192 (not a multiple of 128)
+    (1, 9, 11, 64, 64, 3, 2, 1),        # odd sizes
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+def test_conv_tiles(shape, tile):
+    from vi_depth_completion_amd import ops
+    B, H, W, cin, cout, k, stride, groups = shape
+    x, w, s1, b1 = _conv_case(11, B, H, W, cin, cout, k, stride, groups)
+    pad = k // 2
+    ref = F.relu(_ref_conv(x, w, s1, b1, k, stride, pad, groups))
+    wp = torch.stack([ops.pack_conv_weight(wg.to(DEV)) for wg in w])
+    y = ops.conv2d_bn_act(nhwc(x).to(DEV), wp, s1.to(DEV), b1.to(DEV), k, k, stride, pad, relu1=True, tile=tile, groups=groups)
+    err = (nchw(y).cpu() - ref).abs().max().item()
+    assert err < 2e-4, err
+
+
+@pytest.mark.parametrize("splitk", [2, 4, 7])
+def test_conv_splitk_and_epilogue(splitk):
+    """split-K + every epilogue stage: affine1, relu, affine2, relu, residual, relu, accumulate."""
+    from vi_depth_completion_amd import ops
+    B, H, W, cin, cout, k, stride, groups = 1, 15, 20, 256, 256, 3, 1, 3
+    x, w, s1, b1 = _conv_case(5, B, H, W, cin, cout, k, stride, groups)
+    s2 = (S.uniform01(5, "s2", (groups, cout)) + 0.5)
+    b2 = S.normal01(5, "b2", (groups, cout)).float() * 0.1
+    res = S.normal01(5, "res", (B, groups * cout, H, W)).float()
+    acc0 = S.normal01(5, "acc", (B, groups * cout, H, W)).float()
+    t = F.relu(_ref_conv(x, w, s1, b1, k, stride, 1, groups))
+    t = F.relu(t * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1))
+    ref = acc0 + F.relu(t + res)
+    wp = torch.stack([ops.pack_conv_weight(wg.to(DEV)) for wg in w])
+    y = nhwc(acc0).to(DEV)
+    ops.conv2d_bn_act(nhwc(x).to(DEV), wp, s1.to(DEV), b1.to(DEV), k, k, stride, 1, relu1=True, scale2=s2.to(DEV), shift2=b2.to(DEV),
+                      relu2=True, residual=nhwc(res).to(DEV), relu3=True, accumulate_into=y, tile=4, splitk=splitk, groups=groups)
+    err = (nchw(y).cpu() - ref).abs().max().item()
+    assert err < 3e-4, err
+
+
+def test_conv_is_deterministic():
+    from vi_depth_completion_amd import ops
+    x, w, s1, b1 = _conv_case(3, 1, 30, 40, 128, 128, 3, 1)
+    wp = ops.pack_conv_weight(w[0].to(DEV))
+    a = ops.conv2d_bn_act(nhwc(x).to(DEV), wp, s1.to(DEV), b1.to(DEV), 3, 3, 1, 1, relu1=True, splitk=4, tile=4)
+    b = ops.conv2d_bn_act(nhwc(x).to(DEV), wp, s1.to(DEV), b1.to(DEV), 3, 3, 1, 1, relu1=True, splitk=4, tile=4)
+    assert torch.equal(a, b)
+
+
+def test_conv_rejects_bad_shapes():
+    from vi_depth_completion_amd import ops
+    x = torch.zeros(1, 8, 8, 48, device=DEV)      # Cin=48 is not a multiple of 32
+    w = torch.zeros(64, 48, device=DEV)
+    with pytest.raises(RuntimeError, match="Cin"):
+        ops.conv2d_bn_act(x, w, torch.ones(64, device=DEV), torch.zeros(64, device=DEV), 1, 1)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.conv2d_bn_act(x.cpu(), w.cpu(), torch.ones(64), torch.zeros(64), 1, 1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# glue kernels
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin", [1, 3])
+@pytest.mark.parametrize("hw", [(240, 320), (256, 320), (37, 53)])
+def test_stem_conv(cin, hw):
+    from vi_depth_completion_amd import ops
+    x = S.normal01(2, "stem.x", (2, cin, hw[0], hw[1])).float()
+    w = S.normal01(2, "stem.w", (64, cin, 3, 3), scale=0.3).float()
+    ref = F.relu(F.conv2d(x, w, None, 2, 1))
+    y = ops.stem_conv3x3s2(x.to(DEV), w.to(DEV), relu=True)
+    assert (nchw(y).cpu() - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("hw", [(120, 160), (128, 160), (7, 9)])
+def test_maxpool(hw):
+    from vi_depth_completion_amd import ops
+    x = S.normal01(4, "mp.x", (2, 128, hw[0], hw[1])).float()
+    ref = F.max_pool2d(x, 3, 2, 1)
+    assert torch.equal(nchw(ops.maxpool3x3s2(nhwc(x).to(DEV))).cpu(), ref)
+
+
+@pytest.mark.parametrize("sizes", [((8, 10), (15, 20)), ((15, 20), (30, 40)), ((30, 40), (60, 80)), ((8, 10), (16, 20)), ((5, 7), (5, 7))])
+def test_upsample(sizes):
+    from vi_depth_completion_amd import ops
+    (h, w), (H, W) = sizes
+    x = S.normal01(6, "up.x", (2, 64, h, w)).float()
+    ref = F.interpolate(x, size=(H, W), mode="bilinear", align_corners=True)
+    y = ops.upsample_bilinear_ac(nhwc(x).to(DEV), (H, W))
+    assert (nchw(y).cpu() - ref).abs().max() < 2e-6
+    base = S.normal01(6, "up.base", (2, 64, H, W)).float()
+    acc = nhwc(base).to(DEV)
+    ops.upsample_bilinear_ac(nhwc(x).to(DEV), (H, W), relu=True, accumulate_into=acc)
+    assert (nchw(acc).cpu() - (base + F.relu(ref))).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("cfg", [(64, 3, 0, False), (192, 1, 1, True)])
+def test_head(cfg):
+    from vi_depth_completion_amd import ops
+    cin, cout, pad, relu = cfg
+    x = S.normal01(8, "head.x", (2, cin, 60, 80)).float()
+    w = S.normal01(8, "head.w", (cout, cin, 1, 1), scale=0.1).float()
+    b = torch.full((cout,), 2.0) if cout == 1 else S.normal01(8, "head.b", (cout,)).float()
+    low_ref = F.conv2d(x, w, b, 1, pad)
+    ref = F.interpolate(low_ref, size=(240, 320), mode="bilinear", align_corners=True)
+    ref = F.relu(ref) if relu else ref
+    y, low = ops.head_conv1x1_upsample(nhwc(x).to(DEV), w.to(DEV), b.to(DEV), pad, (240, 320), relu)
+    assert low.shape == low_ref.shape
+    assert (low.cpu() - low_ref).abs().max() < 2e-5
+    assert (y.cpu() - ref).abs().max() < 2e-5
+    if pad:   # the reference's padded 1x1 conv: border ring == bias
+        assert torch.all(low[:, :, 0, :] == 2.0) and torch.all(low[:, :, :, -1] == 2.0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# networks and the whole path
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def pipeline(seeded_weights):
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    p = DepthCompletionPipeline(enriched_samples=200)
+    p.load_state_dicts(seeded_weights["sn"], seeded_weights["dc"])
+    p.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(240, 320))
+    return p
+
+
+def _golden_batch(f, name):
+    if name.startswith("demo_"):
+        img = torch.from_numpy(f["image_u8"]).permute(2, 0, 1).float().div(255)
+    else:
+        img = S.synthetic_batch(1, 240, 320, 1234)["image"][0]
+    sd = torch.zeros(240, 320)
+    rc = torch.from_numpy(f["sparse_rc"]).long()
+    sd[rc[:, 0], rc[:, 1]] = torch.from_numpy(f["sparse_val"])
+    return {"image": img[None], "sparse_depth": sd[None, None], "gravity": torch.from_numpy(f["gravity"])[None],
+            "aligned_direction": torch.from_numpy(f["aligned"])[None],
+            "homogeneous_coordinates": S.homogeneous_grid(S.DEMO_FC, S.DEMO_CC, 320, 240)[None]}
+
+
+GOLDEN_FRAMES = ["demo_000000", "demo_000068", "demo_000085", "synthetic_f0"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_FRAMES)
+def test_surface_normal_net_vs_golden(pipeline, golden_dir, name):
+    f = np.load(os.path.join(golden_dir, name + ".npz"))
+    b = _golden_batch(f, name)
+    n = pipeline.surface_normal_cnn(b["image"].to(DEV), b["gravity"].to(DEV), b["aligned_direction"].to(DEV))
+    d = np.abs(n[0].cpu().numpy() - f["normals"])
+    assert d.max() < 1e-3 and d.mean() < 2e-5, (d.max(), d.mean())
+    assert abs(float(n.norm(dim=1).mean()) - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("name", GOLDEN_FRAMES)
+def test_depth_completion_net_teacher_forced(pipeline, golden_dir, name):
+    """ModifiedFPN fed the reference's own normals and enriched depth: isolates the 337-conv depth network."""
+    f = np.load(os.path.join(golden_dir, name + ".npz"))
+    b = _golden_batch(f, name)
+    en = torch.zeros(240, 320)
+    rc = torch.from_numpy(f["enriched_rc"]).long()
+    en[rc[:, 0], rc[:, 1]] = torch.from_numpy(f["enriched_val"])
+    d = pipeline.cnn(b["image"].to(DEV), torch.from_numpy(f["normals"])[None].to(DEV), en[None, None].to(DEV))[0, 0].cpu().numpy()
+    rmse = float(np.sqrt(np.mean((d - f["depth"]) ** 2)))
+    assert rmse < 1e-4 and np.abs(d - f["depth"]).max() < 1e-3, (rmse, np.abs(d - f["depth"]).max())
+
+
+@pytest.mark.parametrize("name", GOLDEN_FRAMES)
+def test_plane_block_vs_golden(pipeline, golden_dir, name):
+    """Plane block fed the reference's normals; RNG stream seeded like the golden run."""
+    f = np.load(os.path.join(golden_dir, name + ".npz"))
+    b = _golden_batch(f, name)
+    np.random.seed(int(f["np_seed"]))
+    normals = torch.from_numpy(f["normals"])[None].to(DEV)
+    ds = b["sparse_depth"].to(DEV)
+    di, nnz = pipeline.planes.plane_depth(normals, [S.plane_id_map(240, 320)], ds, b["homogeneous_coordinates"].to(DEV))
+    rec = pipeline.planes.last_records.cpu().numpy()
+    for s, slot in enumerate(pipeline.planes.last_slots):
+        p = "plane%d" % slot[1]
+        sc = f[p + ".scalars"]    # n_inl, mean_angle, accepted, offset, n_off_inl, valid
+        assert np.abs(rec[s, 0:3] - f[p + ".n_bar"]).max() < 2e-5
+        assert abs(rec[s, 4] - sc[0]) <= 3 and abs(rec[s, 5] - sc[1]) < 1e-2
+        assert bool(rec[s, 6]) == bool(sc[2]) and abs(rec[s, 3] - sc[3]) < 2e-4
+        assert rec[s, 9] == sc[4] and (rec[s, 10] == 1.0) == bool(sc[5])
+    assert abs(int(nnz[0]) - int(f["plane_depth_nnz"])) <= 3
+    pd = f["plane_depth_f16"].astype(np.float32)
+    d = np.abs(di[0, 0].cpu().numpy() - pd)
+    assert np.mean(d > 5e-3 * np.maximum(pd, 1.0)) < 1e-3          # fp16 golden copy: 5e-3 relative, <0.1% outliers
+    assert abs(float(di.double().sum()) - float(f["plane_depth_sum"])) < 1e-4 * float(f["plane_depth_sum"]) + 20.0
+    if int(nnz[0]) == int(f["enrich.nnz"]):                          # same candidate count -> identical draws
+        en = pipeline.planes.enrich(ds, di, nnz, 200)
+        assert np.array_equal(pipeline.planes.last_sub[0], f["enrich.sub"])
+        rc = f["enriched_rc"]
+        e = en[0, 0].cpu().numpy()
+        assert int((e != 0).sum()) == len(rc)
+        assert np.abs(e[rc[:, 0], rc[:, 1]] - f["enriched_val"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("name", GOLDEN_FRAMES)
+def test_full_path_vs_golden(pipeline, golden_dir, name):
+    """The whole _call_cnn (main.py:261-298): RMSE vs the reference's depth <= 1e-3 (north_star bar)."""
+    f = np.load(os.path.join(golden_dir, name + ".npz"))
+    b = _golden_batch(f, name)
+    np.random.seed(int(f["np_seed"]))
+    taps = {}
+    d = pipeline._call_cnn(b, taps=taps)[0, 0].cpu().numpy()
+    rmse = float(np.sqrt(np.mean((d - f["depth"]) ** 2)))
+    assert rmse < 1e-3, rmse
+    assert d.min() >= 0.0
+
+
+def test_full_path_vs_oracle_batch2(pipeline, seeded_weights):
+    """Batch of 2 synthetic frames through HIP and through the oracle with the same RNG stream."""
+    batch = S.synthetic_batch(2, 240, 320, 1234, frame0=3)
+    masks = [S.plane_id_map(240, 320)] * 2
+    intr = O.Intrinsics(202.0, 202.0, 0.5 * 319.87654, 0.5 * 239.87603)
+    np.random.seed(5)
+    ref = O.call_cnn(seeded_weights["sn"], seeded_weights["dc"], batch, masks, intr, 200)
+    np.random.seed(5)
+    out = pipeline._call_cnn(batch).cpu()
+    rmse = float((out - ref).pow(2).mean().sqrt())
+    assert rmse < 1e-3, rmse
+
+
+def test_graph_and_eager_agree(pipeline, monkeypatch):
+    batch = S.synthetic_batch(1, 240, 320, 1234, frame0=9)
+    x = (batch["image"].to(DEV), batch["gravity"].to(DEV), batch["aligned_direction"].to(DEV))
+    monkeypatch.setenv("VIDC_EXEC", "graph")
+    a = pipeline.surface_normal_cnn(*x)
+    monkeypatch.setenv("VIDC_EXEC", "eager")
+    b = pipeline.surface_normal_cnn(*x)
+    assert torch.equal(a, b)
+
+
+def test_modules_refuse_cpu_and_training(pipeline):
+    with pytest.raises(RuntimeError, match="GPU"):
+        pipeline.cnn(torch.zeros(1, 3, 240, 320), torch.zeros(1, 3, 240, 320), torch.zeros(1, 1, 240, 320))
+    pipeline.cnn.train()
+    with pytest.raises(RuntimeError, match="inference-only"):
+        pipeline.cnn(torch.zeros(1, 3, 240, 320, device=DEV), torch.zeros(1, 3, 240, 320, device=DEV), torch.zeros(1, 1, 240, 320, device=DEV))
+    pipeline.cnn.eval()

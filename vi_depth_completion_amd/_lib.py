@@ -1,0 +1,133 @@
+"""ctypes binding of libvidc.so (the C ABI declared in include/vidc.h).
+
+There is no fallback: if the library is missing or a call fails, a RuntimeError is raised.
+`build()` compiles it in-tree with hipcc for gfx950 (also used by __graft_entry__.build()).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvidc.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+WARP_PARAMS = 32
+MAX_HYP = 300
+PLANE_RECORD = 16
+MAX_STREAMS = 4
+
+# vidc_conv_flags / vidc_up_flags / vidc_op_kind / vidc_conv_tile
+RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM = 1, 2, 4, 8, 16, 32
+UP_RELU, UP_ACCUM = 1, 2
+OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY = range(1, 10)
+TILE_AUTO = 0
+TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "32x128", 6: "32x64"}
+
+_f32p = C.POINTER(C.c_float)
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p),
+        ("scale1", C.c_void_p), ("shift1", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
+        ("residual", C.c_void_p), ("workspace", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("ldx", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32), ("ldy", C.c_int32), ("ldr", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("flags", C.c_int32), ("groups", C.c_int32),
+        ("x_gs", C.c_int64), ("w_gs", C.c_int64), ("y_gs", C.c_int64), ("r_gs", C.c_int64), ("p_gs", C.c_int64),
+        ("tile", C.c_int32), ("splitk", C.c_int32),
+    ]
+
+
+class GenericArgs(C.Structure):
+    _fields_ = [("p", C.c_void_p * 6), ("i", C.c_int32 * 16), ("f", C.c_float * 8)]
+
+
+class _OpUnion(C.Union):
+    _fields_ = [("conv", ConvDesc), ("g", GenericArgs)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("stream_id", C.c_int32), ("wait_mask", C.c_int32), ("reserved", C.c_int32),
+                ("u", _OpUnion)]
+
+
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+# name -> (restype, argtypes); every symbol include/vidc.h declares
+SIGNATURES = {
+    "vidc_version": (C.c_int, []),
+    "vidc_last_error": (C.c_char_p, []),
+    "vidc_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, _i]),
+    "vidc_warp2dof_params": (C.c_int, [_vp, _vp, _i, _f, _f, _f, _f, _vp, _i, _i, _vp, _vp]),
+    "vidc_warp2dof_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
+    "vidc_warp2dof_inv_rot_norm": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp]),
+    "vidc_pack_conv_weight": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vidc_conv2d_bn_act": (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    "vidc_conv2d_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "vidc_conv2d_plan": (C.c_int, [C.POINTER(ConvDesc)]),
+    "vidc_stem_conv3x3s2": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vidc_maxpool3x3s2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "vidc_upsample_bilinear_ac": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vidc_head_conv1x1_upsample": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vidc_plane_ransac_normal": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "vidc_plane_offset": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "vidc_plane_project_depth": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "vidc_plane_finalize": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp]),
+    "vidc_enrich_scatter": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "vidc_program_create": (C.c_int, [C.POINTER(Op), _i, C.POINTER(_vp)]),
+    "vidc_program_run": (C.c_int, [_vp, _vp]),
+    "vidc_program_capture": (C.c_int, [_vp, _vp]),
+    "vidc_program_launch": (C.c_int, [_vp, _vp]),
+    "vidc_program_time": (C.c_int, [_vp, _vp, _i, _i, _f32p, _f32p]),
+    "vidc_program_destroy": (C.c_int, [_vp]),
+}
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile libvidc.so in-tree: hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "vidc.h"))
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    cmd = ["make", "-C", CSRC, "-j%d" % min(8, os.cpu_count() or 1)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+    if r.returncode != 0:
+        raise RuntimeError("building libvidc.so failed (hipcc, gfx950)")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libvidc.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                               "There is no CPU/eager fallback for the HIP path." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)     # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if L.vidc_version() != 1:
+            raise RuntimeError("libvidc.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("libvidc %s failed (status %d): %s" % (what, rc, lib().vidc_last_error().decode()))
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,228 @@
+// HBM-bound glue kernels of the two networks: stem conv (Cin 1/3), 3x3/s2 max-pool, bilinear align_corners=True
+// upsample, and the prediction-head tail (1x1 conv with few outputs as a wavefront reduction + final upsample).
+// All NHWC fp32 with 16-byte per-lane accesses where the layout allows.
+#include "common.h"
+
+namespace {
+
+// ---- stem: 3x3 stride-2 pad-1 conv, Cin in {1,3}, NCHW in -> NHWC out (networks/surface_normal.py:17-18) --------
+// One workgroup = 64 output pixels of one row segment x all Cout (<=64 per pass) channels.  The 27 (or 9) weights of
+// a lane's output channel live in registers; the input patch is staged in LDS and broadcast.
+template <int CIN>
+__global__ void __launch_bounds__(256)
+stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int H, int W, int Ho, int Wo,
+                 int Cout, int ldy, int relu) {
+    constexpr int PIX = 64;                 // output pixels per workgroup (along X)
+    constexpr int PW = 2 * PIX + 1;         // input patch width
+    __shared__ float patch[CIN][3][PW + 3];
+    const int b = blockIdx.z, oy = blockIdx.y, ox0 = blockIdx.x * PIX;
+    const int tid = threadIdx.x;
+    const size_t plane = (size_t)H * W;
+    const float* xb = x + (size_t)b * CIN * plane;
+    const int ix_base = ox0 * 2 - 1, iy_base = oy * 2 - 1;
+    for (int e = tid; e < CIN * 3 * PW; e += 256) {
+        int c = e / (3 * PW), r = (e / PW) % 3, i = e % PW;
+        int iy = iy_base + r, ix = ix_base + i;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[c * plane + (size_t)iy * W + ix];
+        patch[c][r][i] = v;
+    }
+    __syncthreads();
+    const int co = tid & 63, pgrp = tid >> 6;      // lanes run along channels -> 256-byte coalesced NHWC stores
+    for (int cbase = 0; cbase < Cout; cbase += 64) {
+        const int c_out = cbase + co;
+        float wr[CIN * 9];
+        if (c_out < Cout) {
+#pragma unroll
+            for (int k = 0; k < CIN * 9; ++k) wr[k] = w[(size_t)c_out * CIN * 9 + k];
+        }
+        for (int p = pgrp; p < PIX; p += 4) {
+            const int ox = ox0 + p;
+            if (ox >= Wo || c_out >= Cout) continue;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) acc += patch[c][r][2 * p + s] * wr[(c * 3 + r) * 3 + s];
+            if (relu) acc = fmaxf(acc, 0.f);
+            y[((size_t)(b * Ho + oy) * Wo + ox) * ldy + c_out] = acc;
+        }
+    }
+}
+
+// ---- max-pool 3x3 stride 2 pad 1, NHWC -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int ldx, int Ho, int Wo, int ldy) {
+    const int q = C / 4;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * Ho * Wo * q;
+    if (idx >= total) return;
+    const int c = (int)(idx % q) * 4;
+    long long t = idx / q;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        int iy = oy * 2 - 1 + r;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            int ix = ox * 2 - 1 + s;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            float4 v = *reinterpret_cast<const float4*>(&x[((size_t)(b * H + iy) * W + ix) * ldx + c]);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    *reinterpret_cast<float4*>(&y[((size_t)(b * Ho + oy) * Wo + ox) * ldy + c]) = m;
+}
+
+// ---- bilinear upsample, align_corners=True (nn.UpsamplingBilinear2d), NHWC ---------------------------------------
+// ATen's area_pixel_compute_source_index(scale=(in-1)/(out-1), dst, align_corners=true) = scale*dst.
+__device__ inline void src_index(int dst, int in, int out, int& i0, int& i1, float& l1) {
+    float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    float s = scale * (float)dst;
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+__global__ void __launch_bounds__(256)
+upsample_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int h, int w, int C, int ldx, int H, int W, int ldy,
+                int flags) {
+    const int q = C / 4;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * H * W * q;
+    if (idx >= total) return;
+    const int c = (int)(idx % q) * 4;
+    long long t = idx / q;
+    const int ox = (int)(t % W); t /= W;
+    const int oy = (int)(t % H);
+    const int b = (int)(t / H);
+    int y0, y1, x0, x1; float ly, lx;
+    src_index(oy, h, H, y0, y1, ly);
+    src_index(ox, w, W, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* xb = x + (size_t)b * h * w * ldx + c;
+    float4 v00 = *reinterpret_cast<const float4*>(xb + ((size_t)y0 * w + x0) * ldx);
+    float4 v01 = *reinterpret_cast<const float4*>(xb + ((size_t)y0 * w + x1) * ldx);
+    float4 v10 = *reinterpret_cast<const float4*>(xb + ((size_t)y1 * w + x0) * ldx);
+    float4 v11 = *reinterpret_cast<const float4*>(xb + ((size_t)y1 * w + x1) * ldx);
+    float4 o;
+    o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+    o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+    o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+    o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+    if (flags & VIDC_UP_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    float4* dst = reinterpret_cast<float4*>(&y[((size_t)(b * H + oy) * W + ox) * ldy + c]);
+    if (flags & VIDC_UP_ACCUM) { float4 p = *dst; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    *dst = o;
+}
+
+// ---- head: 1x1 conv to <=4 channels with zero padding, one wavefront per low-res pixel ------------------------------
+// (the "wavefront-reduction" part of the path: each lane owns Cin/64 channels, DPP/shuffle tree over 64 lanes)
+__global__ void __launch_bounds__(256)
+head_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ low,
+                 int B, int h, int wd, int Cin, int ldx, int Cout, int pad) {
+    const int hp = h + 2 * pad, wp = wd + 2 * pad;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int total = B * hp * wp;
+    if (wave >= total) return;
+    const int px = wave % wp, py = (wave / wp) % hp, b = wave / (wp * hp);
+    const int iy = py - pad, ix = px - pad;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)wd) {
+        const float* xp = x + ((size_t)(b * h + iy) * wd + ix) * ldx;
+        for (int c = lane; c < Cin; c += 64) {
+            float v = xp[c];
+            for (int o = 0; o < Cout; ++o) acc[o] += v * w[o * Cin + c];
+        }
+    }
+    for (int o = 0; o < Cout; ++o) {
+        float v = acc[o];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) low[((size_t)(b * Cout + o) * hp + py) * wp + px] = v + bias[o];
+    }
+}
+
+// final UpsamplingBilinear2d(size=(H,W)) of the small NCHW map, optional ReLU, NCHW out (coalesced along X)
+__global__ void __launch_bounds__(256)
+head_upsample_kernel(const float* __restrict__ low, float* __restrict__ y, int BC, int h, int w, int H, int W, int relu) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)BC * H * W) return;
+    const int ox = (int)(idx % W);
+    const int oy = (int)((idx / W) % H);
+    const int bc = (int)(idx / ((long long)W * H));
+    int y0, y1, x0, x1; float ly, lx;
+    src_index(oy, h, H, y0, y1, ly);
+    src_index(ox, w, W, x0, x1, lx);
+    const float* p = low + (size_t)bc * h * w;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    float v = hy * (hx * p[y0 * w + x0] + lx * p[y0 * w + x1]) + ly * (hx * p[y1 * w + x0] + lx * p[y1 * w + x1]);
+    if (relu) v = fmaxf(v, 0.f);
+    y[idx] = v;
+}
+
+}  // namespace
+
+extern "C" int vidc_stem_conv3x3s2(const float* x, const float* w_oihw, float* y, int B, int Cin, int H, int W, int Cout, int ldy,
+                                   int relu, vidc_stream_t stream) {
+    VIDC_REQUIRE(x && w_oihw && y, VIDC_ERR_NULL, "vidc_stem_conv3x3s2: null pointer");
+    VIDC_REQUIRE((Cin == 1 || Cin == 3) && B > 0 && H > 2 && W > 2 && Cout > 0 && ldy >= Cout, VIDC_ERR_SHAPE,
+                 "vidc_stem_conv3x3s2: unsupported shape (Cin=%d must be 1 or 3)", Cin);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    dim3 grid(vidc::cdiv(Wo, 64), Ho, B);
+    if (Cin == 3)
+        hipLaunchKernelGGL(stem_conv_kernel<3>, grid, dim3(256), 0, vidc::as_stream(stream), x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu);
+    else
+        hipLaunchKernelGGL(stem_conv_kernel<1>, grid, dim3(256), 0, vidc::as_stream(stream), x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu);
+    VIDC_CHECK_LAUNCH("stem_conv_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, vidc_stream_t stream) {
+    VIDC_REQUIRE(x && y, VIDC_ERR_NULL, "vidc_maxpool3x3s2: null pointer");
+    VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C,
+                 VIDC_ERR_SHAPE, "vidc_maxpool3x3s2: bad shape (C, ldx, ldy must be multiples of 4)");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    long long total = (long long)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vidc::as_stream(stream), x, y, B, H, W,
+                       C, ldx, Ho, Wo, ldy);
+    VIDC_CHECK_LAUNCH("maxpool_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_upsample_bilinear_ac(const float* x, float* y, int B, int h, int w, int C, int ldx, int H, int W, int ldy,
+                                         int flags, vidc_stream_t stream) {
+    VIDC_REQUIRE(x && y, VIDC_ERR_NULL, "vidc_upsample_bilinear_ac: null pointer");
+    VIDC_REQUIRE(B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, VIDC_ERR_SHAPE,
+                 "vidc_upsample_bilinear_ac: bad shape");
+    long long total = (long long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vidc::as_stream(stream), x, y, B, h, w,
+                       C, ldx, H, W, ldy, flags);
+    VIDC_CHECK_LAUNCH("upsample_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_head_conv1x1_upsample(const float* x, const float* w, const float* bias, float* lowres, float* y, int B, int h,
+                                          int w_in, int Cin, int ldx, int Cout, int pad, int H, int W, int relu,
+                                          vidc_stream_t stream) {
+    VIDC_REQUIRE(x && w && bias && lowres && y, VIDC_ERR_NULL, "vidc_head_conv1x1_upsample: null pointer");
+    VIDC_REQUIRE(B > 0 && h > 0 && w_in > 0 && Cin > 0 && Cout >= 1 && Cout <= 4 && pad >= 0 && H > 0 && W > 0, VIDC_ERR_SHAPE,
+                 "vidc_head_conv1x1_upsample: bad shape (Cout must be 1..4)");
+    const int hp = h + 2 * pad, wp = w_in + 2 * pad;
+    const int waves = B * hp * wp;
+    hipLaunchKernelGGL(head_conv_kernel, dim3(vidc::cdiv(waves, 4)), dim3(256), 0, vidc::as_stream(stream), x, w, bias, lowres, B, h,
+                       w_in, Cin, ldx, Cout, pad);
+    VIDC_CHECK_LAUNCH("head_conv_kernel");
+    long long total = (long long)B * Cout * H * W;
+    hipLaunchKernelGGL(head_upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vidc::as_stream(stream), lowres, y,
+                       B * Cout, hp, wp, H, W, relu);
+    VIDC_CHECK_LAUNCH("head_upsample_kernel");
+    return VIDC_OK;
+}

@@ -1,0 +1,446 @@
+"""Host side of the HIP engine: records a network as a `Program` (array of C launch descriptors over
+device buffers), plans buffers, folds BatchNorm, packs weights, and runs the whole thing through ONE
+C-ABI call per frame (`vidc_program_run` / hipGraph replay).  PyTorch is used for device memory and
+streams only; there is no eager or CPU execution path here.
+
+Layout: activations are NHWC fp32.  A "grouped" tensor (G > 1) keeps the G groups as channel slices of
+one [B,H,W,G*C] buffer, so the rgb/normal/depth pyramids of ModifiedFPN run as one grouped launch per
+layer and `torch.cat((rgb, normal, depth), dim=1)` (depth_completion.py:151-152) costs nothing.
+"""
+import ctypes as C
+import json
+import os
+
+import torch
+
+from . import _lib as L
+
+
+class K(tuple):
+    """Tuple of parameter-name prefixes (one per group); `K + 'conv1'` appends to every member."""
+
+    def __new__(cls, items):
+        return super().__new__(cls, (items,) if isinstance(items, str) else tuple(items))
+
+    def __add__(self, s):
+        return K(p + s for p in self)
+
+
+def _keys(k):
+    return k if isinstance(k, K) else K(k)
+
+
+class T:
+    """Program tensor: NHWC view (channel slice) of a planned buffer; NCHW for program inputs/outputs."""
+    __slots__ = ("buf", "B", "H", "W", "C", "G", "ld", "ch_off", "nchw")
+
+    def __init__(self, buf, B, H, W, Cc, G=1, ld=None, ch_off=0, nchw=False):
+        self.buf, self.B, self.H, self.W, self.C, self.G = buf, B, H, W, Cc, G
+        self.ld = ld if ld is not None else G * Cc
+        self.ch_off, self.nchw = ch_off, nchw
+
+    @property
+    def numel(self):
+        return self.B * self.H * self.W * self.ld
+
+
+class WeightStore:
+    """Device-resident derived parameters of one nn.Module: packed conv weights and folded BN affines.
+    Rebuilt lazily after `invalidate()` (load_state_dict / .cuda() / .to())."""
+
+    def __init__(self, module):
+        self.module = module
+        self._cache = {}
+        self._sd = None
+
+    def invalidate(self):
+        self._cache.clear()
+        self._sd = None
+
+    def sd(self):
+        if self._sd is None:
+            self._sd = {k: v.detach() for k, v in self.module.state_dict().items()}
+        return self._sd
+
+    def raw(self, key):
+        return self.sd()[key]
+
+    def packed(self, keys):
+        """[G][Cout][KH][KW][Cin] fp32, packed by the C kernel."""
+        ck = ("w",) + tuple(keys)
+        if ck not in self._cache:
+            ws = [self.sd()[k + ".weight"].contiguous() for k in keys]
+            co, ci, kh, kw = ws[0].shape
+            out = torch.empty((len(ws), co, kh * kw * ci), dtype=torch.float32, device=ws[0].device)
+            for g, w in enumerate(ws):
+                assert tuple(w.shape) == (co, ci, kh, kw)
+                L.check(L.lib().vidc_pack_conv_weight(L.ptr(w), L.ptr(out[g]), co, ci, kh, kw, L.current_stream()), "pack")
+            self._cache[ck] = out
+        return self._cache[ck]
+
+    def affine(self, conv_keys, bn_keys):
+        """Per-output-channel (scale, shift) [G][Cout] for conv(+bias) followed by eval-mode BN, folded in fp64."""
+        ck = ("a",) + tuple(conv_keys) + tuple(bn_keys or ())
+        if ck not in self._cache:
+            sd = self.sd()
+            scales, shifts = [], []
+            for g, ckey in enumerate(conv_keys):
+                co = sd[ckey + ".weight"].shape[0] if ckey is not None else sd[bn_keys[g] + ".weight"].shape[0]
+                dev = sd[(ckey or bn_keys[g]) + ".weight"].device
+                bias = sd.get(ckey + ".bias") if ckey is not None else None
+                bias = bias.double() if bias is not None else torch.zeros(co, dtype=torch.float64, device=dev)
+                if bn_keys is not None:
+                    bn = bn_keys[g]
+                    s = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + 1e-5)
+                    t = sd[bn + ".bias"].double() - sd[bn + ".running_mean"].double() * s + bias * s
+                else:
+                    s, t = torch.ones(co, dtype=torch.float64, device=dev), bias
+                scales.append(s.float())
+                shifts.append(t.float())
+            self._cache[ck] = (torch.stack(scales).contiguous(), torch.stack(shifts).contiguous())
+        return self._cache[ck]
+
+
+_TUNING = None
+
+
+def tuning_table():
+    """Optional per-shape (tile, splitk) overrides measured on MI355X (tools/autotune.py writes it)."""
+    global _TUNING
+    if _TUNING is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tuning.json")
+        _TUNING = json.load(open(path)) if os.path.exists(path) else {}
+    return _TUNING
+
+
+def conv_signature(d):
+    return "M%d_N%d_K%d_k%ds%d_G%d" % (d.B * d.Ho * d.Wo, d.Cout, d.KH * d.KW * d.Cin, d.KH, d.stride, d.groups)
+
+
+class Program:
+    """Records ops symbolically (buffers are integers), then `finalize()` plans memory and builds the C program."""
+
+    def __init__(self, weights, device, batch, reuse_buffers=True):
+        self.ws, self.device, self.B = weights, device, batch
+        self.ops = []            # (kind, dict)
+        self.buf_elems = []      # elements per buffer id
+        self.pinned = set()      # buffer ids that must not alias (inputs / outputs)
+        self.inputs, self.outputs = {}, {}
+        self.reuse = reuse_buffers
+        self.stream_id = 0
+        self.wait_mask = 0
+        self.handle = None
+        self.flops = 0           # executed conv FLOPs (2*M*N*K summed)
+        self._keep = []
+
+    # ---- buffers ----------------------------------------------------------------------------------------
+    def _new_buf(self, elems, pinned=False):
+        self.buf_elems.append(int(elems))
+        if pinned:
+            self.pinned.add(len(self.buf_elems) - 1)
+        return len(self.buf_elems) - 1
+
+    def input_nchw(self, name, Cc, H, W):
+        t = T(self._new_buf(self.B * Cc * H * W, True), self.B, H, W, Cc, nchw=True)
+        self.inputs[name] = t
+        return t
+
+    def input_raw(self, name, elems):
+        t = T(self._new_buf(elems, True), 1, 1, 1, elems)
+        self.inputs[name] = t
+        return t
+
+    def mark_output(self, name, t):
+        self.pinned.add(t.buf)
+        self.outputs[name] = t
+
+    def nhwc(self, H, W, Cc, G=1):
+        return T(self._new_buf(self.B * H * W * G * Cc), self.B, H, W, Cc, G)
+
+    def on_stream(self, sid, wait_mask=0):
+        self.stream_id, self.wait_mask = sid, wait_mask
+
+    def _emit(self, kind, reads, writes, **kw):
+        kw.update(stream_id=self.stream_id, wait_mask=self.wait_mask)
+        self.wait_mask = 0
+        self.ops.append((kind, [t.buf for t in reads if t is not None], [t.buf for t in writes], kw))
+
+    # ---- ops ---------------------------------------------------------------------------------------------
+    def conv(self, x, key, bn=None, relu=False, stride=1, padding=0, bn2=None, relu2=False, residual=None,
+             relu_after_residual=False, out=None, accumulate=False):
+        keys = _keys(key)
+        G = len(keys)
+        assert x.G == G and not x.nchw
+        w0 = self.ws.raw(keys[0] + ".weight")
+        co, ci, kh, kw = w0.shape
+        assert ci == x.C, "conv %s expects Cin=%d, got %d" % (keys[0], ci, x.C)
+        Ho = (x.H + 2 * padding - kh) // stride + 1
+        Wo = (x.W + 2 * padding - kw) // stride + 1
+        y = out if out is not None else self.nhwc(Ho, Wo, co, G)
+        assert (y.H, y.W, y.C, y.G) == (Ho, Wo, co, G)
+        flags = (L.RELU1 if relu else 0) | (L.AFFINE2 if bn2 is not None else 0) | (L.RELU2 if relu2 else 0)
+        if residual is not None:
+            assert (residual.H, residual.W, residual.C, residual.G) == (Ho, Wo, co, G)
+            flags |= L.RESIDUAL | (L.RELU3 if relu_after_residual else 0)
+        if accumulate:
+            flags |= L.ACCUM
+        self.flops += 2 * self.B * Ho * Wo * co * ci * kh * kw * G
+        self._emit("conv", [x, residual, y if accumulate else None], [y], x=x, y=y, keys=keys,
+                   bn=_keys(bn) if bn is not None else None, bn2=_keys(bn2) if bn2 is not None else None,
+                   residual=residual, flags=flags, stride=stride, pad=padding, geom=(co, ci, kh, kw, Ho, Wo))
+        return y
+
+    def stem_conv(self, xs, key, relu=True, x_is_nchw=True):
+        """xs: one NCHW tensor or a list (one per group, Cin may differ: 3,3,1)."""
+        keys = _keys(key)
+        xs = xs if isinstance(xs, (list, tuple)) else [xs]
+        G = len(keys)
+        assert len(xs) == G and x_is_nchw
+        co = self.ws.raw(keys[0] + ".weight").shape[0]
+        H, W = xs[0].H, xs[0].W
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        y = self.nhwc(Ho, Wo, co, G)
+        for g in range(G):
+            self._emit("stem", [xs[g]], [y], x=xs[g], y=y, key=keys[g], g=g, relu=relu)
+        return y
+
+    def maxpool(self, x):
+        Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
+        y = self.nhwc(Ho, Wo, x.C, x.G)
+        self._emit("maxpool", [x], [y], x=x, y=y)
+        return y
+
+    def upsample(self, x, size, relu=False, into=None):
+        """UpsamplingBilinear2d(size).  `into`: accumulate (+=) into an existing tensor instead of a new one."""
+        y = into if into is not None else self.nhwc(size[0], size[1], x.C, x.G)
+        assert (y.H, y.W, y.C * y.G) == (size[0], size[1], x.C * x.G)
+        flags = (L.UP_RELU if relu else 0) | (L.UP_ACCUM if into is not None else 0)
+        self._emit("upsample", [x, into], [y], x=x, y=y, flags=flags)
+        return y
+
+    def head(self, x, key, pad, out_size, relu):
+        """1x1 conv to <=4 channels (+pad) -> upsample to out_size -> [relu]; returns the NCHW output tensor."""
+        w = self.ws.raw(key + ".weight")
+        co, ci = w.shape[0], w.shape[1]
+        assert ci == x.C * x.G
+        hp, wp = x.H + 2 * pad, x.W + 2 * pad
+        low = T(self._new_buf(self.B * co * hp * wp), self.B, hp, wp, co, nchw=True)
+        y = T(self._new_buf(self.B * co * out_size[0] * out_size[1]), self.B, out_size[0], out_size[1], co, nchw=True)
+        self._emit("head", [x], [low, y], x=x, low=low, y=y, key=key, pad=pad, relu=relu)
+        return y, low
+
+    def warp_params(self, g, a, intr, kinv):
+        p = T(self._new_buf(self.B * L.WARP_PARAMS), 1, 1, 1, self.B * L.WARP_PARAMS)
+        self._emit("warp_params", [g, a, kinv], [p], g=g, a=a, kinv=kinv, p=p, intr=intr)
+        return p
+
+    def warp_fwd(self, x, params, intr, align_corners):
+        y = T(self._new_buf(x.B * x.C * x.H * x.W), x.B, x.H, x.W, x.C, nchw=True)
+        self._emit("warp_fwd", [x, params], [y], x=x, p=params, y=y, intr=intr, ac=int(align_corners))
+        return y
+
+    def warp_inv(self, x, params, intr, align_corners, normalize=True):
+        y = T(self._new_buf(x.B * 3 * x.H * x.W), x.B, x.H, x.W, 3, nchw=True)
+        self._emit("warp_inv", [x, params], [y], x=x, p=params, y=y, intr=intr, ac=int(align_corners), norm=int(normalize))
+        return y
+
+    def copy(self, src, dst):
+        self._emit("copy", [src], [dst], src=src, dst=dst)
+
+    # ---- planning ----------------------------------------------------------------------------------------
+    def _plan_buffers(self):
+        n = len(self.buf_elems)
+        multi_stream = any(kw["stream_id"] != 0 for _, _, _, kw in self.ops)
+        storage = [None] * n
+        if not self.reuse or multi_stream:
+            for b in range(n):
+                storage[b] = torch.zeros(max(self.buf_elems[b], 4), dtype=torch.float32, device=self.device)
+            return storage
+        last = [-1] * n
+        first = [None] * n
+        for i, (_, reads, writes, _) in enumerate(self.ops):
+            for b in reads + writes:
+                last[b] = i
+                if first[b] is None:
+                    first[b] = i
+        free = []   # (elems, tensor)
+        expire = {}
+        for b in range(n):
+            if b in self.pinned or first[b] is None:
+                storage[b] = torch.zeros(max(self.buf_elems[b], 4), dtype=torch.float32, device=self.device)
+            else:
+                expire.setdefault(last[b], []).append(b)
+        for i, (_, reads, writes, _) in enumerate(self.ops):
+            for b in writes + reads:
+                if storage[b] is None:
+                    need = self.buf_elems[b]
+                    best = None
+                    for j, (el, _t) in enumerate(free):
+                        if el >= need and (best is None or el < free[best][0]):
+                            best = j
+                    if best is not None:
+                        storage[b] = free.pop(best)[1]
+                    else:
+                        storage[b] = torch.zeros(max(need, 4), dtype=torch.float32, device=self.device)
+            for b in expire.get(i, []):
+                free.append((storage[b].numel(), storage[b]))
+        return storage
+
+    def finalize(self):
+        lib = L.lib()
+        storage = self._plan_buffers()
+        self.storage = storage
+        self.bytes_allocated = sum({t.data_ptr(): t.numel() * 4 for t in storage if t is not None}.values())
+
+        def addr(t, extra=0):
+            return storage[t.buf].data_ptr() + 4 * (t.ch_off + extra)
+
+        ops = (L.Op * sum(1 for _ in self.ops))()
+        ws_need = {}
+        conv_ops = []
+        self.op_names = []
+        for i, (kind, _r, _w, kw) in enumerate(self.ops):
+            op = ops[i]
+            op.stream_id, op.wait_mask = kw["stream_id"], kw["wait_mask"]
+            g = op.u.g
+            if kind == "conv":
+                x, y, keys = kw["x"], kw["y"], kw["keys"]
+                co, ci, kh, kwid, Ho, Wo = kw["geom"]
+                d = op.u.conv
+                op.kind = L.OP_CONV
+                wp = self.ws.packed([k for k in keys])
+                s1, b1 = self.ws.affine(list(keys), list(kw["bn"]) if kw["bn"] is not None else None)
+                d.x, d.w, d.y = addr(x), wp.data_ptr(), addr(y)
+                d.scale1, d.shift1 = s1.data_ptr(), b1.data_ptr()
+                if kw["bn2"] is not None:
+                    s2, b2 = self.ws.affine([None] * len(keys), list(kw["bn2"]))
+                    d.scale2, d.shift2 = s2.data_ptr(), b2.data_ptr()
+                    self._keep += [s2, b2]
+                r = kw["residual"]
+                if r is not None:
+                    d.residual, d.ldr, d.r_gs = addr(r), r.ld, r.C
+                d.B, d.H, d.W, d.Cin, d.ldx = x.B, x.H, x.W, ci, x.ld
+                d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, co, y.ld
+                d.KH, d.KW, d.stride, d.pad = kh, kwid, kw["stride"], kw["pad"]
+                d.flags, d.groups = kw["flags"], len(keys)
+                d.x_gs, d.w_gs, d.y_gs, d.p_gs = x.C, co * kh * kwid * ci, y.C, co
+                d.tile, d.splitk = 0, 1
+                sig = conv_signature(d)
+                if sig in tuning_table():
+                    d.tile, d.splitk = tuning_table()[sig]
+                else:
+                    L.check(lib.vidc_conv2d_plan(C.byref(d)), "conv plan")
+                need = lib.vidc_conv2d_workspace_bytes(C.byref(d))
+                if need:
+                    ws_need[op.stream_id] = max(ws_need.get(op.stream_id, 0), need)
+                conv_ops.append(op)
+                self._keep += [wp, s1, b1]
+                self.op_names.append("conv:%s:%s:sk%d %s" % (keys[0], L.TILE_NAMES[d.tile], d.splitk, sig))
+            elif kind == "stem":
+                x, y = kw["x"], kw["y"]
+                w = self.ws.raw(kw["key"] + ".weight").contiguous()
+                self._keep.append(w)
+                op.kind = L.OP_STEM
+                g.p[0], g.p[1], g.p[2] = addr(x), w.data_ptr(), addr(y, kw["g"] * y.C)
+                for j, v in enumerate((x.B, x.C, x.H, x.W, y.C, y.ld, int(kw["relu"]))):
+                    g.i[j] = v
+                self.op_names.append("stem:" + kw["key"])
+            elif kind == "maxpool":
+                x, y = kw["x"], kw["y"]
+                op.kind = L.OP_MAXPOOL
+                g.p[0], g.p[1] = addr(x), addr(y)
+                for j, v in enumerate((x.B, x.H, x.W, x.C * x.G, x.ld, y.ld)):
+                    g.i[j] = v
+                self.op_names.append("maxpool")
+            elif kind == "upsample":
+                x, y = kw["x"], kw["y"]
+                op.kind = L.OP_UPSAMPLE
+                g.p[0], g.p[1] = addr(x), addr(y)
+                for j, v in enumerate((x.B, x.H, x.W, x.C * x.G, x.ld, y.H, y.W, y.ld, kw["flags"])):
+                    g.i[j] = v
+                self.op_names.append("upsample:%dx%dx%d->%dx%d" % (x.H, x.W, x.C * x.G, y.H, y.W))
+            elif kind == "head":
+                x, low, y = kw["x"], kw["low"], kw["y"]
+                w = self.ws.raw(kw["key"] + ".weight").reshape(y.C, -1).contiguous()
+                b = self.ws.raw(kw["key"] + ".bias").contiguous()
+                self._keep += [w, b]
+                op.kind = L.OP_HEAD
+                g.p[0], g.p[1], g.p[2], g.p[3], g.p[4] = addr(x), w.data_ptr(), b.data_ptr(), addr(low), addr(y)
+                for j, v in enumerate((x.B, x.H, x.W, x.C * x.G, x.ld, y.C, kw["pad"], y.H, y.W, int(kw["relu"]))):
+                    g.i[j] = v
+                self.op_names.append("head:" + kw["key"])
+            elif kind == "warp_params":
+                it = kw["intr"]
+                op.kind = L.OP_WARP_PARAMS
+                g.p[0], g.p[1], g.p[2], g.p[3] = addr(kw["g"]), addr(kw["a"]), addr(kw["kinv"]), addr(kw["p"])
+                g.i[0], g.i[1], g.i[2] = self.B, it.W, it.H
+                g.f[0], g.f[1], g.f[2], g.f[3] = it.fx, it.fy, it.cx, it.cy
+                self.op_names.append("warp_params")
+            elif kind == "warp_fwd":
+                x, it = kw["x"], kw["intr"]
+                op.kind = L.OP_WARP_FWD
+                g.p[0], g.p[1], g.p[2] = addr(x), addr(kw["p"]), addr(kw["y"])
+                for j, v in enumerate((x.B, x.C, x.H, x.W, kw["ac"])):
+                    g.i[j] = v
+                g.f[0], g.f[1] = it.cx, it.cy
+                self.op_names.append("warp_fwd")
+            elif kind == "warp_inv":
+                x, it = kw["x"], kw["intr"]
+                op.kind = L.OP_WARP_INV
+                g.p[0], g.p[1], g.p[2] = addr(x), addr(kw["p"]), addr(kw["y"])
+                for j, v in enumerate((x.B, x.H, x.W, kw["ac"], kw["norm"])):
+                    g.i[j] = v
+                g.f[0], g.f[1] = it.cx, it.cy
+                self.op_names.append("warp_inv_rot_norm")
+            elif kind == "copy":
+                src, dst = kw["src"], kw["dst"]
+                nbytes = min(self.buf_elems[src.buf], self.buf_elems[dst.buf]) * 4
+                op.kind = L.OP_COPY
+                g.p[0], g.p[1] = addr(src), addr(dst)
+                g.i[0], g.i[1] = nbytes & 0xFFFFFFFF, nbytes >> 32
+                self.op_names.append("copy")
+            else:
+                raise ValueError(kind)
+        # split-K workspaces (one per stream id so concurrent convs never share partials)
+        self.workspaces = {sid: torch.empty(nb // 4 + 4, dtype=torch.float32, device=self.device) for sid, nb in ws_need.items()}
+        for op in conv_ops:
+            if op.u.conv.splitk > 1:
+                op.u.conv.workspace = self.workspaces[op.stream_id].data_ptr()
+        self.c_ops = ops
+        h = C.c_void_p()
+        L.check(lib.vidc_program_create(ops, len(ops), C.byref(h)), "program_create")
+        self.handle = h
+        self.captured = False
+        return self
+
+    # ---- execution ----------------------------------------------------------------------------------------
+    def tensor(self, t):
+        """torch view of a program tensor (NCHW tensors come back shaped (B,C,H,W))."""
+        s = self.storage[t.buf]
+        if t.nchw:
+            return s[: t.B * t.C * t.H * t.W].view(t.B, t.C, t.H, t.W)
+        return s[: t.B * t.H * t.W * t.ld].view(t.B, t.H, t.W, t.ld)[..., t.ch_off: t.ch_off + t.C * t.G]
+
+    def run(self, stream=None):
+        L.check(L.lib().vidc_program_run(self.handle, stream if stream is not None else L.current_stream()), "program_run")
+
+    def capture(self, stream=None):
+        L.check(L.lib().vidc_program_capture(self.handle, stream if stream is not None else L.current_stream()), "program_capture")
+        self.captured = True
+
+    def launch(self, stream=None):
+        L.check(L.lib().vidc_program_launch(self.handle, stream if stream is not None else L.current_stream()), "program_launch")
+
+    def time(self, iters=20, use_graph=False, per_op=False, stream=None):
+        ms = (C.c_float * 1)()
+        per = (C.c_float * len(self.ops))() if per_op else None
+        L.check(L.lib().vidc_program_time(self.handle, stream if stream is not None else L.current_stream(), iters,
+                                          int(use_graph), ms, per), "program_time")
+        return (ms[0], list(per)) if per_op else ms[0]
+
+    def __del__(self):
+        try:
+            if self.handle is not None:
+                L.lib().vidc_program_destroy(self.handle)
+        except Exception:
+            pass

@@ -1,0 +1,76 @@
+"""The four-branch FPN-style decoder shared by both networks (networks/surface_normal.py:73-145 and, three
+times wider, networks/depth_completion.py:75-147): parameter containers with the reference's Sequential
+indices, and the walk that turns them into fused engine ops.
+"""
+import torch.nn as nn
+
+# per pyramid level: (kernel, cout multiple of 128*m) for each conv, 'u' = upsample to the next finer level
+_BRANCH_PLAN = {
+    1: [(3, 2), (1, 1)],
+    2: [(1, 2), (3, 2), "u", (1, 1)],
+    3: [(1, 4), (3, 4), "u", (1, 2), (3, 2), "u", (1, 1)],
+    4: [(1, 8), (3, 8), "u", (1, 4), (3, 4), "u", (1, 2), (3, 2), "u", (1, 1)],
+}
+_LEVEL_SIZES_240 = {1: (60, 80), 2: (30, 40), 3: (15, 20)}   # the reference's literals, used only as nn metadata
+
+
+def build_branch(level, m):
+    """nn.Sequential whose indices/shapes equal `feature{level}_upsamping` of the reference (m = width multiplier)."""
+    mods = []
+    cin = 256 * m * (2 ** (level - 1))
+    target = level
+    for step in _BRANCH_PLAN[level]:
+        if step == "u":
+            target -= 1
+            mods.append(nn.UpsamplingBilinear2d(size=_LEVEL_SIZES_240[target]))
+            continue
+        k, mult = step
+        cout = 128 * m * mult
+        mods += [nn.Conv2d(cin, cout, k, 1, k // 2), nn.BatchNorm2d(cout), nn.ReLU(inplace=True)]
+        cin = cout
+    return nn.Sequential(*mods)
+
+
+def emit_branch(prog, seq, prefix, x, level_sizes, zsum):
+    """Walks one branch.  Conv2d+BatchNorm2d+ReLU triples become one fused conv; the last conv of the branch writes
+    (branch 1) or accumulates (branches 2-4) into `zsum`, which implements z1+z2+z3+z4 without add kernels."""
+    mods = list(seq)
+    n_conv = sum(isinstance(mm, nn.Conv2d) for mm in mods)
+    seen = 0
+    t = x
+    i = 0
+    while i < len(mods):
+        mm = mods[i]
+        if isinstance(mm, nn.Conv2d):
+            assert isinstance(mods[i + 1], nn.BatchNorm2d) and isinstance(mods[i + 2], nn.ReLU)
+            seen += 1
+            last = seen == n_conv
+            pad = mm.padding[0] if isinstance(mm.padding, tuple) else mm.padding
+            if last and zsum is not None:
+                t = prog.conv(t, "%s%d" % (prefix, i), bn="%s%d" % (prefix, i + 1), relu=True, padding=pad, out=zsum,
+                              accumulate=True)
+            else:
+                t = prog.conv(t, "%s%d" % (prefix, i), bn="%s%d" % (prefix, i + 1), relu=True, padding=pad)
+            i += 3
+        elif isinstance(mm, nn.UpsamplingBilinear2d):
+            # target size = the next finer pyramid level of *this* input resolution (the reference hard-codes 240x320)
+            level = [lv for lv, sz in level_sizes.items() if sz == (t.H, t.W)][0] - 1
+            t = prog.upsample(t, level_sizes[level])
+            i += 1
+        else:
+            raise TypeError(type(mm))
+    return t
+
+
+def emit_decoder(prog, module, levels):
+    """levels: [x1..x4] program tensors (possibly grouped = channel-concatenated).  Returns z1+z2+z3+z4."""
+    from ..engine import T
+    flat = [T(t.buf, t.B, t.H, t.W, t.C * t.G, 1, t.ld, t.ch_off) for t in levels]   # concat view: groups -> channels
+    sizes = {i + 1: (t.H, t.W) for i, t in enumerate(flat)}
+    zsum = None
+    for b in (1, 2, 3, 4):
+        seq = getattr(module, "feature%d_upsamping" % b)
+        z = emit_branch(prog, seq, "feature%d_upsamping." % b, flat[b - 1], sizes, zsum)
+        if zsum is None:
+            zsum = z
+    return zsum

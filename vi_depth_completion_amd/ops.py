@@ -1,0 +1,120 @@
+"""Functional (tensor in -> tensor out) wrappers over single libvidc.so entry points.
+
+The networks do not go through these (they run as whole `engine.Program`s); they exist so that every C entry
+point can be exercised and parity-tested on its own, and for the plane block host code.  All tensors must be
+CUDA/HIP tensors; nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("vidc ops take GPU tensors only (no CPU fallback)")
+
+
+def pack_conv_weight(w_oihw):
+    _dev(w_oihw)
+    w = w_oihw.contiguous().float()
+    co, ci, kh, kw = w.shape
+    out = torch.empty((co, kh * kw * ci), dtype=torch.float32, device=w.device)
+    L.check(L.lib().vidc_pack_conv_weight(L.ptr(w), L.ptr(out), co, ci, kh, kw, L.current_stream()), "pack_conv_weight")
+    return out
+
+
+def conv2d_bn_act(x, w_packed, scale1, shift1, kh, kw, stride=1, pad=0, relu1=False, scale2=None, shift2=None, relu2=False,
+                  residual=None, relu3=False, accumulate_into=None, tile=0, splitk=1, groups=1):
+    """x: NHWC (B,H,W,G*Cin) contiguous; w_packed: (G,Cout,kh*kw*Cin) or (Cout,K); returns NHWC (B,Ho,Wo,G*Cout)."""
+    _dev(x, w_packed, scale1, shift1)
+    x = x.contiguous()
+    B, H, W, ld = x.shape
+    G = groups
+    cin = ld // G
+    wp = w_packed.contiguous().view(G, -1, kh * kw * cin)
+    cout = wp.shape[1]
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    y = accumulate_into if accumulate_into is not None else torch.empty((B, Ho, Wo, G * cout), dtype=torch.float32, device=x.device)
+    d = L.ConvDesc()
+    d.x, d.w, d.y = L.ptr(x), L.ptr(wp), L.ptr(y)
+    s1, b1 = scale1.contiguous().float(), shift1.contiguous().float()
+    d.scale1, d.shift1 = L.ptr(s1), L.ptr(b1)
+    flags = (L.RELU1 if relu1 else 0)
+    keep = [s1, b1]
+    if scale2 is not None:
+        s2, b2 = scale2.contiguous().float(), shift2.contiguous().float()
+        d.scale2, d.shift2 = L.ptr(s2), L.ptr(b2)
+        keep += [s2, b2]
+        flags |= L.AFFINE2 | (L.RELU2 if relu2 else 0)
+    if residual is not None:
+        residual = residual.contiguous()
+        d.residual, d.ldr, d.r_gs = L.ptr(residual), residual.shape[-1], cout
+        flags |= L.RESIDUAL | (L.RELU3 if relu3 else 0)
+    if accumulate_into is not None:
+        flags |= L.ACCUM
+    d.B, d.H, d.W, d.Cin, d.ldx = B, H, W, cin, ld
+    d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, cout, G * cout
+    d.KH, d.KW, d.stride, d.pad, d.flags, d.groups = kh, kw, stride, pad, flags, G
+    d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, cout * kh * kw * cin, cout, cout
+    d.tile, d.splitk = tile, splitk
+    if tile == 0:
+        L.check(L.lib().vidc_conv2d_plan(C.byref(d)), "conv2d_plan")
+        if splitk > 1:
+            d.splitk = splitk
+    ws = None
+    nbytes = L.lib().vidc_conv2d_workspace_bytes(C.byref(d))
+    if nbytes:
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        d.workspace = L.ptr(ws)
+    L.check(L.lib().vidc_conv2d_bn_act(C.byref(d), L.current_stream()), "conv2d_bn_act")
+    return y
+
+
+def stem_conv3x3s2(x_nchw, w_oihw, relu=True):
+    _dev(x_nchw, w_oihw)
+    x, w = x_nchw.contiguous().float(), w_oihw.contiguous().float()
+    B, cin, H, W = x.shape
+    co = w.shape[0]
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((B, Ho, Wo, co), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vidc_stem_conv3x3s2(L.ptr(x), L.ptr(w), L.ptr(y), B, cin, H, W, co, co, int(relu), L.current_stream()), "stem")
+    return y
+
+
+def maxpool3x3s2(x):
+    _dev(x)
+    x = x.contiguous()
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vidc_maxpool3x3s2(L.ptr(x), L.ptr(y), B, H, W, Cc, Cc, Cc, L.current_stream()), "maxpool")
+    return y
+
+
+def upsample_bilinear_ac(x, size, relu=False, accumulate_into=None):
+    _dev(x)
+    x = x.contiguous()
+    B, h, w, Cc = x.shape
+    y = accumulate_into if accumulate_into is not None else torch.empty((B, size[0], size[1], Cc), dtype=torch.float32, device=x.device)
+    flags = (L.UP_RELU if relu else 0) | (L.UP_ACCUM if accumulate_into is not None else 0)
+    L.check(L.lib().vidc_upsample_bilinear_ac(L.ptr(x), L.ptr(y), B, h, w, Cc, Cc, size[0], size[1], Cc, flags,
+                                              L.current_stream()), "upsample")
+    return y
+
+
+def head_conv1x1_upsample(x, w, bias, pad, size, relu):
+    """x NHWC (B,h,w,Cin); w (Cout,Cin[,1,1]); returns (y NCHW (B,Cout,H,W), lowres NCHW (B,Cout,h+2p,w+2p))."""
+    _dev(x, w, bias)
+    x = x.contiguous()
+    B, h, wd, cin = x.shape
+    w2 = w.reshape(w.shape[0], -1).contiguous().float()
+    co = w2.shape[0]
+    low = torch.empty((B, co, h + 2 * pad, wd + 2 * pad), dtype=torch.float32, device=x.device)
+    y = torch.empty((B, co, size[0], size[1]), dtype=torch.float32, device=x.device)
+    b = bias.contiguous().float()
+    L.check(L.lib().vidc_head_conv1x1_upsample(L.ptr(x), L.ptr(w2), L.ptr(b), L.ptr(low), L.ptr(y), B, h, wd, cin, cin, co, pad,
+                                               size[0], size[1], int(relu), L.current_stream()), "head")
+    return y, low

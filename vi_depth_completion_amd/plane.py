@@ -1,0 +1,123 @@
+"""Plane block + sparse-depth enrichment: host orchestration over the libvidc.so plane kernels.
+
+Replaces `extract_plane_images_from_normal_image` (main.py:130-190) and the enrichment loop of
+`RunDepthCompletion._call_cnn` (main.py:277-297).  The host keeps exactly what the reference keeps on the host --
+the numpy legacy RNG draws (np.random.permutation / np.random.randint, in the reference's order) and the plane-id
+maps, which arrive as numpy arrays from the plane detector (predictor.py:143-150) -- and hands index arrays to the
+device.  Everything else (RANSAC, offset, projection, override, scatter) is one launch per stage for the whole batch.
+"""
+import numpy as np
+import torch
+
+from . import _lib as L
+
+NUM_HYPOTHESES = 300   # main.py:38,68
+
+
+def draw_normal_hypotheses(id_maps, rng=np.random):
+    """For every image and every plane id > 0 (ascending, like torch.unique), draw the hypothesis rows exactly as
+    mean_normal_ranasc does (main.py:43) and convert them to flat pixel indices.
+    Returns (slots int32 [n,4] = (b, cls, hyp_offset, n_hyp), hyp_pix int32)."""
+    slots, hyp = [], []
+    off = 0
+    for b, m in enumerate(id_maps):
+        flat = np.asarray(m).reshape(-1)
+        classes = np.unique(flat)
+        if int(classes.max()) + 1 == 1:
+            continue                      # only background: the reference returns its inputs unchanged (main.py:135-137)
+        for cls in classes:
+            if cls == 0:
+                continue
+            pix = np.flatnonzero(flat == cls)
+            n = pix.shape[0]
+            idx = rng.permutation(np.r_[0:n])[0:min(NUM_HYPOTHESES, n)]
+            hyp.append(pix[idx].astype(np.int32))
+            slots.append((b, int(cls), off, len(idx)))
+            off += len(idx)
+    slots = np.asarray(slots, dtype=np.int32).reshape(-1, 4)
+    hyp = np.concatenate(hyp).astype(np.int32) if hyp else np.zeros(0, dtype=np.int32)
+    return slots, hyp
+
+
+def draw_enrichment(nnz, goal, rng=np.random):
+    """main.py:290-292 for every image: np.unique(np.random.randint(0, nnz, size=min(goal, nnz)))."""
+    subs, offs = [], [0]
+    for n in nnz:
+        n = int(n)
+        k = min(goal, n)
+        sub = np.unique(rng.randint(0, n, size=k)) if n > 0 else np.zeros(0, dtype=np.int64)
+        subs.append(sub.astype(np.int32))
+        offs.append(offs[-1] + len(sub))
+    sub = np.concatenate(subs) if subs else np.zeros(0, dtype=np.int32)
+    return sub, np.asarray(offs, dtype=np.int32)
+
+
+class PlaneBlock:
+    """Device buffers are cached per (B, HW, n_slots); id maps are re-uploaded only when they change."""
+
+    def __init__(self):
+        self._ids_key = None
+        self._ids_dev = None
+        self.last_records = None
+
+    def _upload_ids(self, id_maps, device):
+        key = tuple(id(m) for m in id_maps)
+        arr = np.stack([np.asarray(m, dtype=np.uint8) for m in id_maps])
+        if self._ids_key != key or self._ids_dev is None or self._ids_dev.device != device or not np.array_equal(self._ids_host, arr):
+            self._ids_host = arr
+            self._ids_dev = torch.from_numpy(arr).to(device)
+            self._ids_key = key
+        return self._ids_dev
+
+    def plane_depth(self, normals, id_maps, sparse_depth, homo, rng=np.random):
+        """normals (B,3,H,W), sparse_depth (B,1,H,W), homo (B,H,W,3): GPU fp32.  id_maps: B numpy (H,W) integer maps.
+        Returns (di (B,1,H,W), nnz (B,) int32 device tensor = #(di > 0))."""
+        if not normals.is_cuda:
+            raise RuntimeError("PlaneBlock runs on the GPU only (no CPU fallback)")
+        lib, st = L.lib(), L.current_stream()
+        B, _, H, W = normals.shape
+        HW = H * W
+        dev = normals.device
+        normals, homo = normals.contiguous(), homo.contiguous()
+        ds = sparse_depth.contiguous().view(B, HW)
+        slots, hyp = draw_normal_hypotheses(id_maps, rng)
+        di = ds.clone()
+        n_slots = slots.shape[0]
+        if n_slots > 0:
+            ids = self._upload_ids(id_maps, dev)
+            slots_d = torch.from_numpy(slots).to(dev)
+            hyp_d = torch.from_numpy(hyp).to(dev)
+            mask = torch.empty((n_slots, HW), dtype=torch.uint8, device=dev)
+            counts = torch.empty((n_slots, L.MAX_HYP), dtype=torch.int32, device=dev)
+            rec = torch.empty((n_slots, L.PLANE_RECORD), dtype=torch.float32, device=dev)
+            L.check(lib.vidc_plane_ransac_normal(L.ptr(normals), L.ptr(ids), L.ptr(slots_d), n_slots, L.ptr(hyp_d), HW, L.ptr(mask),
+                                                 L.ptr(counts), L.ptr(rec), st), "plane_ransac_normal")
+            L.check(lib.vidc_plane_offset(L.ptr(homo), L.ptr(ds), L.ptr(slots_d), n_slots, L.ptr(mask), HW, L.ptr(rec), st), "plane_offset")
+            L.check(lib.vidc_plane_project_depth(L.ptr(homo), L.ptr(slots_d), n_slots, L.ptr(mask), HW, L.ptr(rec), L.ptr(di), st),
+                    "plane_project_depth")
+            self.last_records, self.last_slots, self.last_mask = rec, slots, mask
+        else:
+            self.last_records, self.last_slots, self.last_mask = None, slots, None
+        nnz = torch.empty(B, dtype=torch.int32, device=dev)
+        L.check(lib.vidc_plane_finalize(L.ptr(ds), L.ptr(di), B, HW, L.ptr(nnz), st), "plane_finalize")
+        return di.view(B, 1, H, W), nnz
+
+    def check_records(self):
+        """Raises if a plane had more than 300 sparse points (would need the host permutation of main.py:78)."""
+        if self.last_records is not None and bool((self.last_records[:, 10] < 0).any()):
+            raise NotImplementedError("a plane has more than %d sparse depth points; the subsampled plane-offset RANSAC "
+                                      "(main.py:78) is not implemented on device" % L.MAX_HYP)
+
+    def enrich(self, sparse_depth, di, nnz, goal, rng=np.random):
+        """main.py:285-294.  One device->host read of the B counts (the reference syncs on torch.nonzero here)."""
+        lib, st = L.lib(), L.current_stream()
+        B, _, H, W = sparse_depth.shape
+        dev = sparse_depth.device
+        nnz_h = nnz.cpu().numpy()
+        sub, offs = draw_enrichment(nnz_h, goal, rng)
+        out = sparse_depth.clone()
+        self.last_sub, self.last_nnz = (sub, offs), nnz_h
+        if len(sub):
+            sub_d, offs_d = torch.from_numpy(sub).to(dev), torch.from_numpy(offs).to(dev)
+            L.check(lib.vidc_enrich_scatter(L.ptr(di), L.ptr(sub_d), L.ptr(offs_d), B, H * W, L.ptr(out), st), "enrich_scatter")
+        return out
