@@ -85,3 +85,49 @@ def test_rng_draws_follow_reference_order():
     # background-only map: no slots (main.py:135-137)
     s2, h2 = plane.draw_normal_hypotheses([np.zeros((240, 320), np.uint8)])
     assert s2.shape == (0, 4) and h2.size == 0
+
+
+@pytest.fixture(scope="module")
+def recorded_programs(lib):
+    """Both networks recorded on CPU in dry-run mode (no HIP calls): exercises all host-side program logic."""
+    import torch
+    from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
+    from vi_depth_completion_amd.networks.surface_normal import SurfaceNormalPrediction
+    sn = SurfaceNormalPrediction(fc_img=np.array([202.0, 202.0])).eval()
+    dc = ModifiedFPN().eval()
+    return sn.build_program(1, torch.device("cpu"), dry_run=True), dc.build_program(1, 240, 320, torch.device("cpu"), dry_run=True)
+
+
+def test_program_recording_matches_reference_op_counts(recorded_programs):
+    """125 + 337 convs, 293.88 GFLOP per 320x240 frame (46.29 SN + 247.58 DC)."""
+    sn, dc = recorded_programs
+    kinds = lambda p: [k for k, _, _, _ in p.ops]
+    # SN: 1 stem + 103 pyramid + 19 decoder + 1 head 3x3 as conv ops, + 1 head 1x1 kernel = 125 convs
+    assert kinds(sn).count("stem") == 1 and kinds(sn).count("conv") == 123 and kinds(sn).count("head") == 1
+    assert kinds(sn).count("upsample") == 6 and kinds(sn).count("maxpool") == 1
+    # DC: the 3 pyramids run grouped: 3 stems + 103 grouped convs (= 309) + 19 + 1 + head = 337 convs
+    assert kinds(dc).count("stem") == 3 and kinds(dc).count("conv") == 123 and kinds(dc).count("head") == 1
+    stem = lambda cin: 2 * 120 * 160 * 64 * cin * 9
+    head = lambda cin, co, h, w: 2 * h * w * cin * co
+    sn_flops = sn.flops + stem(3) + head(64, 3, 60, 80)
+    dc_flops = dc.flops + 2 * stem(3) + stem(1) + head(192, 1, 60, 80)
+    assert abs(sn_flops / 1e9 - 46.29) < 0.01, sn_flops
+    assert abs(dc_flops / 1e9 - 247.58) < 0.01, dc_flops
+
+
+def test_program_buffer_reuse_is_safe(recorded_programs):
+    """No op may read and write the same storage, and pinned inputs/outputs never alias anything."""
+    for prog in recorded_programs:
+        st = prog.storage
+        for kind, reads, writes, kw in prog.ops:
+            accum = kind in ("conv", "upsample") and kw.get("flags", 0) & (32 if kind == "conv" else 2)
+            for w in writes:
+                for r in reads:
+                    if r == w and accum:
+                        continue
+                    assert st[r].data_ptr() != st[w].data_ptr(), (kind, r, w)
+        pinned = [st[b].data_ptr() for b in prog.pinned]
+        assert len(set(pinned)) == len(pinned)
+        others = {st[b].data_ptr() for b in range(len(st)) if b not in prog.pinned and st[b] is not None}
+        assert not (set(pinned) & others)
+        assert prog.bytes_allocated < 600e6

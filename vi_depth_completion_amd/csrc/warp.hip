@@ -121,7 +121,8 @@ __device__ inline Taps make_taps(float u, float v, float cx, float cy, int W, in
 }
 
 __device__ inline float sample(const float* __restrict__ plane, const Taps& t) {
-    return plane[t.o00] * t.w00 + plane[t.o01] * t.w01 + plane[t.o10] * t.w10 + plane[t.o11] * t.w11;
+    // explicit fma chain: the result must not depend on how the compiler unrolls the channel loop
+    return fmaf(plane[t.o11], t.w11, fmaf(plane[t.o10], t.w10, fmaf(plane[t.o01], t.w01, plane[t.o00] * t.w00)));
 }
 
 // One thread per output pixel (lanes run along X, so the NCHW stores are fully coalesced and the

@@ -65,7 +65,7 @@ class WeightStore:
     def raw(self, key):
         return self.sd()[key]
 
-    def packed(self, keys):
+    def packed(self, keys, dry_run=False):
         """[G][Cout][KH][KW][Cin] fp32, packed by the C kernel."""
         ck = ("w",) + tuple(keys)
         if ck not in self._cache:
@@ -74,7 +74,10 @@ class WeightStore:
             out = torch.empty((len(ws), co, kh * kw * ci), dtype=torch.float32, device=ws[0].device)
             for g, w in enumerate(ws):
                 assert tuple(w.shape) == (co, ci, kh, kw)
-                L.check(L.lib().vidc_pack_conv_weight(L.ptr(w), L.ptr(out[g]), co, ci, kh, kw, L.current_stream()), "pack")
+                if not dry_run:
+                    L.check(L.lib().vidc_pack_conv_weight(L.ptr(w), L.ptr(out[g]), co, ci, kh, kw, L.current_stream()), "pack")
+            if dry_run:
+                return out
             self._cache[ck] = out
         return self._cache[ck]
 
@@ -286,7 +289,8 @@ class Program:
                 free.append((storage[b].numel(), storage[b]))
         return storage
 
-    def finalize(self):
+    def finalize(self, dry_run=False):
+        """Plans buffers and builds the C op array.  dry_run=True stops before any HIP call (host-logic tests on CPU)."""
         lib = L.lib()
         storage = self._plan_buffers()
         self.storage = storage
@@ -308,7 +312,7 @@ class Program:
                 co, ci, kh, kwid, Ho, Wo = kw["geom"]
                 d = op.u.conv
                 op.kind = L.OP_CONV
-                wp = self.ws.packed([k for k in keys])
+                wp = self.ws.packed([k for k in keys], dry_run)
                 s1, b1 = self.ws.affine(list(keys), list(kw["bn"]) if kw["bn"] is not None else None)
                 d.x, d.w, d.y = addr(x), wp.data_ptr(), addr(y)
                 d.scale1, d.shift1 = s1.data_ptr(), b1.data_ptr()
@@ -407,6 +411,9 @@ class Program:
             if op.u.conv.splitk > 1:
                 op.u.conv.workspace = self.workspaces[op.stream_id].data_ptr()
         self.c_ops = ops
+        self.captured = False
+        if dry_run:
+            return self
         h = C.c_void_p()
         L.check(lib.vidc_program_create(ops, len(ops), C.byref(h)), "program_create")
         self.handle = h

@@ -91,7 +91,7 @@ class ResNetPyramids(nn.Module):
         for li in range(1, 5):
             stage = getattr(self, "layer%d" % li)
             for bi, blk in enumerate(stage):
-                t = blk.emit(prog, t, "%slayer%d.%d." % (prefix, li, bi))
+                t = blk.emit(prog, t, prefix + "layer%d.%d." % (li, bi))
             outs.append(t)
         return outs
 

@@ -33,7 +33,7 @@ class ModifiedFPN(_HipModule):
     def combine_rgbdn(self, rgb, normal, depth, level):
         return torch.cat((rgb, normal, depth), dim=1)
 
-    def build_program(self, B, H, W, device):
+    def build_program(self, B, H, W, device, dry_run=False):
         prog = engine.Program(self._weights, device, B)
         img = prog.input_nchw("image", 3, H, W)
         nrm = prog.input_nchw("normal", 3, H, W)
@@ -46,7 +46,7 @@ class ModifiedFPN(_HipModule):
         prog.mark_output("head_lowres", low)
         prog.taps = {"x%d" % (i + 1): t for i, t in enumerate(levels)}
         prog.taps.update(zsum=zsum)
-        prog.finalize()
+        prog.finalize(dry_run)
         return prog
 
     def program(self, B, H, W, device):

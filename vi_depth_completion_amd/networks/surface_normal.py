@@ -72,7 +72,7 @@ class SurfaceNormalPrediction(_HipModule):
                                             nn.UpsamplingBilinear2d(size=output_size))
         self._init_engine()
 
-    def build_program(self, B, device):
+    def build_program(self, B, device, dry_run=False):
         wp = self.warp_2dof_alignment
         prog = engine.Program(self._weights, device, B)
         x = prog.input_nchw("image", self.resnet_pyramids.channel, wp.H, wp.W)
@@ -91,7 +91,7 @@ class SurfaceNormalPrediction(_HipModule):
         prog.mark_output("warp_params", params)
         prog.taps = {"x%d" % (i + 1): t for i, t in enumerate(levels)}
         prog.taps.update(zsum=zsum, normal_raw=y)
-        prog.finalize()
+        prog.finalize(dry_run)
         prog.storage[kinv.buf][:9].copy_(wp.kinv(device))
         return prog
 
