@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of the per-frame depth-completion hot path on N MI355X (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload = BASELINE.json configs[1]: synthetic 320x256 RGB + 200-point sparse depth, batch 1, plane mask fixed;
+one "step" = one frame through warp -> surface-normal net -> plane block + enrichment -> depth-completion net
+(RunDepthCompletion._call_cnn, main.py:261-298), inputs resident in HBM, seeded random-init weights.
+Frames shard over ranks with no data-path collective (weak scaling: every rank runs K frames); RCCL only gathers
+4 doubles per rank at the end.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from vi_depth_completion_amd import synthetic as S   # noqa: E402
+
+FLOPS_PER_FRAME = {(240, 320): 293.88e9, (256, 320): 311.63e9}   # SURVEY.md §8d, reference formulation, 2 FLOP/MAC
+PEAK_F32_MFMA_TFLOPS = 157.3                                       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic frames cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--per-op", type=str, default="", help="write the per-op timing table to this file")
+    return ap.parse_args()
+
+
+def build_pipeline(H, W, dev):
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    cc = (0.5 * 319.87654 * W / 320.0, 0.5 * 239.87603 * H / 240.0)
+    pipe = DepthCompletionPipeline(enriched_samples=200, cc_img=cc, device=dev, rng=np.random.RandomState(1234))
+    sn_sd = S.seeded_state_dict(pipe.surface_normal_cnn.state_dict(), 1234, device=dev)
+    dc_sd = S.seeded_state_dict(pipe.cnn.state_dict(), 1234, device=dev)
+    pipe.load_state_dicts(sn_sd, dc_sd)
+    pipe.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(H, W))
+    return pipe, sn_sd, dc_sd, cc
+
+
+def conv_stack_time_ms(prog, iters=5):
+    """Sum of the fused-conv launch durations of one program execution (HIP events between consecutive ops on the
+    launch stream, eager mode, averaged over `iters`), plus the number of conv launches."""
+    total, per = prog.time(iters=iters, use_graph=False, per_op=True)
+    conv = [(n, t) for n, t in zip(prog.op_names, per) if n.startswith("conv:")]
+    return sum(t for _, t in conv), len(conv), total, list(zip(prog.op_names, per))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.set_grad_enabled(False)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+
+    H, W, B = args.height, args.width, args.batch
+    pipe, sn_sd, dc_sd, cc = build_pipeline(H, W, dev)
+
+    # frame f of the job is a function of (seed, f) only: rank r takes frames r, r+world, ... (round-robin shards)
+    pool = []
+    for j in range(args.pool):
+        b = S.synthetic_batch(B, H, W, 1234, frame0=(rank + j * world) * B)
+        pool.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()})
+
+    def step(i):
+        return pipe._call_cnn(pool[i % len(pool)])
+
+    for i in range(args.warmup):
+        out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    # ---- parity of what was just timed: frame 0 of this rank against the CPU oracle (outside the timed region) ----
+    rec = torch.zeros(4, dtype=torch.float64, device=dev)   # frames, seconds, sum sq err, n px
+    rec[0], rec[1] = args.steps * B, elapsed
+    sq_err = n_px = 0.0
+    cpu_baseline = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import vidc_oracle as O
+        intr = O.Intrinsics(202.0, 202.0, cc[0], cc[1])
+        cpu_sn = {k: v.cpu() for k, v in sn_sd.items()}
+        cpu_dc = {k: v.cpu() for k, v in dc_sd.items()}
+        masks = [S.plane_id_map(H, W)] * B
+        hb = S.synthetic_batch(B, H, W, 1234, frame0=rank * B)
+        ref = O.call_cnn(cpu_sn, cpu_dc, hb, masks, intr, 200, rng=np.random.RandomState(77))   # also the warm-up
+        pipe.rng = np.random.RandomState(77)
+        got = pipe._call_cnn(pool[0]).cpu()
+        sq_err, n_px = float((got - ref).double().pow(2).sum()), float(ref.numel())
+        tc = time.perf_counter()
+        for j in range(args.cpu_frames):
+            hbj = S.synthetic_batch(B, H, W, 1234, frame0=(j + 1) * B)
+            O.call_cnn(cpu_sn, cpu_dc, hbj, masks, intr, 200, rng=np.random.RandomState(j))
+        cpu_s = time.perf_counter() - tc
+        cpu_baseline = {"value": round(args.cpu_frames * B / cpu_s, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
+                        "kind": "port",
+                        "sample": "%d frames of the same %dx%d batch-%d workload through oracle/vidc_oracle.call_cnn "
+                                  "(torch CPU fp32, %d threads of %d host CPUs)" % (args.cpu_frames, W, H, B,
+                                                                                    torch.get_num_threads(), os.cpu_count())}
+    rec[2], rec[3] = sq_err, n_px
+
+    # ---- roofline of the dominant kernel (fused conv, fp32 MFMA), measured live with HIP events ---------------------
+    roofline = None
+    extra = {}
+    if rank == 0:
+        sn_prog = pipe.surface_normal_cnn.program(B, dev)
+        dc_prog = pipe.cnn.program(B, H, W, dev)
+        sn_ms, sn_n, sn_total, sn_ops = conv_stack_time_ms(sn_prog)
+        dc_ms, dc_n, dc_total, dc_ops = conv_stack_time_ms(dc_prog)
+        flops = FLOPS_PER_FRAME.get((H, W), 293.88e9 * H * W / (240.0 * 320.0)) * B
+        conv_ms = sn_ms + dc_ms
+        achieved = flops / (conv_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "conv_igemm_f32 (+conv_splitk_finalize)", "launches_per_frame": sn_n + dc_n,
+                    "avg_launch_us": round(1e3 * conv_ms / (sn_n + dc_n), 2),
+                    "algorithmic_gflop_per_frame": round(flops / 1e9, 2),
+                    "executed_gflop_per_frame": round((sn_prog.flops + dc_prog.flops) / 1e9, 2)}
+        extra = {"program_ms": {"surface_normal": round(sn_total, 3), "depth_completion": round(dc_total, 3)},
+                 "conv_ms_per_frame": round(conv_ms, 3)}
+        if args.per_op:
+            with open(args.per_op, "w") as f:
+                for name, ops in (("surface_normal", sn_ops), ("depth_completion", dc_ops)):
+                    for n, t in ops:
+                        f.write("%s\t%.2f\t%s\n" % (name, t * 1e3, n))
+
+    if world > 1:
+        gathered = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(gathered, rec)                        # the only collective: 4 doubles per rank over RCCL/xGMI
+        allrec = torch.stack(gathered).cpu()
+    else:
+        allrec = rec.cpu()[None]
+    if rank == 0:
+        frames = float(allrec[:, 0].sum())
+        t_max = float(allrec[:, 1].max())
+        se, npx = float(allrec[:, 2].sum()), float(allrec[:, 3].sum())
+        line = {
+            "metric": "frames/sec", "value": round(frames / t_max, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic %dx%d RGB + 200-pt sparse depth, batch %d per GPU, plane mask "
+                                   "fixed; warp + surface-normal net + plane block/enrichment + depth-completion net" % (W, H, B),
+                       "height": H, "width": W, "batch_per_gpu": B, "weights": "seeded random-init (seed 1234)",
+                       "sharding": "frames round-robin over %d rank(s), no data-path collective" % world},
+            "rmse_vs_oracle": (round(float(np.sqrt(se / npx)), 8) if npx else None),
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

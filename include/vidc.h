@@ -102,8 +102,10 @@ typedef struct vidc_conv_desc {
     int32_t splitk;        /* >= 1                                                    */
 } vidc_conv_desc;
 
+/* Workgroup tilings (BM x BN output tile; _Kn = n k-slices reduced inside the workgroup through LDS). */
 enum vidc_conv_tile { VIDC_TILE_AUTO = 0, VIDC_TILE_128x128 = 1, VIDC_TILE_128x64 = 2, VIDC_TILE_64x128 = 3,
-                      VIDC_TILE_64x64 = 4, VIDC_TILE_32x128 = 5, VIDC_TILE_32x64 = 6, VIDC_TILE_COUNT = 7 };
+                      VIDC_TILE_64x64 = 4, VIDC_TILE_64x64_K2 = 5, VIDC_TILE_32x64_K2 = 6, VIDC_TILE_32x32_K4 = 7,
+                      VIDC_TILE_32x128 = 8, VIDC_TILE_32x32_K8 = 9, VIDC_TILE_COUNT = 10 };
 
 int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream);
 size_t vidc_conv2d_workspace_bytes(const vidc_conv_desc* d);

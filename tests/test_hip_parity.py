@@ -141,7 +141,7 @@ CONV_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", list(range(10)))
 def test_conv_tiles(shape, tile):
     from vi_depth_completion_amd import ops
     B, H, W, cin, cout, k, stride, groups = shape

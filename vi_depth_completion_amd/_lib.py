@@ -21,7 +21,9 @@ RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM = 1, 2, 4, 8, 16, 32
 UP_RELU, UP_ACCUM = 1, 2
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY = range(1, 10)
 TILE_AUTO = 0
-TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "32x128", 6: "32x64"}
+TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "64x64k2", 6: "32x64k2", 7: "32x32k4", 8: "32x128",
+              9: "32x32k8"}
+TILE_COUNT = 10
 
 _f32p = C.POINTER(C.c_float)
 

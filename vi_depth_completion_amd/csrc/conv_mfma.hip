@@ -5,10 +5,11 @@
 // networks/depth_completion.py:16-147 (on the reference: one cuDNN/ATen call per layer, 462 convs + 458 BNs per frame).
 //
 //   M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin, activations NHWC fp32, weights packed [Cout][KH][KW][Cin].
-//   Workgroup tile BM x BN, K-step 32 (one (kh,kw) tap, 32 input channels = 128 contiguous bytes per pixel row).
-//   Global -> registers (16 B/lane, issued one K-step ahead) -> LDS (rows padded to 36 floats) -> ds_read_b128
-//   fragments.  Each lane's b128 holds 4 consecutive k of its row; MFMA t of a group consumes element t of the A and
-//   of the B fragment, i.e. the k-order inside an 8-wide chunk is permuted identically for both operands.
+//   Workgroup tile BM x BN, K unit 32 floats (one (kh,kw) tap, 32 input channels = 128 contiguous bytes per pixel row).
+//   Global -> LDS by DMA (global_load_lds, 16 B/lane) into an NS-deep ring with counted vmcnt waits and raw barriers,
+//   so NS-1 stages of weights/activations are in flight per workgroup (weights are always HBM-cold: 1.5 GB per frame).
+//   LDS -> ds_read_b128 fragments.  Each lane's b128 holds 4 consecutive k of its row; MFMA t of a group consumes
+//   element t of the A and of the B fragment, i.e. the k-order inside an 8-wide chunk is permuted identically for both.
 //   Epilogue in registers: acc*scale1+shift1, relu, [*scale2+shift2, relu], [+residual, relu], [+= y], store NHWC
 //   at a channel offset (concat-free skip connections).  Split-K writes fp32 partials and a finalize kernel applies
 //   the same epilogue.  `groups` (blockIdx.z) runs the three ModifiedFPN pyramids in one launch.
@@ -46,98 +47,198 @@ __device__ inline float epilogue(float v, int n, size_t off_r, size_t off_y, con
     return v;
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN))
+// Zero source for LDS-DMA lanes whose row is padding (conv halo, M tail, Cout tail, K tail).
+__device__ float g_zero_chunk[64] = {0};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+// Workgroup = WMW x WNW x WKW waves.  The (WMW x WNW) waves of one k-slice tile the BM x BN output; the WKW k-slices
+// split every pipeline stage's K range (32 floats each) and are summed through LDS at the end (deterministic order).
+// NS-deep LDS ring filled by global_load_lds (16 B per lane, 1 KiB = 8 rows x 128 B per wave-instruction); the 16-byte
+// chunks of a row are XOR-swizzled by (row & 7) through the per-lane SOURCE address so ds_read_b128 fragments are at
+// worst 2-way bank conflicted while the DMA destination stays lane-linear.
+template <int BM, int BN, int WMW, int WNW, int WKW, int NS>
+__global__ void __launch_bounds__(64 * WMW * WNW * WKW)
 conv_igemm_f32(const ConvArgs a) {
-    constexpr int WAVES_N = BN / WN;
-    constexpr int NT = 64 * (BM / WM) * (BN / WN);
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_ITERS = (BM * 8 + NT - 1) / NT;   // float4 loads per thread per K-step
-    constexpr int B_ITERS = (BN * 8 + NT - 1) / NT;
-    constexpr int ROWS_PER_PASS = NT / 8;
+    constexpr int NW = WMW * WNW * WKW, WPK = WMW * WNW;
+    constexpr int TM = BM / (32 * WMW), TN = BN / (32 * WNW);
+    constexpr int A_J = (BM / 8) / WPK, B_J = (BN / 8) / WPK;      // DMA instructions per wave per stage
+    constexpr int LPS = A_J + B_J;
+    constexpr int STAGE = (BM + BN) * BK * WKW;                    // floats per ring slot
+    static_assert((BM / 8) % WPK == 0 && (BN / 8) % WPK == 0, "tile rows must split evenly over the waves");
+    static_assert(NS >= 2 && (NS - 2) * LPS <= 63, "vmcnt is a 6-bit counter");
+    static_assert((WKW - 1) * WPK * TM * TN * 1024 <= NS * STAGE, "K-reduction scratch must fit in the ring");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                               // [2][BM][LDS_LD]
-    float* Bs = smem + 2 * BM * LDS_LD;             // [2][BN][LDS_LD]
+#ifdef VIDC_CONV_TIMING
+    // debug build only: per-workgroup phase stamps (shader clock + 100 MHz wall clock) into a.ws
+    long long* dbg = reinterpret_cast<long long*>(a.ws) + (size_t)blockIdx.x * 8;
+    const long long t_begin = __builtin_readcyclecounter();
+#define VIDC_STAMP(k) do { if (threadIdx.x == 0) dbg[k] = __builtin_readcyclecounter() - t_begin; } while (0)
+    if (threadIdx.x == 0) dbg[6] = (long long)__builtin_amdgcn_s_memrealtime();
+#else
+#define VIDC_STAMP(k) do {} while (0)
+#endif
 
     const int tid = threadIdx.x;
-    const int g = blockIdx.z;
-    const int tile_n = blockIdx.x / a.tiles_m;      // consecutive blocks walk M: they share one weight tile (L2 reuse)
-    const int tile_m = blockIdx.x - tile_n * a.tiles_m;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int kq = wave / WPK, wq = wave - kq * WPK;
+    const int wm = wq / WNW, wn = wq - wm * WNW;
+    // XCD-aware workgroup mapping (guide T1).  Workgroup w runs on XCD w % 8 (observed, never relied on for
+    // correctness: the map below is a bijection).  Each XCD gets a CONTIGUOUS range of the work list ordered
+    // (group, n-tile, k-split, m-tile), so one (HBM-cold) weight tile is fetched by one XCD's L2 instead of by all
+    // eight; the small, just-produced activation tiles are what gets shared across XCDs.
+    int g, tile_n, tile_m, kz;
+    {
+        const int W = gridDim.x, w = blockIdx.x;
+        const int xcd = w & 7, j = w >> 3, q = W >> 3, r = W & 7;
+        int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        tile_m = v % a.tiles_m; v /= a.tiles_m;
+        kz = v % a.splitk; v /= a.splitk;
+        tile_n = v % a.tiles_n;
+        g = v / a.tiles_n;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int kz = blockIdx.y;
-    const int ks_begin = (int)(((long long)a.ksteps * kz) / a.splitk);
-    const int ks_end = (int)(((long long)a.ksteps * (kz + 1)) / a.splitk);
+    const int units = a.ksteps;                                       // K in units of 32 floats
+    const int stages_total = (units + WKW - 1) / WKW;
+    const int st_begin = (int)(((long long)stages_total * kz) / a.splitk);
+    const int st_end = (int)(((long long)stages_total * (kz + 1)) / a.splitk);
+    const int nst = st_end - st_begin;
 
-    const float* __restrict__ xg = a.x + g * a.x_gs;
-    const float* __restrict__ wg = a.w + g * a.w_gs;
-
-    // ---- per-thread load coordinates -----------------------------------------------------------------
-    const int lrow = tid >> 3, c4 = (tid & 7) * 4;
-    const float* a_ptr[A_ITERS];
-    int a_iy0[A_ITERS], a_ix0[A_ITERS];
-    bool a_ok[A_ITERS];
+    // ---- per-lane DMA source coordinates -----------------------------------------------------------------
+    // Buffer addressing: one descriptor per operand (SGPRs) + a 32-bit byte offset per lane.  A lane whose row is
+    // padding (conv halo, M tail, Cout tail, K tail) gets an offset beyond num_records and the hardware returns zeros,
+    // so there is no per-lane pointer select and no 64-bit address arithmetic in the loop.
+    constexpr unsigned OOB = 0x80000000u;
+    // (descriptor inputs go through readfirstlane so that hipcc can prove them wave-uniform; otherwise it wraps every
+    //  buffer op in a waterfall loop -- guide T20)
+    auto uniform_ptr = [](const float* p) {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+    };
+    const int x_bytes = __builtin_amdgcn_readfirstlane((int)(((long long)a.B * a.H * a.W * a.ldx - g * a.x_gs) * 4));
+    const int w_bytes = __builtin_amdgcn_readfirstlane((int)((long long)a.Cout * a.K * 4));
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.x + g * a.x_gs), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.w + g * a.w_gs), 0, w_bytes, 0x00020000);
+    const int lrow = lane >> 3;
+    const int csw = ((lane & 7) ^ lrow) * 4;            // swizzled 16-byte chunk this lane fetches (row & 7 == lane >> 3)
+    int a_off[A_J];                                      // byte offset of (pixel, tap (0,0), channel csw); may be negative
+    unsigned a_taps[A_J];                                // bit t set: tap t = kh*KW+kw of this row reads a real pixel
     const int HoWo = a.Ho * a.Wo;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)a.Wo;
 #pragma unroll
-    for (int j = 0; j < A_ITERS; ++j) {
-        int r = lrow + j * ROWS_PER_PASS;
-        int m = m0 + r;
-        bool ok = (r < BM) && (m < a.M);
-        int mm = ok ? m : 0;
-        int b = mm / HoWo, rem = mm - b * HoWo;
-        int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-        a_iy0[j] = oy * a.stride - a.pad;
-        a_ix0[j] = ox * a.stride - a.pad;
-        a_ok[j] = ok;
-        a_ptr[j] = xg + ((long long)(b * a.H + a_iy0[j]) * a.W + a_ix0[j]) * a.ldx + c4;
+    for (int j = 0; j < A_J; ++j) {
+        const int m = m0 + (j * WPK + wq) * 8 + lrow;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        int b = (int)((float)mm * inv_howo);             // float reciprocal + fix-up: exact for M < 2^23
+        int rem = mm - b * HoWo;
+        if (rem < 0) { --b; rem += HoWo; } else if (rem >= HoWo) { ++b; rem -= HoWo; }
+        int oy = (int)((float)rem * inv_wo);
+        int ox = rem - oy * a.Wo;
+        if (ox < 0) { --oy; ox += a.Wo; } else if (ox >= a.Wo) { ++oy; ox -= a.Wo; }
+        const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+        unsigned colm = 0, taps = 0;                     // KH + KW steps instead of KH * KW
+        for (int tw = 0; tw < a.KW; ++tw) colm |= ((unsigned)(ix0 + tw) < (unsigned)a.W) ? 1u << tw : 0u;
+        for (int th = 0; th < a.KH; ++th) taps |= ((unsigned)(iy0 + th) < (unsigned)a.H) ? colm << (th * a.KW) : 0u;
+        a_taps[j] = ok ? taps : 0u;
+        a_off[j] = (((b * a.H + iy0) * a.W + ix0) * a.ldx + csw) * 4;
     }
-    const float* b_ptr[B_ITERS];
-    bool b_ok[B_ITERS];
+    unsigned b_off[B_J];
 #pragma unroll
-    for (int j = 0; j < B_ITERS; ++j) {
-        int r = lrow + j * ROWS_PER_PASS;
-        int n = n0 + r;
-        b_ok[j] = (r < BN) && (n < a.Cout);
-        b_ptr[j] = wg + (long long)(b_ok[j] ? n : 0) * a.K + c4;
+    for (int j = 0; j < B_J; ++j) {
+        const int n = n0 + (j * WPK + wq) * 8 + lrow;
+        b_off[j] = n < a.Cout ? (unsigned)((n * a.K + csw) * 4) : OOB;
     }
-
-    // K-step -> (kh, kw, channel chunk), advanced incrementally
+    // this wave's K unit -> (kh, kw, channel chunk), advanced by WKW units per stage
     const int cpt = a.Cin / BK;
-    int tap = ks_begin / cpt, cc = ks_begin - tap * cpt;
+    int unit = st_begin * WKW + kq;
+    int tap = unit / cpt, cc = unit - tap * cpt;
     int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int unit_end = min(units, st_end * WKW);      // past this workgroup's K range every DMA lane fetches zeros
 
-    float4 ra[A_ITERS], rb[B_ITERS];
-    auto load_tile = [&](int ks) {
-        const long long tap_off = ((long long)kh * a.W + kw) * a.ldx + cc * BK;
+    // One pipeline stage = A_J + B_J DMA instructions per wave, issued in two halves that the main loop places inside
+    // groups of MFMAs (branch-free, so the scheduler can interleave them with the 64-clk MFMA issue slots).
+    auto issue_a = [&](int slot) {
+        float* sbase = smem + slot * STAGE;
+        const unsigned tapbit = unit < unit_end ? 1u << (kh * a.KW + kw) : 0u;
+        const int tap_off = (((kh * a.W + kw) * a.ldx) + cc * BK) * 4;
 #pragma unroll
-        for (int j = 0; j < A_ITERS; ++j) {
-            int iy = a_iy0[j] + kh, ix = a_ix0[j] + kw;
-            bool ok = a_ok[j] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            ra[j] = ok ? *reinterpret_cast<const float4*>(a_ptr[j] + tap_off) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < B_ITERS; ++j)
-            rb[j] = b_ok[j] ? *reinterpret_cast<const float4*>(b_ptr[j] + (long long)ks * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (++cc == cpt) { cc = 0; if (++kw == a.KW) { kw = 0; ++kh; } }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < A_ITERS; ++j) {
-            int r = lrow + j * ROWS_PER_PASS;
-            if (A_ITERS * ROWS_PER_PASS == BM || r < BM)
-                *reinterpret_cast<float4*>(&As[(buf * BM + r) * LDS_LD + c4]) = ra[j];
-        }
-#pragma unroll
-        for (int j = 0; j < B_ITERS; ++j) {
-            int r = lrow + j * ROWS_PER_PASS;
-            if (B_ITERS * ROWS_PER_PASS == BN || r < BN)
-                *reinterpret_cast<float4*>(&Bs[(buf * BN + r) * LDS_LD + c4]) = rb[j];
+        for (int j = 0; j < A_J; ++j) {
+            const unsigned voff = (a_taps[j] & tapbit) ? (unsigned)(a_off[j] + tap_off) : OOB;
+            float* dst = sbase + (kq * BM + (j * WPK + wq) * 8) * BK;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void_t*)dst, 16, (int)voff, 0, 0, 0);
         }
     };
+    auto issue_b = [&](int slot) {
+        float* sbase = smem + slot * STAGE;
+        const unsigned uoff = unit < unit_end ? (unsigned)(unit * BK * 4) : OOB;   // valid + OOB stays >= 2^31
+#pragma unroll
+        for (int j = 0; j < B_J; ++j) {
+            float* dst = sbase + (WKW * BM + kq * BN + (j * WPK + wq) * 8) * BK;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t*)dst, 16, (int)(b_off[j] + uoff), 0, 0, 0);
+        }
+        unit += WKW;
+        cc += WKW;
+        while (cc >= cpt) { cc -= cpt; if (++kw == a.KW) { kw = 0; ++kh; } }
+    };
+    auto issue_stage = [&](int slot) { issue_a(slot); issue_b(slot); };
 
-    // ---- main loop -----------------------------------------------------------------------------------
-    const int wave = tid >> 6, lane = tid & 63;
-    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    // ---- epilogue operands, fetched now so their (cold) latency hides under the main loop --------------------------
     const int li = lane & 31, lh = lane >> 5;
+    const float* res = a.residual ? a.residual + g * a.r_gs : nullptr;
+    float* yg = a.y + g * a.y_gs;
+    float e_s1[TN], e_b1[TN], e_s2[TN], e_b2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 32 * TN + j * 32 + li;
+        const bool nok = n < a.Cout;
+        const int ni = (int)(g * a.p_gs) + (nok ? n : 0);
+        e_s1[j] = a.scale1[ni]; e_b1[j] = a.shift1[ni];
+        e_s2[j] = 1.f; e_b2[j] = 0.f;
+        if (a.flags & VIDC_AFFINE2) { e_s2[j] = a.scale2[ni]; e_b2[j] = a.shift2[ni]; }
+    }
+    float e_res[TM][TN][16];
+    if ((a.flags & VIDC_RESIDUAL) && a.splitk == 1) {    // uniform branch; indices clamped so every load is unconditional
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = min(n0 + wn * 32 * TN + j * 32 + li, a.Cout - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = min(m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.M - 1);
+                    e_res[i][j][r] = res[(size_t)m * a.ldr + n];
+                }
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e_res[i][j][r] = 0.f;
+    }
+
+    // ---- main loop -----------------------------------------------------------------------------------------
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -146,64 +247,132 @@ conv_igemm_f32(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int buf = 0;
-    if (ks_begin < ks_end) {
-        load_tile(ks_begin);
-        store_tile(0);
-    }
-    __syncthreads();
-    for (int ks = ks_begin; ks < ks_end; ++ks) {
-        const bool more = ks + 1 < ks_end;
-        if (more) load_tile(ks + 1);     // global loads in flight under the MFMAs below
-        const float* Ab = &As[(buf * BM + wm * WM + li) * LDS_LD + lh * 4];
-        const float* Bb = &Bs[(buf * BN + wn * WN + li) * LDS_LD + lh * 4];
+    // Every iteration issues exactly one stage (zero-sourced beyond the K range), so the DMA issue code is branch-free
+    // and can be scheduled between MFMAs, and the vmcnt distance is the same in every iteration.
+    VIDC_STAMP(0);      // setup done
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_stage(s);
+    VIDC_STAMP(1);      // prologue DMAs issued
+
+    // Fragment reads are inline asm: hipcc cannot prove that a ds_read does not alias an in-flight LDS-DMA and would
+    // otherwise drain the whole ring (s_waitcnt vmcnt(0)) before the first read of every stage.  Ordering is ours:
+    // counted lgkmcnt + sched_barrier(0) before the MFMAs that consume the registers (guide §5.7 form iii, rule 18).
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) float*)smem);
+    const unsigned a_base = lds0 + 4u * (unsigned)((kq * BM + wm * 32 * TM + li) * BK);
+    const unsigned b_base = lds0 + 4u * (unsigned)((WKW * BM + kq * BN + wn * 32 * TN + li) * BK);
+    const int sw = li & 7;
+    unsigned coff[BK / 8];
+#pragma unroll
+    for (int sub = 0; sub < BK / 8; ++sub) coff[sub] = (unsigned)(((sub * 2 + lh) ^ sw) * 16);
+
+    int slot = 0;
+    for (int s = 0; s < nst; ++s) {
+        // stage s has landed once at most the (NS-2) younger stages are still in flight
+        wait_vmcnt<(NS - 2) * LPS>();
+        __builtin_amdgcn_s_barrier();     // every wave's pieces of stage s are in LDS; everyone finished stage s-1
+        if (s == 0) VIDC_STAMP(2);      // first stage landed
+        int fill = slot + NS - 1; if (fill >= NS) fill -= NS;     // the slot read in iteration s-1: free since the barrier
+        const unsigned Ab = a_base + (unsigned)(slot * STAGE * 4);
+        const unsigned Bb = b_base + (unsigned)(slot * STAGE * 4);
+        f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = lds_read_b128<0>(Ab + coff[0] + i * 32 * BK * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = lds_read_b128<0>(Bb + coff[0] + j * 32 * BK * 4);
 #pragma unroll
         for (int sub = 0; sub < BK / 8; ++sub) {
-            float4 fa[TM], fb[TN];
+            const int cur = sub & 1, nxt = cur ^ 1;
+            if (sub + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + sub * 8);
+                for (int i = 0; i < TM; ++i) fa[nxt][i] = lds_read_b128<0>(Ab + coff[sub + 1] + i * 32 * BK * 4);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + sub * 8);
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read_b128<0>(Bb + coff[sub + 1] + j * 32 * BK * 4);
+                wait_lgkmcnt<TM + TN>();      // the reads of `cur` are complete (LDS returns in order)
+            } else {
+                wait_lgkmcnt<0>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (sub == 0) issue_a(fill);     // scheduled among the MFMAs below
+            if (sub == 1) issue_b(fill);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) store_tile(buf ^ 1);
+        if (++slot == NS) slot = 0;
+    }
+
+    // ---- in-workgroup K reduction (k-slices 1.. add into slice 0, fixed order) ---------------------------------------
+    VIDC_STAMP(3);      // main loop done
+    wait_vmcnt<0>();                     // drain the (zero-sourced) tail DMAs before LDS is reused / the wave ends
+    if (WKW > 1) {
         __syncthreads();
-        buf ^= 1;
+        float* red = smem;
+        if (kq > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((kq - 1) * WPK + wq) * TM + i) * TN + j) * 1024 + r * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kq > 0) return;
+#pragma unroll
+        for (int q = 1; q < WKW; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][j][r] += red[((((q - 1) * WPK + wq) * TM + i) * TN + j) * 1024 + r * 64 + lane];
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -----------
-    const float* s1 = a.scale1 + g * a.p_gs;
-    const float* b1 = a.shift1 + g * a.p_gs;
-    const float* s2 = a.scale2 ? a.scale2 + g * a.p_gs : nullptr;
-    const float* b2 = a.shift2 ? a.shift2 + g * a.p_gs : nullptr;
-    const float* res = a.residual ? a.residual + g * a.r_gs : nullptr;
-    float* yg = a.y + g * a.y_gs;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 32 + li;
+            const int n = n0 + wn * 32 * TN + j * 32 + li;
             if (n >= a.Cout) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= a.M) continue;
+#ifndef VIDC_CONV_TIMING
                 if (a.splitk > 1) {
                     a.ws[((size_t)(kz * a.groups + g) * a.M + m) * a.Cout + n] = acc[i][j][r];
-                } else {
-                    size_t oy = (size_t)m * a.ldy + n;
-                    yg[oy] = epilogue(acc[i][j][r], n, (size_t)m * a.ldr + n, oy, a, s1, b1, s2, b2, res, yg);
+                } else
+#endif
+                {
+                    float v = acc[i][j][r] * e_s1[j] + e_b1[j];
+                    if (a.flags & VIDC_RELU1) v = fmaxf(v, 0.f);
+                    if (a.flags & VIDC_AFFINE2) {
+                        v = v * e_s2[j] + e_b2[j];
+                        if (a.flags & VIDC_RELU2) v = fmaxf(v, 0.f);
+                    }
+                    if (a.flags & VIDC_RESIDUAL) {
+                        v += e_res[i][j][r];
+                        if (a.flags & VIDC_RELU3) v = fmaxf(v, 0.f);
+                    }
+                    const size_t oy = (size_t)m * a.ldy + n;
+                    if (a.flags & VIDC_ACCUM) v += yg[oy];
+                    yg[oy] = v;
                 }
             }
         }
+    VIDC_STAMP(4);      // epilogue stores issued
+#ifdef VIDC_CONV_TIMING
+    if (threadIdx.x == 0) dbg[7] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // Sums the split-K partials and applies the fused epilogue; one thread per 4 output channels.
@@ -246,22 +415,32 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
     wp[idx] = w[(((long long)o * Cin + c) * KH + kh) * KW + kw];
 }
 
-struct TileInfo { int bm, bn, threads; };
-constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {{0, 0, 0}, {128, 128, 256}, {128, 64, 256}, {64, 128, 256}, {64, 64, 256},
-                                              {32, 128, 256}, {32, 64, 128}};
+struct TileInfo { int bm, bn, wmw, wnw, wkw, ns; };
+constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {
+    {0, 0, 0, 0, 0, 0},
+    {128, 128, 2, 2, 1, 2},   // VIDC_TILE_128x128
+    {128, 64, 2, 2, 1, 3},    // VIDC_TILE_128x64
+    {64, 128, 2, 2, 1, 3},    // VIDC_TILE_64x128
+    {64, 64, 2, 2, 1, 4},     // VIDC_TILE_64x64
+    {64, 64, 2, 2, 2, 3},     // VIDC_TILE_64x64_K2   (8 waves)
+    {32, 64, 1, 2, 2, 3},     // VIDC_TILE_32x64_K2
+    {32, 32, 1, 1, 4, 3},     // VIDC_TILE_32x32_K4
+    {32, 128, 1, 4, 1, 4},    // VIDC_TILE_32x128
+    {32, 32, 1, 1, 8, 2},     // VIDC_TILE_32x32_K8   (8 waves)
+};
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WMW, int WNW, int WKW, int NS>
 int launch_tile(const ConvArgs& a, hipStream_t st) {
-    constexpr int NT = 64 * (BM / WM) * (BN / WN);
-    constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    constexpr int NT = 64 * WMW * WNW * WKW;
+    constexpr size_t lds = (size_t)NS * (BM + BN) * BK * WKW * sizeof(float);
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
-        VIDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN>),
+        VIDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WMW, WNW, WKW, NS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid(a.tiles_m * a.tiles_n, a.splitk, a.groups);
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN>), grid, dim3(NT), lds, st, a);
+    dim3 grid(a.tiles_m * a.tiles_n * a.splitk * a.groups, 1, 1);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WMW, WNW, WKW, NS>), grid, dim3(NT), lds, st, a);
     VIDC_CHECK_LAUNCH("conv_igemm_f32");
     return VIDC_OK;
 }
@@ -289,28 +468,29 @@ int validate(const vidc_conv_desc* d) {
 
 extern "C" int vidc_conv2d_plan(vidc_conv_desc* d) {
     VIDC_REQUIRE(d, VIDC_ERR_NULL, "conv plan: null descriptor");
-    // Cost model: every SIMD issues one 32x32x2 MFMA per 64 clk; a workgroup keeps the 4 SIMDs of one CU busy, so the
-    // time of a launch ~ ceil(workgroups / 256 CUs) * (MFMAs per wave) + fixed prologue/epilogue; split-K adds a pass
-    // over the partials.  Pick the (tile, splitk) minimising that.
+    // Cost model (the measured table in conv_tuning.json overrides it): every SIMD issues one 32x32x2 MFMA per 64 clk.
+    // A workgroup of NW waves puts NW/4 waves on each SIMD of its CU; with 256 CUs a launch takes about
+    // ceil(workgroups / 256) * (MFMA clocks of one workgroup per SIMD) + a fixed fill/drain cost, and global split-K
+    // adds a pass over the fp32 partials plus a second launch.
     const long long M = (long long)d->B * d->Ho * d->Wo;
-    const int ksteps = d->KH * d->KW * d->Cin / BK;
-    int n_cu = 256;
+    const int units = d->KH * d->KW * d->Cin / BK;
+    const int n_cu = 256;
     double best = 1e30;
     int best_tile = VIDC_TILE_64x64, best_sk = 1;
     for (int t = 1; t < VIDC_TILE_COUNT; ++t) {
         const TileInfo ti = kTiles[t];
-        if (ti.bn > d->Cout && ti.bn != 64) continue;
+        if (ti.bn > d->Cout && ti.bn > 64) continue;
         const long long tm = (M + ti.bm - 1) / ti.bm, tn = (d->Cout + ti.bn - 1) / ti.bn;
-        const int waves = ti.threads / 64;
-        const double mfma_per_wave_kstep = (double)(ti.bm / 32) * (ti.bn / 32) / waves * 16.0;
+        const int nw = ti.wmw * ti.wnw * ti.wkw;
+        const double mfma_per_wave_stage = (double)(ti.bm / (32 * ti.wmw)) * (ti.bn / (32 * ti.wnw)) * 16.0;
+        const int stages = (units + ti.wkw - 1) / ti.wkw;
         for (int sk = 1; sk <= 16; sk *= 2) {
-            if (sk > 1 && ksteps / sk < 8) break;
+            if (sk > 1 && stages / sk < 4) break;
             const long long wgs = tm * tn * sk * d->groups;
-            // a CU hosts 4 waves per "slot"; smaller workgroups pack (256/threads) per slot
-            const double slots = (double)wgs * ti.threads / 256.0;
-            const double rounds = ceil(slots / n_cu);
-            double cyc = rounds * ((double)((ksteps + sk - 1) / sk) * mfma_per_wave_kstep * 64.0 + 3000.0);
-            if (sk > 1) cyc += 4000.0 + (double)M * d->Cout * d->groups * (sk + 1) * 4.0 / 2500.0;   // ~6 TB/s @2.4 GHz
+            const double rounds = ceil((double)wgs / n_cu);
+            double cyc = rounds * ((double)((stages + sk - 1) / sk) * mfma_per_wave_stage * 64.0 * (nw / 4.0) + 2500.0) + 4000.0;
+            if (ti.wkw > 1) cyc += 1500.0;
+            if (sk > 1) cyc += 9000.0 + (double)M * d->Cout * d->groups * (sk + 1) * 4.0 / 2500.0;   // ~6 TB/s @2.4 GHz
             if (cyc < best) { best = cyc; best_tile = t; best_sk = sk; }
         }
     }
@@ -340,18 +520,25 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
     a.ldy = dd.ldy; a.ldr = dd.ldr; a.KH = dd.KH; a.KW = dd.KW; a.stride = dd.stride; a.pad = dd.pad; a.flags = dd.flags;
     a.groups = dd.groups; a.x_gs = dd.x_gs; a.w_gs = dd.w_gs; a.y_gs = dd.y_gs; a.r_gs = dd.r_gs; a.p_gs = dd.p_gs;
     a.M = dd.B * dd.Ho * dd.Wo; a.K = dd.KH * dd.KW * dd.Cin; a.ksteps = a.K / BK;
-    a.splitk = dd.splitk > a.ksteps ? a.ksteps : dd.splitk;
+    a.splitk = dd.splitk;
     const TileInfo ti = kTiles[dd.tile];
     a.tiles_m = (a.M + ti.bm - 1) / ti.bm;
     a.tiles_n = (a.Cout + ti.bn - 1) / ti.bn;
+    {
+        const int stages = (a.ksteps + ti.wkw - 1) / ti.wkw;
+        if (a.splitk > stages) a.splitk = stages;
+    }
     hipStream_t st = vidc::as_stream(stream);
     switch (dd.tile) {
-        case VIDC_TILE_128x128: rc = launch_tile<128, 128, 64, 64>(a, st); break;
-        case VIDC_TILE_128x64:  rc = launch_tile<128, 64, 64, 32>(a, st); break;
-        case VIDC_TILE_64x128:  rc = launch_tile<64, 128, 32, 64>(a, st); break;
-        case VIDC_TILE_64x64:   rc = launch_tile<64, 64, 32, 32>(a, st); break;
-        case VIDC_TILE_32x128:  rc = launch_tile<32, 128, 32, 32>(a, st); break;
-        case VIDC_TILE_32x64:   rc = launch_tile<32, 64, 32, 32>(a, st); break;
+        case VIDC_TILE_128x128:  rc = launch_tile<128, 128, 2, 2, 1, 2>(a, st); break;
+        case VIDC_TILE_128x64:   rc = launch_tile<128, 64, 2, 2, 1, 3>(a, st); break;
+        case VIDC_TILE_64x128:   rc = launch_tile<64, 128, 2, 2, 1, 3>(a, st); break;
+        case VIDC_TILE_64x64:    rc = launch_tile<64, 64, 2, 2, 1, 4>(a, st); break;
+        case VIDC_TILE_64x64_K2: rc = launch_tile<64, 64, 2, 2, 2, 3>(a, st); break;
+        case VIDC_TILE_32x64_K2: rc = launch_tile<32, 64, 1, 2, 2, 3>(a, st); break;
+        case VIDC_TILE_32x32_K4: rc = launch_tile<32, 32, 1, 1, 4, 3>(a, st); break;
+        case VIDC_TILE_32x128:   rc = launch_tile<32, 128, 1, 4, 1, 4>(a, st); break;
+        case VIDC_TILE_32x32_K8: rc = launch_tile<32, 32, 1, 1, 8, 2>(a, st); break;
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
     if (rc != VIDC_OK) return rc;
