@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--per-op", type=str, default="", help="write the per-op timing table to this file")
+    ap.add_argument("--in-flight", type=int, default=2, help="frames executing concurrently on separate HIP streams (1 = strictly sequential _call_cnn)")
     return ap.parse_args()
 
 
@@ -83,18 +84,23 @@ def main():
         b = S.synthetic_batch(B, H, W, 1234, frame0=(rank + j * world) * B)
         pool.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()})
 
-    def step(i):
-        return pipe._call_cnn(pool[i % len(pool)])
+    def run(n):
+        """n steps (= n frames of batch B through the whole hot path); all n outputs are complete on return."""
+        if args.in_flight <= 1:
+            for i in range(n):
+                out = pipe._call_cnn(pool[i % len(pool)])
+        else:
+            for out in pipe.run_stream((pool[i % len(pool)] for i in range(n)), in_flight=args.in_flight):
+                pass
+        return out
 
-    for i in range(args.warmup):
-        out = step(i)
+    run(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
+    run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -171,6 +177,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: synthetic %dx%d RGB + 200-pt sparse depth, batch %d per GPU, plane mask "
                                    "fixed; warp + surface-normal net + plane block/enrichment + depth-completion net" % (W, H, B),
                        "height": H, "width": W, "batch_per_gpu": B, "weights": "seeded random-init (seed 1234)",
+                       "frames_in_flight": args.in_flight,
                        "sharding": "frames round-robin over %d rank(s), no data-path collective" % world},
             "rmse_vs_oracle": (round(float(np.sqrt(se / npx)), 8) if npx else None),
             "roofline": roofline, "cpu_baseline": cpu_baseline,

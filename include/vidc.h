@@ -146,35 +146,49 @@ int vidc_head_conv1x1_upsample(const float* x, const float* w, const float* bias
  *   [10] 1 = depth written, 0 = plane failed the validity tests, -1 = n_pts > VIDC_MAX_HYP (needs the host permutation
  *        of main.py:78; not done on device)  [11] n projected pixels  [12] best hypothesis row */
 
-/* mean_normal_ranasc (main.py:38-62) + the inlier write-back of main.py:157 + the 20-degree acceptance test (:162).
+#define VIDC_MAX_SPARSE 4096      /* most sparse-depth pixels per image the plane-offset stage will look at */
+
+/* Bytes of device scratch the three plane stages below share for one batch (chunk partial sums, validity statistics,
+ * the per-image row-major list of sparse-depth pixels). */
+size_t vidc_plane_scratch_bytes(int n_slots, int B, int HW);
+
+/* mean_normal_ranasc (main.py:38-62) + the inlier write-back of main.py:157.
  * normals: NCHW [B][3][HW] unit normals; ids: [B][HW] uint8 plane-id maps; hyp_pix: flat pixel indices of the
  * hypothesis normals of every slot, concatenated (the host draws np.random.permutation exactly like main.py:43);
- * inlier_mask: [n_slots][HW] uint8 out; counts: [n_slots][VIDC_MAX_HYP] int32 scratch; records: [n_slots][16] out. */
+ * inlier_mask: [n_slots][HW] uint8 out; counts: [n_slots][VIDC_MAX_HYP] int32 out (inliers per hypothesis);
+ * the mean normal / mean angle partial sums stay in `scratch` for vidc_plane_offset. */
 int vidc_plane_ransac_normal(const float* normals, const uint8_t* ids, const int32_t* slots, int n_slots,
-                             const int32_t* hyp_pix, int HW, uint8_t* inlier_mask, int32_t* counts, float* records,
+                             const int32_t* hyp_pix, int HW, uint8_t* inlier_mask, int32_t* counts, void* scratch,
                              vidc_stream_t stream);
 
-/* plane_offset_ransac (main.py:68-101) with the point cloud of main.py:171-173: points homo*depth on
+/* Finishes the record of every slot (n_bar, mean |angle|, the 20-degree acceptance test of main.py:162), then
+ * plane_offset_ransac (main.py:68-101) with the point cloud of main.py:171-173: points homo*depth on
  * inlier_mask & depth>0 (row-major order), hypotheses d_j = -n.P_j (all points, n_pts <= VIDC_MAX_HYP, :76-77),
  * inliers |d_j + n.P| < 0.1, d = -mean(n.P over the best hypothesis' inliers).  homo: [B][HW][3]; depth: [B][HW]. */
-int vidc_plane_offset(const float* homo, const float* depth, const int32_t* slots, int n_slots, const uint8_t* inlier_mask,
-                      int HW, float* records, vidc_stream_t stream);
+int vidc_plane_offset(const float* homo, const float* depth, const int32_t* slots, int n_slots, int B,
+                      const uint8_t* inlier_mask, const int32_t* counts, int HW, void* scratch, float* records,
+                      vidc_stream_t stream);
 
 /* generate_depth_from_plane (main.py:110-127) -- the normal->depth plane projection: depth = -d/(n.homo) on
  * mask & |n.homo| > 1e-3; the plane is dropped when > 5% of its values exceed 10*mean_depth, any exceeds 10 m or any
  * is negative; otherwise the values are written into plane_depth [B][HW] (pre-initialised with the sparse depth). */
 int vidc_plane_project_depth(const float* homo, const int32_t* slots, int n_slots, const uint8_t* inlier_mask, int HW,
-                             float* records, float* plane_depth, vidc_stream_t stream);
+                             void* scratch, float* records, float* plane_depth, vidc_stream_t stream);
 
-/* main.py:186-187 (the original sparse depths override the plane depths) fused with the count the enrichment needs
- * (main.py:287-289): plane_depth[p] = depth[p] where depth[p] > 0; nnz_out[b] = #(plane_depth[b] > 0). */
-int vidc_plane_finalize(const float* depth, float* plane_depth, int B, int HW, int32_t* nnz_out, vidc_stream_t stream);
+/* main.py:186-187 (the original sparse depths override the plane depths) fused with what the enrichment needs from the
+ * device (main.py:287-289): plane_depth[p] = depth[p] where depth[p] > 0, and `info` (vidc_plane_info_count(B,HW)
+ * int32) = for every image the number of pixels with plane_depth > 0 in each 256-pixel chunk, followed by one word:
+ * the number of slots whose record is flagged -1.  This buffer is the ONLY device->host read of the whole path. */
+int vidc_plane_info_count(int B, int HW);
+int vidc_plane_finalize(const float* depth, float* plane_depth, int B, int HW, const float* records, int n_slots,
+                        int32_t* info, vidc_stream_t stream);
 
 /* main.py:290-294: for image b the sub[k]-th nonzeros (row-major, like torch.nonzero) of plane_depth[b] are copied
  * into enriched[b] (a clone of the sparse depth).  sub: sorted unique indices drawn on the host with
- * np.unique(np.random.randint(...)); image b owns sub[sub_offsets[b] .. sub_offsets[b+1]). */
-int vidc_enrich_scatter(const float* plane_depth, const int32_t* sub, const int32_t* sub_offsets, int B, int HW,
-                        float* enriched, vidc_stream_t stream);
+ * np.unique(np.random.randint(...)); image b owns sub[sub_offsets[b] .. sub_offsets[b+1]); chunk_base: [B][chunks]
+ * exclusive prefix sums of the chunk counts returned by vidc_plane_finalize. */
+int vidc_enrich_scatter(const float* plane_depth, const int32_t* sub, const int32_t* sub_offsets, const int32_t* chunk_base,
+                        int B, int HW, float* enriched, vidc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * programs: a whole network (or the whole frame) as one native call / one hipGraph

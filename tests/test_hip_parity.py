@@ -308,7 +308,8 @@ def test_plane_block_vs_golden(pipeline, golden_dir, name):
     np.random.seed(int(f["np_seed"]))
     normals = torch.from_numpy(f["normals"])[None].to(DEV)
     ds = b["sparse_depth"].to(DEV)
-    di, nnz = pipeline.planes.plane_depth(normals, [S.plane_id_map(240, 320)], ds, b["homogeneous_coordinates"].to(DEV))
+    di, info = pipeline.planes.plane_depth(normals, [S.plane_id_map(240, 320)], ds, b["homogeneous_coordinates"].to(DEV))
+    nnz = [int(info[:-1].sum())]
     rec = pipeline.planes.last_records.cpu().numpy()
     for s, slot in enumerate(pipeline.planes.last_slots):
         p = "plane%d" % slot[1]
@@ -323,7 +324,7 @@ def test_plane_block_vs_golden(pipeline, golden_dir, name):
     assert np.mean(d > 5e-3 * np.maximum(pd, 1.0)) < 1e-3          # fp16 golden copy: 5e-3 relative, <0.1% outliers
     assert abs(float(di.double().sum()) - float(f["plane_depth_sum"])) < 1e-4 * float(f["plane_depth_sum"]) + 20.0
     if int(nnz[0]) == int(f["enrich.nnz"]):                          # same candidate count -> identical draws
-        en = pipeline.planes.enrich(ds, di, nnz, 200)
+        en = pipeline.planes.enrich(ds, di, info, 200)
         assert np.array_equal(pipeline.planes.last_sub[0], f["enrich.sub"])
         rc = f["enriched_rc"]
         e = en[0, 0].cpu().numpy()
@@ -365,6 +366,24 @@ def test_graph_and_eager_agree(pipeline, monkeypatch):
     monkeypatch.setenv("VIDC_EXEC", "eager")
     b = pipeline.surface_normal_cnn(*x)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_run_stream_matches_sequential(pipeline, in_flight):
+    """Frames in flight on separate HIP streams give bit-identical depth maps to sequential _call_cnn calls when
+    every frame owns its RNG (frame order, slot reuse and drain are all exercised with 7 frames)."""
+    frames = [S.synthetic_batch(1, 240, 320, 1234, frame0=20 + i) for i in range(7)]
+    frames = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()} for b in frames]
+    seq = []
+    saved = pipeline.rng
+    for i, b in enumerate(frames):
+        pipeline.rng = np.random.RandomState(100 + i)
+        seq.append(pipeline._call_cnn(b).cpu())
+    pipeline.rng = saved
+    outs = [o.cpu() for o in pipeline.run_stream(iter(frames), in_flight=in_flight, frame_rng=lambda i: np.random.RandomState(100 + i))]
+    assert len(outs) == len(seq)
+    for a, b in zip(outs, seq):
+        assert torch.equal(a, b)
 
 
 def test_modules_refuse_cpu_and_training(pipeline):

@@ -72,11 +72,13 @@ SIGNATURES = {
     "vidc_maxpool3x3s2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_upsample_bilinear_ac": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_head_conv1x1_upsample": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vidc_plane_scratch_bytes": (C.c_size_t, [_i, _i, _i]),
     "vidc_plane_ransac_normal": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
-    "vidc_plane_offset": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
-    "vidc_plane_project_depth": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
-    "vidc_plane_finalize": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp]),
-    "vidc_enrich_scatter": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "vidc_plane_offset": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "vidc_plane_project_depth": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "vidc_plane_info_count": (C.c_int, [_i, _i]),
+    "vidc_plane_finalize": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    "vidc_enrich_scatter": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "vidc_program_create": (C.c_int, [C.POINTER(Op), _i, C.POINTER(_vp)]),
     "vidc_program_run": (C.c_int, [_vp, _vp]),
     "vidc_program_capture": (C.c_int, [_vp, _vp]),

@@ -1,14 +1,15 @@
 // Plane block on device: RANSAC mean normal, plane-offset RANSAC, normal->depth plane projection, sparse-depth
-// override + count, and enrichment scatter.  Replaces main.py:29-190 and :285-294 of the reference, where each plane
-// costs ~470 ATen calls and dozens of host syncs; here every stage is ONE launch over all plane "slots"
-// (slot = one plane id of one image of the batch) and nothing synchronises with the host.
+// override + candidate counts, and enrichment scatter.  Replaces main.py:29-190 and :285-294 of the reference, where
+// each plane costs ~470 ATen calls and dozens of host syncs; here every stage is a launch over ALL plane "slots"
+// (slot = one plane id of one image of the batch) x pixel chunks, reductions are two-level with a fixed order
+// (bit-reproducible), and the host is synchronised exactly once per batch (the read of the enrichment counts).
 //
 // Random draws stay on the host (numpy legacy RNG, exactly like the reference) and arrive as index arrays.
 #include "common.h"
 
 namespace {
 
-constexpr int NT = 1024;                  // threads of the single-workgroup-per-slot kernels
+constexpr int CH = 256;                   // pixels per workgroup chunk
 constexpr float ANGLE_THR = 20.0f;        // MEAN_NORMAL_ANGLE_DIFF_THR / angle_threshold_degrees (main.py:25,38)
 constexpr float RAD2DEG = (float)(180.0 / 3.14159265358979323846);
 constexpr float COS_THR = 0.93969262078590838f;   // cos(20 deg)
@@ -31,8 +32,9 @@ __device__ inline float dot3(float ax, float ay, float az, float bx, float by, f
     return fmaf(az, bz, fmaf(ay, by, ax * bx));
 }
 
+// Sum over the 256 threads of a workgroup; fixed order -> deterministic.  Result valid in every thread.
 template <typename T>
-__device__ inline T block_sum(T v, T* red) {          // all NT threads call; result broadcast
+__device__ inline T block_sum(T v, T* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -40,171 +42,202 @@ __device__ inline T block_sum(T v, T* red) {          // all NT threads call; re
     if (lane == 0) red[wave] = v;
     __syncthreads();
     T s = 0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];   // fixed order -> deterministic
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
     return s;
 }
 
-// ---- stage 1a: inlier counts of every hypothesis (grid: pixel chunks x slots) -----------------------------------
-__global__ void __launch_bounds__(256)
+__device__ inline int first_argmax(const int32_t* c, int n) {   // torch.argmax: first maximal index
+    int best = 0, bc = -1;
+    for (int h = 0; h < n; ++h) if (c[h] > bc) { bc = c[h]; best = h; }
+    return best;
+}
+
+// ---- stage 1a: inlier counts of every hypothesis.  threads = hypotheses, 256 pixels of one slot staged in LDS ---------
+__global__ void __launch_bounds__(320)
 ransac_count_kernel(const float* __restrict__ normals, const uint8_t* __restrict__ ids, const Slot* __restrict__ slots,
                     const int32_t* __restrict__ hyp_pix, int HW, int32_t* __restrict__ counts) {
-    __shared__ float hn[VIDC_MAX_HYP * 3];
-    __shared__ int cnt[VIDC_MAX_HYP];
+    __shared__ float px[CH], py[CH], pz[CH];
+    __shared__ int n_mine;
     const Slot s = slots[blockIdx.y];
     const float* nb = normals + (size_t)s.b * 3 * HW;
     const uint8_t* idb = ids + (size_t)s.b * HW;
-    for (int h = threadIdx.x; h < s.n_hyp; h += blockDim.x) {
-        int p = hyp_pix[s.hyp_off + h];
-        hn[h * 3 + 0] = nb[p]; hn[h * 3 + 1] = nb[HW + p]; hn[h * 3 + 2] = nb[2 * HW + p];
-        cnt[h] = 0;
-    }
+    if (threadIdx.x == 0) n_mine = 0;
     __syncthreads();
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = p < HW && idb[p] == (uint8_t)s.cls;
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    if (mine) { nx = nb[p]; ny = nb[HW + p]; nz = nb[2 * HW + p]; }
-    const int lane = threadIdx.x & 63;
-    if (__ballot(mine) != 0ull) {
-        for (int h = 0; h < s.n_hyp; ++h) {
-            bool c = mine && close_angle(dot3(hn[h * 3], hn[h * 3 + 1], hn[h * 3 + 2], nx, ny, nz));
-            unsigned long long m = __ballot(c);
-            if (lane == 0 && m) atomicAdd(&cnt[h], __popcll(m));
+    if (threadIdx.x < CH) {          // compact this chunk's pixels of the class into LDS (order is irrelevant for a count)
+        const int p = blockIdx.x * CH + threadIdx.x;
+        if (p < HW && idb[p] == (uint8_t)s.cls) {
+            int k = atomicAdd(&n_mine, 1);
+            px[k] = nb[p]; py[k] = nb[HW + p]; pz[k] = nb[2 * HW + p];
         }
     }
     __syncthreads();
-    for (int h = threadIdx.x; h < s.n_hyp; h += blockDim.x)
-        if (cnt[h]) atomicAdd(&counts[blockIdx.y * VIDC_MAX_HYP + h], cnt[h]);
+    const int n = n_mine;
+    if (n == 0 || (int)threadIdx.x >= s.n_hyp) return;
+    const int hp = hyp_pix[s.hyp_off + threadIdx.x];
+    const float hx = nb[hp], hy = nb[HW + hp], hz = nb[2 * HW + hp];
+    int c = 0;
+    for (int k = 0; k < n; ++k) c += close_angle(dot3(hx, hy, hz, px[k], py[k], pz[k])) ? 1 : 0;
+    if (c) atomicAdd(&counts[blockIdx.y * VIDC_MAX_HYP + threadIdx.x], c);     // integer: order-independent
 }
 
-// ---- stage 1b: best hypothesis -> inlier mask, mean normal, mean angle (one workgroup per slot) ----------------------
-__global__ void __launch_bounds__(NT)
-ransac_select_kernel(const float* __restrict__ normals, const uint8_t* __restrict__ ids, const Slot* __restrict__ slots,
-                     const int32_t* __restrict__ hyp_pix, int HW, const int32_t* __restrict__ counts,
-                     uint8_t* __restrict__ inlier_mask, float* __restrict__ records) {
-    __shared__ float redf[NT / 64];
-    __shared__ int redi[NT / 64];
+// ---- stage 1b: inlier mask of the best hypothesis + per-chunk partial sums of the inlier normals ---------------------
+__global__ void __launch_bounds__(CH)
+ransac_mask_kernel(const float* __restrict__ normals, const uint8_t* __restrict__ ids, const Slot* __restrict__ slots,
+                   const int32_t* __restrict__ hyp_pix, int HW, const int32_t* __restrict__ counts,
+                   uint8_t* __restrict__ inlier_mask, float* __restrict__ partial /* [slot][chunk][4] */) {
+    __shared__ float redf[CH / 64];
     __shared__ int s_best;
-    const Slot s = slots[blockIdx.x];
+    const Slot s = slots[blockIdx.y];
     const float* nb = normals + (size_t)s.b * 3 * HW;
-    const uint8_t* idb = ids + (size_t)s.b * HW;
-    uint8_t* mk = inlier_mask + (size_t)blockIdx.x * HW;
-    float* rec = records + (size_t)blockIdx.x * VIDC_PLANE_RECORD;
-    if (threadIdx.x == 0) {          // torch.argmax: first maximal index
-        int best = 0, bc = -1;
-        for (int h = 0; h < s.n_hyp; ++h) {
-            int c = counts[blockIdx.x * VIDC_MAX_HYP + h];
-            if (c > bc) { bc = c; best = h; }
-        }
-        s_best = best;
-    }
+    if (threadIdx.x == 0) s_best = first_argmax(counts + blockIdx.y * VIDC_MAX_HYP, s.n_hyp);
     __syncthreads();
     const int bp = s.n_hyp > 0 ? hyp_pix[s.hyp_off + s_best] : 0;
     const float hx = nb[bp], hy = nb[HW + bp], hz = nb[2 * HW + bp];
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    int n_in = 0;
-    const int per = vidc::cdiv(HW, NT);
-    const int p0 = threadIdx.x * per, p1 = min(HW, p0 + per);
-    for (int p = p0; p < p1; ++p) {
-        bool in = false;
-        if (s.n_hyp > 0 && idb[p] == (uint8_t)s.cls) {
-            float nx = nb[p], ny = nb[HW + p], nz = nb[2 * HW + p];
-            in = close_angle(dot3(hx, hy, hz, nx, ny, nz));
-            if (in) { sx += nx; sy += ny; sz += nz; ++n_in; }
-        }
-        mk[p] = in ? 1 : 0;
+    const int p = blockIdx.x * CH + threadIdx.x;
+    bool in = false;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (p < HW && s.n_hyp > 0 && ids[(size_t)s.b * HW + p] == (uint8_t)s.cls) {
+        nx = nb[p]; ny = nb[HW + p]; nz = nb[2 * HW + p];
+        in = close_angle(dot3(hx, hy, hz, nx, ny, nz));
     }
-    sx = block_sum(sx, redf); sy = block_sum(sy, redf); sz = block_sum(sz, redf);
-    n_in = block_sum(n_in, redi);
-    // mean_normal (main.py:29-34): F.normalize(mean)
-    float mx = 0.f, my = 0.f, mz = 0.f;
-    if (n_in > 0) {
-        mx = sx / (float)n_in; my = sy / (float)n_in; mz = sz / (float)n_in;
-        float nrm = fmaxf(sqrtf(mx * mx + my * my + mz * mz), 1e-12f);
-        mx /= nrm; my /= nrm; mz /= nrm;
-    }
-    float asum = 0.f;
-    for (int p = p0; p < p1; ++p)
-        if (mk[p]) {
-            float d = fminf(fmaxf(dot3(nb[p], nb[HW + p], nb[2 * HW + p], mx, my, mz), -1.f), 1.f);
-            asum += fabsf(acosf(d) * RAD2DEG);
-        }
-    asum = block_sum(asum, redf);
+    if (p < HW) inlier_mask[(size_t)blockIdx.y * HW + p] = in ? 1 : 0;
+    const float sx = block_sum(in ? nx : 0.f, redf), sy = block_sum(in ? ny : 0.f, redf), sz = block_sum(in ? nz : 0.f, redf);
+    const float cn = block_sum(in ? 1.f : 0.f, redf);
     if (threadIdx.x == 0) {
-        float mean_angle = n_in > 0 ? asum / (float)n_in : 0.f;
-        rec[0] = mx; rec[1] = my; rec[2] = mz; rec[3] = 0.f;
-        rec[4] = (float)n_in; rec[5] = mean_angle;
-        rec[6] = (n_in > 0 && !(mean_angle > ANGLE_THR)) ? 1.f : 0.f;
-        for (int i = 7; i < VIDC_PLANE_RECORD; ++i) rec[i] = 0.f;
-        rec[12] = (float)s_best;
+        float* q = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        q[0] = sx; q[1] = sy; q[2] = sz; q[3] = cn;
     }
 }
 
-// ---- stage 2: plane offset from the sparse depths on the inliers (one workgroup per slot) ---------------------------
-__global__ void __launch_bounds__(NT)
+// mean_normal (main.py:29-34) from the chunk partials; fixed two-level order (thread t owns chunks t, t+256, ...), so every
+// workgroup that recomputes it gets the same bits.
+__device__ inline void mean_normal_from_partials(const float* partial, int n_chunks, float* redf /* LDS [CH/64] */, float& mx,
+                                                 float& my, float& mz, int& n_in) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int c = threadIdx.x; c < n_chunks; c += CH) {
+        const float4 q = *reinterpret_cast<const float4*>(partial + (size_t)c * 4);
+        s0 += q.x; s1 += q.y; s2 += q.z; s3 += q.w;
+    }
+    s0 = block_sum(s0, redf); s1 = block_sum(s1, redf); s2 = block_sum(s2, redf); s3 = block_sum(s3, redf);
+    n_in = (int)s3;
+    mx = my = mz = 0.f;
+    if (n_in > 0) {
+        mx = s0 / (float)n_in; my = s1 / (float)n_in; mz = s2 / (float)n_in;
+        const float nrm = fmaxf(sqrtf(mx * mx + my * my + mz * mz), 1e-12f);   // F.normalize
+        mx /= nrm; my /= nrm; mz /= nrm;
+    }
+}
+
+// ---- stage 1c: per-chunk partial sums of |angle(n, n_bar)| over the inliers ---------------------------------------------
+__global__ void __launch_bounds__(CH)
+ransac_angle_kernel(const float* __restrict__ normals, const Slot* __restrict__ slots, int HW,
+                    const uint8_t* __restrict__ inlier_mask, const float* __restrict__ partial, float* __restrict__ apartial) {
+    __shared__ float redf[CH / 64];
+    const Slot s = slots[blockIdx.y];
+    const float* nb = normals + (size_t)s.b * 3 * HW;
+    float mx, my, mz; int n_in;
+    mean_normal_from_partials(partial + (size_t)blockIdx.y * gridDim.x * 4, gridDim.x, redf, mx, my, mz, n_in);
+    const int p = blockIdx.x * CH + threadIdx.x;
+    float a = 0.f;
+    if (p < HW && inlier_mask[(size_t)blockIdx.y * HW + p]) {
+        const float d = fminf(fmaxf(dot3(nb[p], nb[HW + p], nb[2 * HW + p], mx, my, mz), -1.f), 1.f);
+        a = fabsf(acosf(d) * RAD2DEG);
+    }
+    a = block_sum(a, redf);
+    if (threadIdx.x == 0) apartial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = a;
+}
+
+// ---- stage 2: record + plane offset from the (few) sparse depths on the inliers.  One workgroup per slot. ---------------
+// sparse_idx: per image, the flat indices of the pixels with depth > 0 in row-major order (boolean-indexing order),
+// built once per batch by sparse_list_kernel; n_sparse[b] their count.
+__global__ void __launch_bounds__(CH)
 plane_offset_kernel(const float* __restrict__ homo, const float* __restrict__ depth, const Slot* __restrict__ slots,
-                    const uint8_t* __restrict__ inlier_mask, int HW, float* __restrict__ records) {
+                    const uint8_t* __restrict__ inlier_mask, int HW, int n_chunks, const float* __restrict__ partial,
+                    const float* __restrict__ apartial, const int32_t* __restrict__ sparse_idx, const int32_t* __restrict__ n_sparse,
+                    int max_sparse, const int32_t* __restrict__ counts, float* __restrict__ records) {
+    __shared__ float redf[CH / 64];
+    __shared__ int redi[CH / 64];
     __shared__ float dots[VIDC_MAX_HYP];
-    __shared__ int redi[NT / 64];
-    __shared__ float redf[NT / 64];
-    __shared__ int scan[NT];
     __shared__ int hcnt[VIDC_MAX_HYP];
-    __shared__ int s_best;
+    __shared__ int s_n, s_best;
+    __shared__ float s_dsum;
     const Slot s = slots[blockIdx.x];
     float* rec = records + (size_t)blockIdx.x * VIDC_PLANE_RECORD;
-    if (rec[6] == 0.f) return;                      // plane rejected by the normal test (main.py:162)
+    float mx, my, mz; int n_in;
+    mean_normal_from_partials(partial + (size_t)blockIdx.x * n_chunks * 4, n_chunks, redf, mx, my, mz, n_in);
+    float asum = 0.f;
+    for (int c = threadIdx.x; c < n_chunks; c += CH) asum += apartial[(size_t)blockIdx.x * n_chunks + c];
+    // fixed-order second level: thread t owns chunks t, t+256, ...; block_sum is order-fixed too
+    asum = block_sum(asum, redf);
+    const float mean_angle = n_in > 0 ? asum / (float)n_in : 0.f;
+    const bool accepted = n_in > 0 && !(mean_angle > ANGLE_THR);            // main.py:162
+    if (threadIdx.x == 0) {
+        rec[0] = mx; rec[1] = my; rec[2] = mz; rec[3] = 0.f; rec[4] = (float)n_in; rec[5] = mean_angle; rec[6] = accepted ? 1.f : 0.f;
+        for (int i = 7; i < VIDC_PLANE_RECORD; ++i) rec[i] = 0.f;
+        rec[12] = (float)first_argmax(counts + blockIdx.x * VIDC_MAX_HYP, s.n_hyp);
+        s_n = 0; s_dsum = 0.f;
+    }
+    __syncthreads();
+    if (!accepted) return;
+    // ordered compaction of the sparse points that lie on the plane (the list is already in row-major order)
     const float* hb = homo + (size_t)s.b * HW * 3;
     const float* db = depth + (size_t)s.b * HW;
     const uint8_t* mk = inlier_mask + (size_t)blockIdx.x * HW;
-    const float nx = rec[0], ny = rec[1], nz = rec[2];
-    const int per = vidc::cdiv(HW, NT);
-    const int p0 = threadIdx.x * per, p1 = min(HW, p0 + per);
-    int mine = 0;
-    float dsum = 0.f;
-    for (int p = p0; p < p1; ++p)
-        if (mk[p] && db[p] > 0.f) { ++mine; dsum += db[p]; }
-    // ordered compaction (row-major like boolean indexing): exclusive scan of per-thread counts
-    scan[threadIdx.x] = mine;
-    __syncthreads();
-    for (int off = 1; off < NT; off <<= 1) {
-        int v = threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
-        __syncthreads();
-        scan[threadIdx.x] += v;
-        __syncthreads();
+    const int ns = min(n_sparse[s.b], max_sparse);
+    {
+        __shared__ int wcnt[CH / 64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        int total = 0;
+        float dloc = 0.f;
+        for (int base = 0; base < ns; base += CH) {       // uniform trip count; ranks keep the list's row-major order
+            const int i = base + threadIdx.x;
+            bool f = false;
+            float d = 0.f, dt = 0.f;
+            if (i < ns) {
+                const int p = sparse_idx[(size_t)s.b * max_sparse + i];
+                if (mk[p]) {
+                    f = true;
+                    d = db[p];
+                    dt = dot3(mx, my, mz, hb[p * 3] * d, hb[p * 3 + 1] * d, hb[p * 3 + 2] * d);
+                }
+            }
+            const unsigned long long m = __ballot(f);
+            __syncthreads();
+            if (lane == 0) wcnt[wave] = __popcll(m);
+            __syncthreads();
+            int k = total;
+            for (int w = 0; w < wave; ++w) k += wcnt[w];
+            k += __popcll(m & ((1ull << lane) - 1ull));
+            if (f && k < VIDC_MAX_HYP) dots[k] = dt;
+            dloc += d;
+            for (int w = 0; w < CH / 64; ++w) total += wcnt[w];
+        }
+        dloc = block_sum(dloc, redf);
+        if (threadIdx.x == 0) { s_n = total; s_dsum = dloc; }
     }
-    const int n_pts = scan[NT - 1];
-    int k = scan[threadIdx.x] - mine;
-    dsum = block_sum(dsum, redf);
-    if (n_pts > VIDC_MAX_HYP) {                      // would need the host permutation (main.py:78): flagged, not faked
+    __syncthreads();
+    const int n_pts = s_n;
+    if (n_pts > VIDC_MAX_HYP || n_sparse[s.b] > max_sparse) {   // would need the host permutation (main.py:78): flagged, not faked
         if (threadIdx.x == 0) { rec[7] = (float)n_pts; rec[9] = 0.f; rec[10] = -1.f; rec[6] = 0.f; }
         return;
     }
-    for (int p = p0; p < p1; ++p)
-        if (mk[p] && db[p] > 0.f) {
-            float d = db[p];
-            dots[k++] = dot3(nx, ny, nz, hb[p * 3] * d, hb[p * 3 + 1] * d, hb[p * 3 + 2] * d);
-        }
-    __syncthreads();
     float offset = 0.f;
     int n_inl = 0;
     if (n_pts == 1) {
         offset = -dots[0]; n_inl = 1;               // main.py:81-83
     } else if (n_pts > 1) {
-        for (int j = threadIdx.x; j < n_pts; j += NT) {
+        for (int j = threadIdx.x; j < n_pts; j += CH) {
             int c = 0;
             const float hyp = -dots[j];
             for (int i = 0; i < n_pts; ++i) c += (fabsf(hyp + dots[i]) < DIST_THR) ? 1 : 0;
             hcnt[j] = c;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int best = 0, bc = -1;
-            for (int j = 0; j < n_pts; ++j) if (hcnt[j] > bc) { bc = hcnt[j]; best = j; }
-            s_best = best;
-        }
+        if (threadIdx.x == 0) s_best = first_argmax(hcnt, n_pts);
         __syncthreads();
         const float hyp = -dots[s_best];
         float sdot = 0.f; int c = 0;
-        for (int i = threadIdx.x; i < n_pts; i += NT)
+        for (int i = threadIdx.x; i < n_pts; i += CH)
             if (fabsf(hyp + dots[i]) < DIST_THR) { sdot += dots[i]; ++c; }
         sdot = block_sum(sdot, redf);
         n_inl = block_sum(c, redi);
@@ -213,153 +246,224 @@ plane_offset_kernel(const float* __restrict__ homo, const float* __restrict__ de
     if (threadIdx.x == 0) {
         rec[3] = offset;
         rec[7] = (float)n_pts;
-        rec[8] = n_pts > 0 ? dsum / (float)n_pts : 0.f;
+        rec[8] = n_pts > 0 ? s_dsum / (float)n_pts : 0.f;
         rec[9] = (float)n_inl;
     }
 }
 
-// ---- stage 3: depth = -d / (n . homo) on the plane, validity tests, masked write (one workgroup per slot) ------------
-__global__ void __launch_bounds__(NT)
-plane_project_kernel(const float* __restrict__ homo, const Slot* __restrict__ slots, const uint8_t* __restrict__ inlier_mask,
-                     int HW, float* __restrict__ records, float* __restrict__ plane_depth) {
-    __shared__ int redi[NT / 64];
-    const Slot s = slots[blockIdx.x];
-    float* rec = records + (size_t)blockIdx.x * VIDC_PLANE_RECORD;
-    if (rec[6] == 0.f || rec[9] == 0.f) return;      // rejected plane, or no offset inliers (main.py:176-178)
-    const float* hb = homo + (size_t)s.b * HW * 3;
-    const uint8_t* mk = inlier_mask + (size_t)blockIdx.x * HW;
-    float* out = plane_depth + (size_t)s.b * HW;
-    const float nx = rec[0], ny = rec[1], nz = rec[2], d = rec[3], mean_depth = rec[8];
-    const int per = vidc::cdiv(HW, NT);
-    const int p0 = threadIdx.x * per, p1 = min(HW, p0 + per);
-    int n = 0, n_big = 0, n_over = 0, n_neg = 0;
-    for (int p = p0; p < p1; ++p) {
-        if (!mk[p]) continue;
-        float dots = (hb[p * 3] * nx + hb[p * 3 + 1] * ny) + hb[p * 3 + 2] * nz;
-        if (!(fabsf(dots) > 1e-3f)) continue;
-        float v = -d / dots;
-        ++n;
-        n_big += v > mean_depth * MAX_DEPTH_MULT;
-        n_over += v > MAX_DEPTH;
-        n_neg += v < 0.f;
-    }
-    n = block_sum(n, redi); n_big = block_sum(n_big, redi); n_over = block_sum(n_over, redi); n_neg = block_sum(n_neg, redi);
-    bool valid = true;
-    if (n > 0) {
-        if ((float)n_big / (float)n > 0.05f || n_over > 0) valid = false;
-        if (n_neg > 0) valid = false;
-    }
-    if (threadIdx.x == 0) { rec[10] = valid ? 1.f : 0.f; rec[11] = (float)n; }
-    if (!valid) return;
-    for (int p = p0; p < p1; ++p) {
-        if (!mk[p]) continue;
-        float dots = (hb[p * 3] * nx + hb[p * 3 + 1] * ny) + hb[p * 3 + 2] * nz;
-        if (fabsf(dots) > 1e-3f) out[p] = -d / dots;
-    }
-}
-
-// ---- stage 4: sparse depths override the plane depths; count the candidates for enrichment ---------------------------
-__global__ void __launch_bounds__(256)
-plane_finalize_kernel(const float* __restrict__ depth, float* __restrict__ plane_depth, int HW, int32_t* __restrict__ nnz) {
-    const int b = blockIdx.y;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    bool nz = false;
-    if (p < HW) {
-        float d = depth[(size_t)b * HW + p];
-        float v = plane_depth[(size_t)b * HW + p];
-        if (d > 0.f) { v = d; plane_depth[(size_t)b * HW + p] = d; }
-        nz = v > 0.f;
-    }
-    unsigned long long m = __ballot(nz);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&nnz[b], __popcll(m));
-}
-
-// ---- stage 5: copy the sub[]-th nonzeros (row-major order) of plane_depth into the enriched sparse depth -----------
-__global__ void __launch_bounds__(NT)
-enrich_scatter_kernel(const float* __restrict__ plane_depth, const int32_t* __restrict__ sub, const int32_t* __restrict__ sub_off,
-                      int HW, float* __restrict__ enriched) {
-    __shared__ int scan[NT];
+// Row-major list of the pixels with depth > 0 of every image (one workgroup per image; each thread owns a contiguous run).
+__global__ void __launch_bounds__(1024)
+sparse_list_kernel(const float* __restrict__ depth, int HW, int max_sparse, int32_t* __restrict__ sparse_idx,
+                   int32_t* __restrict__ n_sparse) {
+    __shared__ int scan[1024];
     const int b = blockIdx.x;
-    const float* pd = plane_depth + (size_t)b * HW;
-    float* en = enriched + (size_t)b * HW;
-    const int s0 = sub_off[b], n_sub = sub_off[b + 1] - s0;
-    if (n_sub <= 0) return;
-    const int per = vidc::cdiv(HW, NT);
+    const float* db = depth + (size_t)b * HW;
+    const int per = vidc::cdiv(HW, 1024);
     const int p0 = threadIdx.x * per, p1 = min(HW, p0 + per);
     int mine = 0;
-    for (int p = p0; p < p1; ++p) mine += pd[p] > 0.f;
+    for (int p = p0; p < p1; ++p) mine += db[p] > 0.f;
     scan[threadIdx.x] = mine;
     __syncthreads();
-    for (int off = 1; off < NT; off <<= 1) {
-        int v = threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (int)threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
         __syncthreads();
         scan[threadIdx.x] += v;
         __syncthreads();
     }
     int k = scan[threadIdx.x] - mine;
-    // first entry of sub[] that is >= k (sub is sorted, unique)
-    int lo = 0, hi = n_sub;
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (sub[s0 + mid] < k) lo = mid + 1; else hi = mid; }
-    for (int p = p0; p < p1 && lo < n_sub; ++p)
-        if (pd[p] > 0.f) {
-            if (sub[s0 + lo] == k) { en[p] = pd[p]; ++lo; }
-            ++k;
-        }
+    for (int p = p0; p < p1 && mine; ++p)
+        if (db[p] > 0.f) { if (k < max_sparse) sparse_idx[(size_t)b * max_sparse + k] = p; ++k; }
+    if (threadIdx.x == 1023) n_sparse[b] = scan[1023];
+}
+
+// ---- stage 3: depth = -d / (n . homo) on the plane: per-chunk validity statistics, then the masked write ---------------
+__device__ inline bool plane_value(const float* hb, int p, float nx, float ny, float nz, float d, float& v) {
+    const float dots = (hb[p * 3] * nx + hb[p * 3 + 1] * ny) + hb[p * 3 + 2] * nz;
+    if (!(fabsf(dots) > 1e-3f)) return false;
+    v = -d / dots;
+    return true;
+}
+
+__global__ void __launch_bounds__(CH)
+plane_stats_kernel(const float* __restrict__ homo, const Slot* __restrict__ slots, const uint8_t* __restrict__ inlier_mask, int HW,
+                   const float* __restrict__ records, int32_t* __restrict__ stats /* [slot][chunk][4] */) {
+    __shared__ int redi[CH / 64];
+    const Slot s = slots[blockIdx.y];
+    const float* rec = records + (size_t)blockIdx.y * VIDC_PLANE_RECORD;
+    int32_t* q = stats + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    if (rec[6] == 0.f || rec[9] == 0.f) {            // rejected plane, or no offset inliers (main.py:176-178)
+        if (threadIdx.x < 4) q[threadIdx.x] = 0;
+        return;
+    }
+    const float* hb = homo + (size_t)s.b * HW * 3;
+    const int p = blockIdx.x * CH + threadIdx.x;
+    int n = 0, n_big = 0, n_over = 0, n_neg = 0;
+    float v;
+    if (p < HW && inlier_mask[(size_t)blockIdx.y * HW + p] && plane_value(hb, p, rec[0], rec[1], rec[2], rec[3], v)) {
+        n = 1; n_big = v > rec[8] * MAX_DEPTH_MULT; n_over = v > MAX_DEPTH; n_neg = v < 0.f;
+    }
+    n = block_sum(n, redi); n_big = block_sum(n_big, redi); n_over = block_sum(n_over, redi); n_neg = block_sum(n_neg, redi);
+    if (threadIdx.x == 0) { q[0] = n; q[1] = n_big; q[2] = n_over; q[3] = n_neg; }
+}
+
+__global__ void __launch_bounds__(CH)
+plane_write_kernel(const float* __restrict__ homo, const Slot* __restrict__ slots, const uint8_t* __restrict__ inlier_mask, int HW,
+                   float* __restrict__ records, const int32_t* __restrict__ stats, float* __restrict__ plane_depth) {
+    __shared__ int tot[4];
+    const Slot s = slots[blockIdx.y];
+    float* rec = records + (size_t)blockIdx.y * VIDC_PLANE_RECORD;
+    if (rec[6] == 0.f || rec[9] == 0.f) return;
+    if (threadIdx.x < 4) {
+        int t = 0;
+        for (int c = 0; c < (int)gridDim.x; ++c) t += stats[((size_t)blockIdx.y * gridDim.x + c) * 4 + threadIdx.x];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const int n = tot[0], n_big = tot[1], n_over = tot[2], n_neg = tot[3];
+    bool valid = true;                                 // main.py:120-125 (true division)
+    if (n > 0) {
+        if ((float)n_big / (float)n > 0.05f || n_over > 0) valid = false;
+        if (n_neg > 0) valid = false;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { rec[10] = valid ? 1.f : 0.f; rec[11] = (float)n; }
+    if (!valid) return;
+    const float* hb = homo + (size_t)s.b * HW * 3;
+    const int p = blockIdx.x * CH + threadIdx.x;
+    float v;
+    if (p < HW && inlier_mask[(size_t)blockIdx.y * HW + p] && plane_value(hb, p, rec[0], rec[1], rec[2], rec[3], v))
+        plane_depth[(size_t)s.b * HW + p] = v;
+}
+
+// ---- stage 4: sparse depths override the plane depths; per-chunk counts of the enrichment candidates ---------------------
+// info layout (int32): [B][n_chunks] chunk counts of (plane_depth > 0), then [1] = number of slots flagged -1.
+__global__ void __launch_bounds__(CH)
+plane_finalize_kernel(const float* __restrict__ depth, float* __restrict__ plane_depth, int HW, const float* __restrict__ records,
+                      int n_slots, int32_t* __restrict__ info) {
+    __shared__ int redi[CH / 64];
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * CH + threadIdx.x;
+    int nz = 0;
+    if (p < HW) {
+        const float d = depth[(size_t)b * HW + p];
+        float v = plane_depth[(size_t)b * HW + p];
+        if (d > 0.f) { v = d; plane_depth[(size_t)b * HW + p] = d; }
+        nz = v > 0.f;
+    }
+    nz = block_sum(nz, redi);
+    if (threadIdx.x == 0) info[(size_t)b * gridDim.x + blockIdx.x] = nz;
+    if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+        int flagged = 0;
+        for (int s = 0; s < n_slots; ++s) flagged += records[(size_t)s * VIDC_PLANE_RECORD + 10] < 0.f;
+        info[(size_t)gridDim.y * gridDim.x] = flagged;
+    }
+}
+
+// ---- stage 5: copy the sub[]-th nonzeros (row-major order) of plane_depth into the enriched sparse depth -----------
+// chunk_base: [B][n_chunks] exclusive prefix of the chunk counts (computed by the host from `info`).
+__global__ void __launch_bounds__(CH)
+enrich_scatter_kernel(const float* __restrict__ plane_depth, const int32_t* __restrict__ sub, const int32_t* __restrict__ sub_off,
+                      const int32_t* __restrict__ chunk_base, int HW, float* __restrict__ enriched) {
+    __shared__ int wave_base[CH / 64];
+    const int b = blockIdx.y;
+    const int s0 = sub_off[b], n_sub = sub_off[b + 1] - s0;
+    if (n_sub <= 0) return;
+    const int p = blockIdx.x * CH + threadIdx.x;
+    const float v = p < HW ? plane_depth[(size_t)b * HW + p] : 0.f;
+    const bool nz = v > 0.f;
+    const unsigned long long m = __ballot(nz);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_base[wave] = __popcll(m);
+    __syncthreads();
+    int k = chunk_base[(size_t)b * gridDim.x + blockIdx.x];
+    for (int w = 0; w < wave; ++w) k += wave_base[w];
+    k += __popcll(m & ((1ull << lane) - 1ull));       // row-major rank of this pixel among the nonzeros of image b
+    if (!nz) return;
+    int lo = 0, hi = n_sub;                            // sub is sorted and unique: binary search for k
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sub[s0 + mid] < k) lo = mid + 1; else hi = mid; }
+    if (lo < n_sub && sub[s0 + lo] == k) enriched[(size_t)b * HW + p] = v;
 }
 
 }  // namespace
 
+extern "C" size_t vidc_plane_scratch_bytes(int n_slots, int B, int HW) {
+    const size_t nc = (size_t)vidc::cdiv(HW, CH);
+    // partial [slots][nc][4] f32 + apartial [slots][nc] f32 + stats [slots][nc][4] i32 + sparse list [B][VIDC_MAX_SPARSE] + n_sparse[B]
+    return (size_t)n_slots * nc * (4 + 1 + 4) * 4 + (size_t)B * (VIDC_MAX_SPARSE + 1) * 4 + 256;
+}
+
 extern "C" int vidc_plane_ransac_normal(const float* normals, const uint8_t* ids, const int32_t* slots, int n_slots,
-                                        const int32_t* hyp_pix, int HW, uint8_t* inlier_mask, int32_t* counts, float* records,
+                                        const int32_t* hyp_pix, int HW, uint8_t* inlier_mask, int32_t* counts, void* scratch,
                                         vidc_stream_t stream) {
-    VIDC_REQUIRE(normals && ids && slots && hyp_pix && inlier_mask && counts && records, VIDC_ERR_NULL,
+    VIDC_REQUIRE(normals && ids && slots && hyp_pix && inlier_mask && counts && scratch, VIDC_ERR_NULL,
                  "vidc_plane_ransac_normal: null pointer");
     VIDC_REQUIRE(n_slots > 0 && HW > 0, VIDC_ERR_SHAPE, "vidc_plane_ransac_normal: bad shape");
     hipStream_t st = vidc::as_stream(stream);
+    const int nc = vidc::cdiv(HW, CH);
+    float* partial = reinterpret_cast<float*>(scratch);
+    float* apartial = partial + (size_t)n_slots * nc * 4;
     VIDC_HIP(hipMemsetAsync(counts, 0, (size_t)n_slots * VIDC_MAX_HYP * sizeof(int32_t), st));
     const Slot* sl = reinterpret_cast<const Slot*>(slots);
-    hipLaunchKernelGGL(ransac_count_kernel, dim3(vidc::cdiv(HW, 256), n_slots), dim3(256), 0, st, normals, ids, sl, hyp_pix, HW, counts);
+    hipLaunchKernelGGL(ransac_count_kernel, dim3(nc, n_slots), dim3(320), 0, st, normals, ids, sl, hyp_pix, HW, counts);
     VIDC_CHECK_LAUNCH("ransac_count_kernel");
-    hipLaunchKernelGGL(ransac_select_kernel, dim3(n_slots), dim3(NT), 0, st, normals, ids, sl, hyp_pix, HW, counts, inlier_mask, records);
-    VIDC_CHECK_LAUNCH("ransac_select_kernel");
+    hipLaunchKernelGGL(ransac_mask_kernel, dim3(nc, n_slots), dim3(CH), 0, st, normals, ids, sl, hyp_pix, HW, counts, inlier_mask, partial);
+    VIDC_CHECK_LAUNCH("ransac_mask_kernel");
+    hipLaunchKernelGGL(ransac_angle_kernel, dim3(nc, n_slots), dim3(CH), 0, st, normals, sl, HW, inlier_mask, partial, apartial);
+    VIDC_CHECK_LAUNCH("ransac_angle_kernel");
     return VIDC_OK;
 }
 
-extern "C" int vidc_plane_offset(const float* homo, const float* depth, const int32_t* slots, int n_slots,
-                                 const uint8_t* inlier_mask, int HW, float* records, vidc_stream_t stream) {
-    VIDC_REQUIRE(homo && depth && slots && inlier_mask && records, VIDC_ERR_NULL, "vidc_plane_offset: null pointer");
-    VIDC_REQUIRE(n_slots > 0 && HW > 0, VIDC_ERR_SHAPE, "vidc_plane_offset: bad shape");
-    hipLaunchKernelGGL(plane_offset_kernel, dim3(n_slots), dim3(NT), 0, vidc::as_stream(stream), homo, depth,
-                       reinterpret_cast<const Slot*>(slots), inlier_mask, HW, records);
+extern "C" int vidc_plane_offset(const float* homo, const float* depth, const int32_t* slots, int n_slots, int B,
+                                 const uint8_t* inlier_mask, const int32_t* counts, int HW, void* scratch, float* records,
+                                 vidc_stream_t stream) {
+    VIDC_REQUIRE(homo && depth && slots && inlier_mask && counts && scratch && records, VIDC_ERR_NULL, "vidc_plane_offset: null pointer");
+    VIDC_REQUIRE(n_slots > 0 && HW > 0 && B > 0, VIDC_ERR_SHAPE, "vidc_plane_offset: bad shape");
+    hipStream_t st = vidc::as_stream(stream);
+    const int nc = vidc::cdiv(HW, CH);
+    float* partial = reinterpret_cast<float*>(scratch);
+    float* apartial = partial + (size_t)n_slots * nc * 4;
+    int32_t* sparse_idx = reinterpret_cast<int32_t*>(apartial + (size_t)n_slots * nc) + (size_t)n_slots * nc * 4;
+    int32_t* n_sparse = sparse_idx + (size_t)B * VIDC_MAX_SPARSE;
+    hipLaunchKernelGGL(sparse_list_kernel, dim3(B), dim3(1024), 0, st, depth, HW, VIDC_MAX_SPARSE, sparse_idx, n_sparse);
+    VIDC_CHECK_LAUNCH("sparse_list_kernel");
+    hipLaunchKernelGGL(plane_offset_kernel, dim3(n_slots), dim3(CH), 0, st, homo, depth, reinterpret_cast<const Slot*>(slots),
+                       inlier_mask, HW, nc, partial, apartial, sparse_idx, n_sparse, VIDC_MAX_SPARSE, counts, records);
     VIDC_CHECK_LAUNCH("plane_offset_kernel");
     return VIDC_OK;
 }
 
 extern "C" int vidc_plane_project_depth(const float* homo, const int32_t* slots, int n_slots, const uint8_t* inlier_mask, int HW,
-                                        float* records, float* plane_depth, vidc_stream_t stream) {
-    VIDC_REQUIRE(homo && slots && inlier_mask && records && plane_depth, VIDC_ERR_NULL, "vidc_plane_project_depth: null pointer");
+                                        void* scratch, float* records, float* plane_depth, vidc_stream_t stream) {
+    VIDC_REQUIRE(homo && slots && inlier_mask && scratch && records && plane_depth, VIDC_ERR_NULL, "vidc_plane_project_depth: null pointer");
     VIDC_REQUIRE(n_slots > 0 && HW > 0, VIDC_ERR_SHAPE, "vidc_plane_project_depth: bad shape");
-    hipLaunchKernelGGL(plane_project_kernel, dim3(n_slots), dim3(NT), 0, vidc::as_stream(stream), homo,
-                       reinterpret_cast<const Slot*>(slots), inlier_mask, HW, records, plane_depth);
-    VIDC_CHECK_LAUNCH("plane_project_kernel");
+    hipStream_t st = vidc::as_stream(stream);
+    const int nc = vidc::cdiv(HW, CH);
+    int32_t* stats = reinterpret_cast<int32_t*>(reinterpret_cast<float*>(scratch) + (size_t)n_slots * nc * 5);
+    const Slot* sl = reinterpret_cast<const Slot*>(slots);
+    hipLaunchKernelGGL(plane_stats_kernel, dim3(nc, n_slots), dim3(CH), 0, st, homo, sl, inlier_mask, HW, records, stats);
+    VIDC_CHECK_LAUNCH("plane_stats_kernel");
+    hipLaunchKernelGGL(plane_write_kernel, dim3(nc, n_slots), dim3(CH), 0, st, homo, sl, inlier_mask, HW, records, stats, plane_depth);
+    VIDC_CHECK_LAUNCH("plane_write_kernel");
     return VIDC_OK;
 }
 
-extern "C" int vidc_plane_finalize(const float* depth, float* plane_depth, int B, int HW, int32_t* nnz_out, vidc_stream_t stream) {
-    VIDC_REQUIRE(depth && plane_depth && nnz_out, VIDC_ERR_NULL, "vidc_plane_finalize: null pointer");
-    VIDC_REQUIRE(B > 0 && HW > 0, VIDC_ERR_SHAPE, "vidc_plane_finalize: bad shape");
-    hipStream_t st = vidc::as_stream(stream);
-    VIDC_HIP(hipMemsetAsync(nnz_out, 0, (size_t)B * sizeof(int32_t), st));
-    hipLaunchKernelGGL(plane_finalize_kernel, dim3(vidc::cdiv(HW, 256), B), dim3(256), 0, st, depth, plane_depth, HW, nnz_out);
+extern "C" int vidc_plane_info_count(int B, int HW) { return B * vidc::cdiv(HW, CH) + 1; }
+
+extern "C" int vidc_plane_finalize(const float* depth, float* plane_depth, int B, int HW, const float* records, int n_slots,
+                                   int32_t* info, vidc_stream_t stream) {
+    VIDC_REQUIRE(depth && plane_depth && info && (records || n_slots == 0), VIDC_ERR_NULL, "vidc_plane_finalize: null pointer");
+    VIDC_REQUIRE(B > 0 && HW > 0 && n_slots >= 0, VIDC_ERR_SHAPE, "vidc_plane_finalize: bad shape");
+    hipLaunchKernelGGL(plane_finalize_kernel, dim3(vidc::cdiv(HW, CH), B), dim3(CH), 0, vidc::as_stream(stream), depth, plane_depth, HW,
+                       records, n_slots, info);
     VIDC_CHECK_LAUNCH("plane_finalize_kernel");
     return VIDC_OK;
 }
 
-extern "C" int vidc_enrich_scatter(const float* plane_depth, const int32_t* sub, const int32_t* sub_offsets, int B, int HW,
-                                   float* enriched, vidc_stream_t stream) {
-    VIDC_REQUIRE(plane_depth && sub && sub_offsets && enriched, VIDC_ERR_NULL, "vidc_enrich_scatter: null pointer");
+extern "C" int vidc_enrich_scatter(const float* plane_depth, const int32_t* sub, const int32_t* sub_offsets, const int32_t* chunk_base,
+                                   int B, int HW, float* enriched, vidc_stream_t stream) {
+    VIDC_REQUIRE(plane_depth && sub && sub_offsets && chunk_base && enriched, VIDC_ERR_NULL, "vidc_enrich_scatter: null pointer");
     VIDC_REQUIRE(B > 0 && HW > 0, VIDC_ERR_SHAPE, "vidc_enrich_scatter: bad shape");
-    hipLaunchKernelGGL(enrich_scatter_kernel, dim3(B), dim3(NT), 0, vidc::as_stream(stream), plane_depth, sub, sub_offsets, HW, enriched);
+    hipLaunchKernelGGL(enrich_scatter_kernel, dim3(vidc::cdiv(HW, CH), B), dim3(CH), 0, vidc::as_stream(stream), plane_depth, sub,
+                       sub_offsets, chunk_base, HW, enriched);
     VIDC_CHECK_LAUNCH("enrich_scatter_kernel");
     return VIDC_OK;
 }

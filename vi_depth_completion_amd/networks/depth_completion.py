@@ -49,18 +49,22 @@ class ModifiedFPN(_HipModule):
         prog.finalize(dry_run)
         return prog
 
-    def program(self, B, H, W, device):
-        key = (B, H, W, str(device))
+    def program(self, B, H, W, device, slot=0):
+        key = (B, H, W, str(device), slot)
         if key not in self._programs:
             self._programs[key] = self.build_program(B, H, W, device)
         return self._programs[key]
 
-    def forward(self, image, normal, incomplete_depth):
+    def enqueue(self, image, normal, incomplete_depth, slot=0):
+        """Enqueues one forward pass on the current stream; returns a VIEW of the program's output buffer."""
         self._check(image, normal, incomplete_depth)
         B, _, H, W = image.shape
-        prog = self.program(B, H, W, image.device)
-        prog.tensor(prog.inputs["image"]).copy_(image)
-        prog.tensor(prog.inputs["normal"]).copy_(normal)
-        prog.tensor(prog.inputs["depth"]).copy_(incomplete_depth)
+        prog = self.program(B, H, W, image.device, slot)
+        prog.tensor(prog.inputs["image"]).copy_(image, non_blocking=True)
+        prog.tensor(prog.inputs["normal"]).copy_(normal, non_blocking=True)
+        prog.tensor(prog.inputs["depth"]).copy_(incomplete_depth, non_blocking=True)
         self._execute(prog)
-        return prog.tensor(prog.outputs["depth"]).clone()
+        return prog.tensor(prog.outputs["depth"])
+
+    def forward(self, image, normal, incomplete_depth):
+        return self.enqueue(image, normal, incomplete_depth).clone()

@@ -95,18 +95,25 @@ class SurfaceNormalPrediction(_HipModule):
         prog.storage[kinv.buf][:9].copy_(wp.kinv(device))
         return prog
 
-    def program(self, B, device):
-        key = (B, str(device), self.warp_2dof_alignment.align_corners)
+    def program(self, B, device, slot=0):
+        """Programs are cached per batch size and per `slot` (independent activation buffers sharing the weights), so
+        several frames can be in flight on different HIP streams."""
+        key = (B, str(device), self.warp_2dof_alignment.align_corners, slot)
         if key not in self._programs:
             self._programs[key] = self.build_program(B, device)
         return self._programs[key]
 
-    def forward(self, x, gravity_tensor, alignment_tensor):
+    def enqueue(self, x, gravity_tensor, alignment_tensor, slot=0):
+        """Enqueues one forward pass on the current stream; returns a VIEW of the program's output buffer (valid
+        until the next enqueue on the same slot)."""
         self._check(x, gravity_tensor, alignment_tensor)
         B = x.shape[0]
-        prog = self.program(B, x.device)
-        prog.tensor(prog.inputs["image"]).copy_(x)
-        prog.storage[prog.inputs["gravity"].buf][: B * 3].copy_(gravity_tensor.reshape(-1))
-        prog.storage[prog.inputs["aligned"].buf][: B * 3].copy_(alignment_tensor.reshape(-1))
+        prog = self.program(B, x.device, slot)
+        prog.tensor(prog.inputs["image"]).copy_(x, non_blocking=True)
+        prog.storage[prog.inputs["gravity"].buf][: B * 3].copy_(gravity_tensor.reshape(-1), non_blocking=True)
+        prog.storage[prog.inputs["aligned"].buf][: B * 3].copy_(alignment_tensor.reshape(-1), non_blocking=True)
         self._execute(prog)
-        return prog.tensor(prog.outputs["normals"]).clone()
+        return prog.tensor(prog.outputs["normals"])
+
+    def forward(self, x, gravity_tensor, alignment_tensor):
+        return self.enqueue(x, gravity_tensor, alignment_tensor).clone()

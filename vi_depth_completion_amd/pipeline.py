@@ -65,22 +65,88 @@ class DepthCompletionPipeline:
             m.load_state_dict(state)
 
     # ---- the hot path ------------------------------------------------------------------------------------------------
-    @torch.no_grad()
-    def _call_cnn(self, input_batch, taps=None):
+    def _stage1(self, input_batch, slot=0, planes=None, rng=None):
+        """warp + surface-normal net + plane block, enqueued on the current stream (main.py:262-283)."""
         dev = self.device
+        planes = planes or self.planes
         ds = input_batch["sparse_depth"].to(dev, non_blocking=True)
         rgb = input_batch["image"].to(dev, non_blocking=True)
-        normals = self.surface_normal_cnn(rgb, input_batch["gravity"].to(dev), input_batch["aligned_direction"].to(dev))
+        normals = self.surface_normal_cnn.enqueue(rgb, input_batch["gravity"].to(dev), input_batch["aligned_direction"].to(dev), slot)
+        rng = rng if rng is not None else self.rng
+        st = {"ds": ds, "rgb": rgb, "normals": normals, "di": None, "nnz": None, "rng": rng}
+        if self.args.enriched_samples != 0:
+            homo = input_batch["homogeneous_coordinates"].to(dev, non_blocking=True)
+            masks = [np.asarray(self.plane_masks_extraction.run_on_tensor(input_batch["image"][i])).reshape(ds.shape[-2], ds.shape[-1])
+                     for i in range(ds.shape[0])]
+            st["di"], st["nnz"] = planes.plane_depth(normals, masks, ds, homo, rng=rng)
+        return st
+
+    def _stage2(self, st, slot=0, planes=None):
+        """enrichment (one small device->host read of the candidate counts) + depth-completion net (main.py:285-297)."""
+        planes = planes or self.planes
+        depth_in = st["ds"]
+        if st["di"] is not None:
+            depth_in = planes.enrich(st["ds"], st["di"], st["nnz"], self.args.enriched_samples, rng=st["rng"])
+            st["enriched"] = depth_in
+        return self.cnn.enqueue(st["rgb"], st["normals"], depth_in, slot)
+
+    @torch.no_grad()
+    def _call_cnn(self, input_batch, taps=None):
+        st = self._stage1(input_batch)
+        out = self._stage2(st).clone()
         if taps is not None:
-            taps["normals"] = normals
-        if self.args.enriched_samples == 0:
-            return self.cnn(rgb, normals, ds)
-        homo = input_batch["homogeneous_coordinates"].to(dev, non_blocking=True)
-        masks = [np.asarray(self.plane_masks_extraction.run_on_tensor(input_batch["image"][i])).reshape(ds.shape[-2], ds.shape[-1])
-                 for i in range(ds.shape[0])]
-        di, nnz = self.planes.plane_depth(normals, masks, ds, homo, rng=self.rng)
-        enriched = self.planes.enrich(ds, di, nnz, self.args.enriched_samples, rng=self.rng)
-        self.planes.check_records()
-        if taps is not None:
-            taps.update(plane_depth=di, enriched=enriched, records=self.planes.last_records)
-        return self.cnn(rgb, normals, enriched)
+            taps["normals"] = st["normals"].clone()
+            if st["di"] is not None:
+                taps.update(plane_depth=st["di"], enriched=st["enriched"], records=self.planes.last_records)
+        return out
+
+    @torch.no_grad()
+    def run_stream(self, batches, in_flight=2, frame_rng=None):
+        """Throughput mode: yields the depth map of every batch, in order, with up to `in_flight` frames executing
+        concurrently on separate HIP streams (frame i's depth network overlaps frame i+1's surface-normal network --
+        at batch 1 the 134 small layer-3 convolutions per network cannot fill 256 CUs on their own).
+
+        Same kernels and arithmetic as `_call_cnn`.  The RANSAC / enrichment draws of different frames interleave
+        differently on the shared `self.rng` than in back-to-back `_call_cnn` calls (frame i+1's hypotheses are drawn
+        before frame i's enrichment indices); pass `frame_rng(i) -> np.random.RandomState` to give every frame its own
+        generator, in which case the outputs are identical to sequential calls using the same per-frame generators."""
+        import collections
+        if not hasattr(self, "_slots") or len(self._slots) != in_flight:
+            self._slots = [{"stream": torch.cuda.Stream(device=self.device), "planes": PlaneBlock(), "state": None, "out": None,
+                            "done": torch.cuda.Event()} for _ in range(in_flight)]
+        main = torch.cuda.current_stream(self.device)
+        order = collections.deque()
+
+        def finish_stage2(sl, k):
+            with torch.cuda.stream(sl["stream"]):
+                sl["out"] = self._stage2(sl["state"], slot=k, planes=sl["planes"]).clone()
+                sl["done"].record(sl["stream"])
+            sl["state"] = None
+
+        for i, batch in enumerate(batches):
+            k = i % in_flight
+            sl = self._slots[k]
+            if sl["state"] is not None:
+                finish_stage2(sl, k)             # host waits here for frame i-in_flight's counts; the other slots keep the GPU busy
+            if sl["out"] is not None and len(order) >= in_flight:
+                j = order.popleft()
+                sj = self._slots[j]
+                sj["done"].synchronize()
+                out, sj["out"] = sj["out"], None
+                yield out
+            sl["stream"].wait_stream(main)
+            with torch.cuda.stream(sl["stream"]):
+                sl["state"] = self._stage1(batch, slot=k, planes=sl["planes"], rng=frame_rng(i) if frame_rng else None)
+            order.append(k)
+        # drain: RNG order must stay frame order, so finish the pending second stages oldest first
+        pending = list(order)
+        for j in pending:
+            if self._slots[j]["state"] is not None:
+                finish_stage2(self._slots[j], j)
+        while order:
+            j = order.popleft()
+            sj = self._slots[j]
+            sj["done"].synchronize()
+            out, sj["out"] = sj["out"], None
+            main.wait_stream(sj["stream"])
+            yield out

@@ -71,7 +71,8 @@ class PlaneBlock:
 
     def plane_depth(self, normals, id_maps, sparse_depth, homo, rng=np.random):
         """normals (B,3,H,W), sparse_depth (B,1,H,W), homo (B,H,W,3): GPU fp32.  id_maps: B numpy (H,W) integer maps.
-        Returns (di (B,1,H,W), nnz (B,) int32 device tensor = #(di > 0))."""
+        Returns (di (B,1,H,W), info): `info` is the device int32 buffer vidc_plane_finalize fills (per-chunk candidate
+        counts + the error flag); `enrich()` reads it back -- the single device->host sync of the path."""
         if not normals.is_cuda:
             raise RuntimeError("PlaneBlock runs on the GPU only (no CPU fallback)")
         lib, st = L.lib(), L.current_stream()
@@ -83,41 +84,49 @@ class PlaneBlock:
         slots, hyp = draw_normal_hypotheses(id_maps, rng)
         di = ds.clone()
         n_slots = slots.shape[0]
+        rec = None
         if n_slots > 0:
             ids = self._upload_ids(id_maps, dev)
-            slots_d = torch.from_numpy(slots).to(dev)
-            hyp_d = torch.from_numpy(hyp).to(dev)
+            host = np.concatenate([slots.reshape(-1), hyp]).astype(np.int32)          # one upload: slots then hypotheses
+            host_d = torch.from_numpy(host).to(dev, non_blocking=True)
+            slots_p, hyp_p = host_d.data_ptr(), host_d.data_ptr() + 4 * slots.size
             mask = torch.empty((n_slots, HW), dtype=torch.uint8, device=dev)
             counts = torch.empty((n_slots, L.MAX_HYP), dtype=torch.int32, device=dev)
             rec = torch.empty((n_slots, L.PLANE_RECORD), dtype=torch.float32, device=dev)
-            L.check(lib.vidc_plane_ransac_normal(L.ptr(normals), L.ptr(ids), L.ptr(slots_d), n_slots, L.ptr(hyp_d), HW, L.ptr(mask),
-                                                 L.ptr(counts), L.ptr(rec), st), "plane_ransac_normal")
-            L.check(lib.vidc_plane_offset(L.ptr(homo), L.ptr(ds), L.ptr(slots_d), n_slots, L.ptr(mask), HW, L.ptr(rec), st), "plane_offset")
-            L.check(lib.vidc_plane_project_depth(L.ptr(homo), L.ptr(slots_d), n_slots, L.ptr(mask), HW, L.ptr(rec), L.ptr(di), st),
+            scratch = torch.empty(lib.vidc_plane_scratch_bytes(n_slots, B, HW), dtype=torch.uint8, device=dev)
+            L.check(lib.vidc_plane_ransac_normal(L.ptr(normals), L.ptr(ids), slots_p, n_slots, hyp_p, HW, L.ptr(mask), L.ptr(counts),
+                                                 L.ptr(scratch), st), "plane_ransac_normal")
+            L.check(lib.vidc_plane_offset(L.ptr(homo), L.ptr(ds), slots_p, n_slots, B, L.ptr(mask), L.ptr(counts), HW, L.ptr(scratch),
+                                          L.ptr(rec), st), "plane_offset")
+            L.check(lib.vidc_plane_project_depth(L.ptr(homo), slots_p, n_slots, L.ptr(mask), HW, L.ptr(scratch), L.ptr(rec), L.ptr(di), st),
                     "plane_project_depth")
-            self.last_records, self.last_slots, self.last_mask = rec, slots, mask
-        else:
-            self.last_records, self.last_slots, self.last_mask = None, slots, None
-        nnz = torch.empty(B, dtype=torch.int32, device=dev)
-        L.check(lib.vidc_plane_finalize(L.ptr(ds), L.ptr(di), B, HW, L.ptr(nnz), st), "plane_finalize")
-        return di.view(B, 1, H, W), nnz
+            self._keep = (host_d, scratch, counts)
+        self.last_records, self.last_slots, self.last_mask = rec, slots, (mask if n_slots > 0 else None)
+        info = torch.empty(lib.vidc_plane_info_count(B, HW), dtype=torch.int32, device=dev)
+        L.check(lib.vidc_plane_finalize(L.ptr(ds), L.ptr(di), B, HW, L.ptr(rec), n_slots, L.ptr(info), st), "plane_finalize")
+        return di.view(B, 1, H, W), info
 
-    def check_records(self):
-        """Raises if a plane had more than 300 sparse points (would need the host permutation of main.py:78)."""
-        if self.last_records is not None and bool((self.last_records[:, 10] < 0).any()):
-            raise NotImplementedError("a plane has more than %d sparse depth points; the subsampled plane-offset RANSAC "
-                                      "(main.py:78) is not implemented on device" % L.MAX_HYP)
-
-    def enrich(self, sparse_depth, di, nnz, goal, rng=np.random):
-        """main.py:285-294.  One device->host read of the B counts (the reference syncs on torch.nonzero here)."""
+    def enrich(self, sparse_depth, di, info, goal, rng=np.random):
+        """main.py:285-294.  One device->host read (the reference syncs on torch.nonzero here): per-chunk candidate counts
+        + the flag for planes that would need the >300-point host permutation (main.py:78), which is not done on device."""
         lib, st = L.lib(), L.current_stream()
         B, _, H, W = sparse_depth.shape
         dev = sparse_depth.device
-        nnz_h = nnz.cpu().numpy()
+        info_h = info.cpu().numpy()
+        if info_h[-1] != 0:
+            raise NotImplementedError("a plane has more than %d sparse depth points; the subsampled plane-offset RANSAC "
+                                      "(main.py:78) is not implemented on device" % L.MAX_HYP)
+        chunks = info_h[:-1].reshape(B, -1)
+        nnz_h = chunks.sum(axis=1)
         sub, offs = draw_enrichment(nnz_h, goal, rng)
         out = sparse_depth.clone()
         self.last_sub, self.last_nnz = (sub, offs), nnz_h
         if len(sub):
-            sub_d, offs_d = torch.from_numpy(sub).to(dev), torch.from_numpy(offs).to(dev)
-            L.check(lib.vidc_enrich_scatter(L.ptr(di), L.ptr(sub_d), L.ptr(offs_d), B, H * W, L.ptr(out), st), "enrich_scatter")
+            base = (np.cumsum(chunks, axis=1) - chunks).astype(np.int32)
+            host = np.concatenate([sub, offs, base.reshape(-1)]).astype(np.int32)      # one upload
+            host_d = torch.from_numpy(host).to(dev, non_blocking=True)
+            p0 = host_d.data_ptr()
+            L.check(lib.vidc_enrich_scatter(L.ptr(di), p0, p0 + 4 * len(sub), p0 + 4 * (len(sub) + len(offs)), B, H * W, L.ptr(out), st),
+                    "enrich_scatter")
+            self._keep2 = host_d
         return out
