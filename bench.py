@@ -22,7 +22,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from vi_depth_completion_amd import synthetic as S   # noqa: E402
+from vi_depth_completion_amd import sharding, synthetic as S   # noqa: E402
 
 FLOPS_PER_FRAME = {(240, 320): 293.88e9, (256, 320): 311.63e9}   # SURVEY.md §8d, reference formulation, 2 FLOP/MAC
 PEAK_F32_MFMA_TFLOPS = 157.3                                       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
@@ -160,16 +160,10 @@ def main():
                     for n, t in ops:
                         f.write("%s\t%.2f\t%s\n" % (name, t * 1e3, n))
 
-    if world > 1:
-        gathered = [torch.zeros_like(rec) for _ in range(world)]
-        dist.all_gather(gathered, rec)                        # the only collective: 4 doubles per rank over RCCL/xGMI
-        allrec = torch.stack(gathered).cpu()
-    else:
-        allrec = rec.cpu()[None]
+    allrec = sharding.gather_records(rec)                 # the only collective: 4 doubles per rank over RCCL/xGMI
     if rank == 0:
-        frames = float(allrec[:, 0].sum())
-        t_max = float(allrec[:, 1].max())
-        se, npx = float(allrec[:, 2].sum()), float(allrec[:, 3].sum())
+        job = sharding.combine(allrec)
+        frames, t_max = job["frames"], job["seconds"]
         line = {
             "metric": "frames/sec", "value": round(frames / t_max, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True,
@@ -179,7 +173,7 @@ def main():
                        "height": H, "width": W, "batch_per_gpu": B, "weights": "seeded random-init (seed 1234)",
                        "frames_in_flight": args.in_flight,
                        "sharding": "frames round-robin over %d rank(s), no data-path collective" % world},
-            "rmse_vs_oracle": (round(float(np.sqrt(se / npx)), 8) if npx else None),
+            "rmse_vs_oracle": (round(job["rmse"], 8) if job["rmse"] is not None else None),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         line.update(extra)

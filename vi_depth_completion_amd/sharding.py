@@ -1,0 +1,36 @@
+"""Frame sharding across GPUs: one process per GPU, frames round-robin over ranks, a full weight
+replica per rank, NO data-path collective.  The only communication is one all_gather of 4 doubles per rank at the end
+of a run (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).  This replaces the reference's
+`torch.nn.DataParallel` (network_run.py:97-99), which re-broadcasts 1.24 GB of parameters on every forward and wraps
+only the depth network."""
+import math
+
+import torch
+
+
+def frames_of_rank(rank, world, n_frames_total):
+    """Round-robin shard: rank r processes frames r, r+world, ...  (every frame exactly once)."""
+    return list(range(rank, n_frames_total, world))
+
+
+def metric_record(n_frames, seconds, sum_sq_err=0.0, n_px=0.0, device="cpu"):
+    return torch.tensor([float(n_frames), float(seconds), float(sum_sq_err), float(n_px)], dtype=torch.float64, device=device)
+
+
+def gather_records(rec):
+    """all_gather of the 4-double record of every rank -> (world, 4) CPU tensor.  Single-process: (1, 4)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rec.detach().cpu()[None]
+    out = [torch.zeros_like(rec) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, rec)
+    return torch.stack(out).cpu()
+
+
+def combine(records):
+    """Whole-job metrics: frames/s = total frames / slowest rank's time; RMSE over all compared pixels."""
+    frames = float(records[:, 0].sum())
+    t_max = float(records[:, 1].max())
+    se, npx = float(records[:, 2].sum()), float(records[:, 3].sum())
+    return {"frames": frames, "seconds": t_max, "frames_per_s": frames / t_max if t_max > 0 else 0.0,
+            "rmse": math.sqrt(se / npx) if npx > 0 else None}
