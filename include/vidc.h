@@ -100,12 +100,27 @@ typedef struct vidc_conv_desc {
     int64_t x_gs, w_gs, y_gs, r_gs, p_gs;   /* per-group element strides (p_gs: scale/shift) */
     int32_t tile;          /* vidc_conv_tile, or VIDC_TILE_AUTO                       */
     int32_t splitk;        /* >= 1                                                    */
+    int32_t precision;     /* vidc_conv_precision: with VIDC_PREC_BF16X3, x and w are the
+                              hi|lo bf16 images made by vidc_split_bf16x3 /
+                              vidc_pack_conv_weight_bf16x3 (same strides as fp32)     */
+    int32_t reserved0;
 } vidc_conv_desc;
 
 /* Workgroup tilings (BM x BN output tile; _Kn = n k-slices reduced inside the workgroup through LDS). */
 enum vidc_conv_tile { VIDC_TILE_AUTO = 0, VIDC_TILE_128x128 = 1, VIDC_TILE_128x64 = 2, VIDC_TILE_64x128 = 3,
                       VIDC_TILE_64x64 = 4, VIDC_TILE_64x64_K2 = 5, VIDC_TILE_32x64_K2 = 6, VIDC_TILE_32x32_K4 = 7,
                       VIDC_TILE_32x128 = 8, VIDC_TILE_32x32_K8 = 9, VIDC_TILE_COUNT = 10 };
+
+/* Arithmetic of the contraction.  FP32: v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32, the reference mode).
+ * BF16X3: every operand is split as x = hi + lo (bf16 each, round-to-nearest-even) and each product is computed as
+ * lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-16 relative per product; whole-path
+ * depth RMSE 1.4e-5 against fp32, bar 1e-3).  A 32-channel unit of a split tensor is [32 x bf16 hi | 32 x bf16 lo],
+ * i.e. the same 128 bytes as 32 floats, so all strides/offsets of the fp32 layout carry over unchanged. */
+enum vidc_conv_precision { VIDC_PREC_FP32 = 0, VIDC_PREC_BF16X3 = 1 };
+/* fp32 NHWC rows [rows][ldx] (first C channels) -> split image [rows][C/32][hi|lo]; C % 32 == 0. */
+int vidc_split_bf16x3(const float* x, void* y, long long rows, int C, int ldx, vidc_stream_t stream);
+/* OIHW fp32 -> split packed weights [Cout][KH*KW*Cin/32][hi|lo] (one group per call). */
+int vidc_pack_conv_weight_bf16x3(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW, vidc_stream_t stream);
 
 int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream);
 size_t vidc_conv2d_workspace_bytes(const vidc_conv_desc* d);
@@ -195,7 +210,7 @@ int vidc_enrich_scatter(const float* plane_depth, const int32_t* sub, const int3
  * ---------------------------------------------------------------------------------------------- */
 
 enum vidc_op_kind { VIDC_OP_CONV = 1, VIDC_OP_STEM = 2, VIDC_OP_MAXPOOL = 3, VIDC_OP_UPSAMPLE = 4, VIDC_OP_HEAD = 5,
-                    VIDC_OP_WARP_PARAMS = 6, VIDC_OP_WARP_FWD = 7, VIDC_OP_WARP_INV = 8, VIDC_OP_COPY = 9 };
+                    VIDC_OP_WARP_PARAMS = 6, VIDC_OP_WARP_FWD = 7, VIDC_OP_WARP_INV = 8, VIDC_OP_COPY = 9, VIDC_OP_SPLIT = 10 };
 
 typedef struct vidc_generic_args {   /* arguments of the non-conv launchers, in declaration order */
     const void* p[6];

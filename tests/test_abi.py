@@ -31,8 +31,8 @@ def test_header_symbols_exported(lib):
 
 
 def test_struct_layout_matches_header():
-    # vidc_conv_desc: 9 pointers, 16 int32, 5 int64, 2 int32  (natural alignment)
-    assert C.sizeof(L.ConvDesc) == 9 * 8 + 16 * 4 + 5 * 8 + 2 * 4
+    # vidc_conv_desc: 9 pointers, 16 int32, 5 int64, 4 int32  (natural alignment)
+    assert C.sizeof(L.ConvDesc) == 9 * 8 + 16 * 4 + 5 * 8 + 4 * 4
     assert C.sizeof(L.GenericArgs) == 6 * 8 + 16 * 4 + 8 * 4
     assert C.sizeof(L.Op) == 16 + max(C.sizeof(L.ConvDesc), C.sizeof(L.GenericArgs))
 
@@ -91,6 +91,7 @@ def test_rng_draws_follow_reference_order():
 def recorded_programs(lib):
     """Both networks recorded on CPU in dry-run mode (no HIP calls): exercises all host-side program logic."""
     import torch
+    os.environ["VIDC_PRECISION"] = "mixed"
     from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
     from vi_depth_completion_amd.networks.surface_normal import SurfaceNormalPrediction
     sn = SurfaceNormalPrediction(fc_img=np.array([202.0, 202.0])).eval()
@@ -113,6 +114,29 @@ def test_program_recording_matches_reference_op_counts(recorded_programs):
     dc_flops = dc.flops + 2 * stem(3) + stem(1) + head(192, 1, 60, 80)
     assert abs(sn_flops / 1e9 - 46.29) < 0.01, sn_flops
     assert abs(dc_flops / 1e9 - 247.58) < 0.01, dc_flops
+
+
+def test_mixed_precision_program_structure(recorded_programs):
+    """bf16x3 convs read a split image that is produced by exactly one preceding split op of the right tensor, and no
+    fp32-mode conv reads a split image."""
+    for prog in recorded_programs:
+        split_out = {}
+        n_bf = 0
+        for kind, reads, writes, kw in prog.ops:
+            if kind == "split":
+                split_out[writes[0]] = kw["x"].buf
+            elif kind == "conv":
+                if kw["precision"] == L.PREC_BF16X3:
+                    n_bf += 1
+                    assert kw["x"].buf in split_out, "bf16x3 conv without a split input"
+                    assert kw["geom"][1] % 32 == 0
+                else:
+                    assert kw["x"].buf not in split_out
+        assert n_bf >= 3 and len(split_out) <= n_bf
+    # the 54-GFLOP-class layer (dc.feature1_upsamping.0) must be on the fast path
+    dc = recorded_programs[1]
+    big = [kw for kind, _, _, kw in dc.ops if kind == "conv" and kw["keys"][0] == "feature1_upsamping.0"][0]
+    assert big["precision"] == L.PREC_BF16X3
 
 
 def test_program_buffer_reuse_is_safe(recorded_programs):

@@ -175,6 +175,46 @@ def test_conv_splitk_and_epilogue(splitk):
     assert err < 3e-4, err
 
 
+def _split_bf16(t):
+    hi = t.to(torch.bfloat16).float()
+    return hi, (t - hi).to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("shape", [CONV_SHAPES[1], CONV_SHAPES[2], CONV_SHAPES[4], CONV_SHAPES[5], CONV_SHAPES[7], CONV_SHAPES[8]])
+@pytest.mark.parametrize("tile", [0, 1, 4, 5, 7, 9])
+def test_conv_bf16x3(shape, tile):
+    """Split-bf16 3-pass mode vs an exact CPU emulation of the same arithmetic (hi*hi + hi*lo + lo*hi in fp32:
+    bf16 x bf16 products are exact in fp32, so only the summation order differs) and vs true fp32 (2^-16 class)."""
+    from vi_depth_completion_amd import ops
+    B, H, W, cin, cout, k, stride, groups = shape
+    x, w, s1, b1 = _conv_case(13, B, H, W, cin, cout, k, stride, groups)
+    pad = k // 2
+    outs, exact = [], []
+    for g in range(groups):
+        xg = x[:, g * cin:(g + 1) * cin]
+        xh, xl = _split_bf16(xg)
+        wh, wl = _split_bf16(w[g])
+        y = F.conv2d(xh, wh, None, stride, pad) + F.conv2d(xh, wl, None, stride, pad) + F.conv2d(xl, wh, None, stride, pad)
+        outs.append(F.relu(y * s1[g].view(1, -1, 1, 1) + b1[g].view(1, -1, 1, 1)))
+        exact.append(F.relu(F.conv2d(xg, w[g], None, stride, pad) * s1[g].view(1, -1, 1, 1) + b1[g].view(1, -1, 1, 1)))
+    emu, ref = torch.cat(outs, 1), torch.cat(exact, 1)
+    wp = torch.stack([ops.pack_conv_weight_bf16x3(wg.to(DEV)) for wg in w])
+    y = ops.conv2d_bn_act(nhwc(x).to(DEV), wp, s1.to(DEV), b1.to(DEV), k, k, stride, pad, relu1=True, tile=tile, groups=groups, precision=1)
+    got = nchw(y).cpu()
+    assert (got - emu).abs().max().item() < 2e-4
+    assert (got - ref).abs().max().item() < 5e-4          # |x|~1, |w|~sqrt(2/K): 2^-16 * sum|x w| stays far below this
+
+
+def test_split_bf16x3_layout():
+    from vi_depth_completion_amd import ops
+    x = S.normal01(21, "split.x", (2, 5, 7, 64)).float()
+    img = ops.split_bf16x3(x.to(DEV)).cpu()
+    u = img.view(torch.int16).view(2, 5, 7, 2, 2, 32)            # [.., unit, hi|lo, 32]
+    hi, lo = _split_bf16(x.view(2, 5, 7, 2, 32))
+    assert torch.equal(u[..., 0, :], hi.to(torch.bfloat16).view(torch.int16))
+    assert torch.equal(u[..., 1, :], lo.to(torch.bfloat16).view(torch.int16))
+
+
 def test_conv_is_deterministic():
     from vi_depth_completion_amd import ops
     x, w, s1, b1 = _conv_case(3, 1, 30, 40, 128, 128, 3, 1)

@@ -27,18 +27,51 @@ OUT = os.path.join(ROOT, "vi_depth_completion_amd", "conv_tuning.json")
 TILE_DIMS = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (64, 64), 6: (32, 64), 7: (32, 32), 8: (32, 128), 9: (32, 32)}
 
 
-def time_desc(lib, d, st, iters=10):
-    best = 1e30
-    for _ in range(2):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            if lib.vidc_conv2d_bn_act(C.byref(d), st) != 0:
-                return None
-        e1.record()
-        torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+def time_desc(lib, d, st, copies=20):
+    """GPU-bound timing: a captured hipGraph of `copies` back-to-back launches of the op (launching from Python is
+    host-bound at ~7 us per call and cannot rank configurations of the small layers)."""
+    if lib.vidc_conv2d_bn_act(C.byref(d), st) != 0:       # also sets the kernel's LDS attribute outside capture
+        return None
+    ops = (L.Op * copies)()
+    for o in ops:
+        o.kind = L.OP_CONV
+        C.memmove(C.byref(o.u.conv), C.byref(d), C.sizeof(L.ConvDesc))
+    h = C.c_void_p()
+    if lib.vidc_program_create(ops, copies, C.byref(h)) != 0:
+        return None
+    best = None
+    try:
+        if lib.vidc_program_capture(h, st) == 0:
+            ms = (C.c_float * 1)()
+            for _ in range(2):
+                if lib.vidc_program_time(h, st, 3, 1, ms, None) != 0:
+                    return None
+                us = ms[0] * 1e3 / copies
+                best = us if best is None else min(best, us)
+    finally:
+        lib.vidc_program_destroy(h)
     return best
+
+
+def time_split(lib, x_ptr, y_ptr, rows, Cc, ldx, st, copies=20):
+    """GPU-bound time of the split kernel that a bf16x3 conv needs in front of it."""
+    ops = (L.Op * copies)()
+    for o in ops:
+        o.kind = L.OP_SPLIT
+        o.u.g.p[0], o.u.g.p[1] = x_ptr, y_ptr
+        o.u.g.i[0], o.u.g.i[1], o.u.g.i[2], o.u.g.i[3] = rows & 0xFFFFFFFF, rows >> 32, Cc, ldx
+    h = C.c_void_p()
+    if lib.vidc_program_create(ops, copies, C.byref(h)) != 0:
+        return 0.0
+    try:
+        lib.vidc_program_run(h, st)
+        if lib.vidc_program_capture(h, st) != 0:
+            return 0.0
+        ms = (C.c_float * 1)()
+        lib.vidc_program_time(h, st, 3, 1, ms, None)
+        return ms[0] * 1e3 / copies
+    finally:
+        lib.vidc_program_destroy(h)
 
 
 def main():
@@ -50,8 +83,11 @@ def main():
     dev = torch.device("cuda")
     lib = L.lib()
     engine._TUNING = {}                      # measure against the cost-model plan, not an older table
+    os.environ["VIDC_PRECISION"] = "fp32"      # record the programs with fp32 inputs (no split ops); both modes are timed below
     table, report = {}, []
-    st = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)                 # graph capture needs a non-default stream
+    st = side.cuda_stream
     ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)     # 256 MB split-K scratch
     for H in [int(v) for v in a.heights.split(",")]:
         for B in [int(v) for v in a.batches.split(",")]:
@@ -68,29 +104,34 @@ def main():
                     d = L.ConvDesc.from_buffer_copy(op.u.conv)
                     d.workspace = ws.data_ptr()
                     d.flags &= ~L.ACCUM                     # timing launches must not accumulate into live data forever
-                    base = (d.tile, d.splitk)
                     M = d.B * d.Ho * d.Wo
-                    cands = []
-                    for t, (bm, bn) in TILE_DIMS.items():
-                        if bn > max(64, d.Cout) or bm >= 4 * max(32, M):
-                            continue
-                        for sk in [int(v) for v in a.splitk.split(",")]:
-                            if sk > 1 and (d.KH * d.KW * d.Cin // 32) // sk < 2:
+                    best = {}
+                    for prec in (0, 1):
+                        d.precision = prec
+                        cands = []
+                        for t, (bm, bn) in TILE_DIMS.items():
+                            if bn > max(64, d.Cout) or bm >= 4 * max(32, M):
                                 continue
-                            if sk * d.groups * M * d.Cout > ws.numel():
-                                continue
-                            d.tile, d.splitk = t, sk
-                            us = time_desc(lib, d, st)
-                            if us is not None:
-                                cands.append((us, t, sk))
-                    cands.sort()
-                    d.tile, d.splitk = base
-                    base_us = time_desc(lib, d, st)
-                    us, t, sk = cands[0]
-                    table[sig] = [t, sk]
-                    report.append((sig, base, base_us, (t, sk), us))
-                    print("%-40s plan %-8s sk%-2d %8.1f us   best %-8s sk%-2d %8.1f us" % (
-                        sig, L.TILE_NAMES[base[0]], base[1], base_us, L.TILE_NAMES[t], sk, us), flush=True)
+                            for sk in [int(v) for v in a.splitk.split(",")]:
+                                if sk > 1 and (d.KH * d.KW * d.Cin // 32) // sk < 2:
+                                    continue
+                                if sk * d.groups * M * d.Cout > ws.numel():
+                                    continue
+                                d.tile, d.splitk = t, sk
+                                us = time_desc(lib, d, st)
+                                if us is not None:
+                                    cands.append((us, t, sk))
+                        cands.sort()
+                        best[prec] = cands[0]
+                    # a bf16x3 conv needs its input split first (shared between consumers at best; charged in full here)
+                    rows = d.B * d.H * d.W
+                    t_split = time_split(lib, d.x, ws.data_ptr(), rows, d.Cin * d.groups, d.ldx, st)
+                    us32, t32, sk32 = best[0]
+                    us16, t16, sk16 = best[1]
+                    prec = 1 if us16 + t_split < 0.92 * us32 else 0
+                    table[sig] = [t16, sk16, 1, t32, sk32] if prec else [t32, sk32, 0, t32, sk32]
+                    print("%-40s fp32 %-8s sk%-2d %8.1f us | bf16x3 %-8s sk%-2d %8.1f us + split %5.1f us -> %s" % (
+                        sig, L.TILE_NAMES[t32], sk32, us32, L.TILE_NAMES[t16], sk16, us16, t_split, "bf16x3" if prec else "fp32"), flush=True)
             del sn, dc
             torch.cuda.empty_cache()
     with open(OUT, "w") as f:

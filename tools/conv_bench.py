@@ -35,7 +35,7 @@ KEY_SHAPES = [
 ]
 
 
-def run(shape, tile, splitk, iters=20, check=False):
+def run(shape, tile, splitk, iters=20, check=False, precision=0):
     (H, W), cin, cout, k, stride, G, _ = shape
     dev = "cuda"
     x = S.normal01(1, "cb.x", (1, H, W, G * cin)).float().to(dev)
@@ -50,7 +50,7 @@ def run(shape, tile, splitk, iters=20, check=False):
     d.B, d.H, d.W, d.Cin, d.ldx, d.Ho, d.Wo, d.Cout, d.ldy = 1, H, W, cin, G * cin, Ho, Wo, cout, G * cout
     d.KH, d.KW, d.stride, d.pad, d.flags, d.groups = k, k, stride, pad, L.RELU1, G
     d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, cout * k * k * cin, cout, cout
-    d.tile, d.splitk = tile, splitk
+    d.tile, d.splitk, d.precision = tile, splitk, precision
     lib = L.lib()
     if tile == 0:
         L.check(lib.vidc_conv2d_plan(C.byref(d)), "plan")
@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--splitk", default="1")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--precision", type=int, default=0, help="0 fp32, 1 bf16x3 (timing only: operands are not re-split)")
     ap.add_argument("--shapes", default="key")
     ap.add_argument("--only", type=int, default=-1, help="index into KEY_SHAPES")
     ap.add_argument("--iters", type=int, default=20)
@@ -101,7 +102,7 @@ def main():
         best = None
         for t in tiles:
             for sk in sks:
-                us, tt, ss, err = run(sh, t, sk, iters=a.iters, check=a.check)
+                us, tt, ss, err = run(sh, t, sk, iters=a.iters, check=a.check, precision=a.precision)
                 if us is None:
                     print("  M%-6d N%-5d K%-6d G%d  tile %-8s sk%-2d  FAILED %s" % (H * W, cout, cin * k * k, G, L.TILE_NAMES.get(tt, tt), ss, err))
                     continue

@@ -19,11 +19,12 @@ MAX_STREAMS = 4
 # vidc_conv_flags / vidc_up_flags / vidc_op_kind / vidc_conv_tile
 RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM = 1, 2, 4, 8, 16, 32
 UP_RELU, UP_ACCUM = 1, 2
-OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY = range(1, 10)
+OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY, OP_SPLIT = range(1, 11)
 TILE_AUTO = 0
 TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "64x64k2", 6: "32x64k2", 7: "32x32k4", 8: "32x128",
               9: "32x32k8"}
 TILE_COUNT = 10
+PREC_FP32, PREC_BF16X3 = 0, 1
 
 _f32p = C.POINTER(C.c_float)
 
@@ -38,7 +39,7 @@ class ConvDesc(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("flags", C.c_int32), ("groups", C.c_int32),
         ("x_gs", C.c_int64), ("w_gs", C.c_int64), ("y_gs", C.c_int64), ("r_gs", C.c_int64), ("p_gs", C.c_int64),
-        ("tile", C.c_int32), ("splitk", C.c_int32),
+        ("tile", C.c_int32), ("splitk", C.c_int32), ("precision", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -65,6 +66,8 @@ SIGNATURES = {
     "vidc_warp2dof_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "vidc_warp2dof_inv_rot_norm": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp]),
     "vidc_pack_conv_weight": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vidc_split_bf16x3": (C.c_int, [_vp, _vp, C.c_longlong, _i, _i, _vp]),
+    "vidc_pack_conv_weight_bf16x3": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vidc_conv2d_bn_act": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "vidc_conv2d_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "vidc_conv2d_plan": (C.c_int, [C.POINTER(ConvDesc)]),

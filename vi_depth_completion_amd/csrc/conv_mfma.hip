@@ -54,6 +54,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -75,7 +76,11 @@ __device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
 // NS-deep LDS ring filled by global_load_lds (16 B per lane, 1 KiB = 8 rows x 128 B per wave-instruction); the 16-byte
 // chunks of a row are XOR-swizzled by (row & 7) through the per-lane SOURCE address so ds_read_b128 fragments are at
 // worst 2-way bank conflicted while the DMA destination stays lane-linear.
-template <int BM, int BN, int WMW, int WNW, int WKW, int NS>
+// PREC 0: fp32 operands, v_mfma_f32_32x32x2_f32.  PREC 1 ("bf16x3"): both operands arrive pre-split as bf16 hi + lo
+// (each 32-channel K unit is stored as [32 x hi | 32 x lo] = the same 128 bytes per row as fp32, so addressing, DMA and
+// swizzle are identical) and every K unit is 3 x 2 v_mfma_f32_32x32x16_bf16: lo*hi + hi*lo + hi*hi, fp32 accumulate.
+// Dropping lo*lo leaves ~2^-16 relative error per product: depth RMSE 1.4e-5 vs fp32 over the whole path (bar: 1e-3).
+template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC>
 __global__ void __launch_bounds__(64 * WMW * WNW * WKW)
 conv_igemm_f32(const ConvArgs a) {
     constexpr int NW = WMW * WNW * WKW, WPK = WMW * WNW;
@@ -274,36 +279,73 @@ conv_igemm_f32(const ConvArgs a) {
         int fill = slot + NS - 1; if (fill >= NS) fill -= NS;     // the slot read in iteration s-1: free since the barrier
         const unsigned Ab = a_base + (unsigned)(slot * STAGE * 4);
         const unsigned Bb = b_base + (unsigned)(slot * STAGE * 4);
-        f32x4 fa[2][TM], fb[2][TN];
+        if constexpr (PREC == 1) {
+            // logical 16-byte chunks of a row's unit: 0..3 = hi (k 0-7, 8-15, 16-23, 24-31), 4..7 = lo; MFMA t covers
+            // k 16t..16t+15 with lanes 0-31 supplying the first and lanes 32-63 the second 8 k.
+            f32x4 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[0][i] = lds_read_b128<0>(Ab + coff[0] + i * 32 * BK * 4);
+            for (int t = 0; t < 2; ++t) {
+                const unsigned ch = (unsigned)(((2 * t + lh) ^ sw) * 16), cl = (unsigned)(((4 + 2 * t + lh) ^ sw) * 16);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[0][j] = lds_read_b128<0>(Bb + coff[0] + j * 32 * BK * 4);
-#pragma unroll
-        for (int sub = 0; sub < BK / 8; ++sub) {
-            const int cur = sub & 1, nxt = cur ^ 1;
-            if (sub + 1 < BK / 8) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[nxt][i] = lds_read_b128<0>(Ab + coff[sub + 1] + i * 32 * BK * 4);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read_b128<0>(Bb + coff[sub + 1] + j * 32 * BK * 4);
-                wait_lgkmcnt<TM + TN>();      // the reads of `cur` are complete (LDS returns in order)
-            } else {
-                wait_lgkmcnt<0>();
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (sub == 0) issue_a(fill);     // scheduled among the MFMAs below
-            if (sub == 1) issue_b(fill);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) {
+                    ah[t][i] = lds_read_b128<0>(Ab + ch + i * 32 * BK * 4);
+                    al[t][i] = lds_read_b128<0>(Ab + cl + i * 32 * BK * 4);
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
+                    bh[t][j] = lds_read_b128<0>(Bb + ch + j * 32 * BK * 4);
+                    bl[t][j] = lds_read_b128<0>(Bb + cl + j * 32 * BK * 4);
                 }
-            __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (t == 0) wait_lgkmcnt<2 * (TM + TN)>(); else wait_lgkmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == 0) issue_a(fill); else issue_b(fill);      // scheduled among the MFMAs below
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[t][i]), xl = __builtin_bit_cast(bf16x8, al[t][i]);
+                        const bf16x8 wh = __builtin_bit_cast(bf16x8, bh[t][j]), wl = __builtin_bit_cast(bf16x8, bl[t][j]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            f32x4 fa[2][TM], fb[2][TN];
+    #pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = lds_read_b128<0>(Ab + coff[0] + i * 32 * BK * 4);
+    #pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = lds_read_b128<0>(Bb + coff[0] + j * 32 * BK * 4);
+    #pragma unroll
+            for (int sub = 0; sub < BK / 8; ++sub) {
+                const int cur = sub & 1, nxt = cur ^ 1;
+                if (sub + 1 < BK / 8) {
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[nxt][i] = lds_read_b128<0>(Ab + coff[sub + 1] + i * 32 * BK * 4);
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read_b128<0>(Bb + coff[sub + 1] + j * 32 * BK * 4);
+                    wait_lgkmcnt<TM + TN>();      // the reads of `cur` are complete (LDS returns in order)
+                } else {
+                    wait_lgkmcnt<0>();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (sub == 0) issue_a(fill);     // scheduled among the MFMAs below
+                if (sub == 1) issue_b(fill);
+    #pragma unroll
+                for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (++slot == NS) slot = 0;
     }
@@ -415,6 +457,54 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
     wp[idx] = w[(((long long)o * Cin + c) * KH + kh) * KW + kw];
 }
 
+// ---- bf16x3 operand preparation -------------------------------------------------------------------------------------------
+__device__ inline unsigned short bf16_rne(float x) {          // round-to-nearest-even, like torch's .to(bfloat16) (no NaN inputs here)
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ inline void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
+    hi = bf16_rne(x);
+    lo = bf16_rne(x - __uint_as_float((unsigned)hi << 16));
+}
+
+// fp32 NHWC rows [rows][ldx] (C channels used) -> [rows][C/32][ hi: 32 x bf16 | lo: 32 x bf16 ]; one thread per 8 channels.
+__global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long long rows,
+                                                         int C, int ldx) {
+    const int c8 = C / 8;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * c8) return;
+    const long long r = idx / c8;
+    const int c = (int)(idx - r * c8) * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(x + r * ldx + c), v1 = *reinterpret_cast<const float4*>(x + r * ldx + c + 4);
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    unsigned short hi[8], lo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) split_bf16(v[i], hi[i], lo[i]);
+    unsigned short* base = y + (r * (C / 32) + c / 32) * 64 + (c & 31);
+    uint4 H, Lo;
+    H.x = hi[0] | ((unsigned)hi[1] << 16); H.y = hi[2] | ((unsigned)hi[3] << 16); H.z = hi[4] | ((unsigned)hi[5] << 16); H.w = hi[6] | ((unsigned)hi[7] << 16);
+    Lo.x = lo[0] | ((unsigned)lo[1] << 16); Lo.y = lo[2] | ((unsigned)lo[3] << 16); Lo.z = lo[4] | ((unsigned)lo[5] << 16); Lo.w = lo[6] | ((unsigned)lo[7] << 16);
+    *reinterpret_cast<uint4*>(base) = H;
+    *reinterpret_cast<uint4*>(base + 32) = Lo;
+}
+
+// OIHW fp32 -> packed [Cout][K/32][hi 32 | lo 32] with k = (kh*KW + kw)*Cin + c
+__global__ void __launch_bounds__(256) pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cout,
+                                                                 int Cin, int KH, int KW) {
+    const long long total = (long long)Cout * Cin * KH * KW;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int K = Cin * KH * KW;
+    const int o = (int)(idx / K), k = (int)(idx - (long long)o * K);
+    const int c = k % Cin, t = k / Cin, kw = t % KW, kh = t / KW;
+    unsigned short hi, lo;
+    split_bf16(w[(((long long)o * Cin + c) * KH + kh) * KW + kw], hi, lo);
+    unsigned short* base = wp + ((long long)o * (K / 32) + k / 32) * 64 + (k & 31);
+    base[0] = hi;
+    base[32] = lo;
+}
+
 struct TileInfo { int bm, bn, wmw, wnw, wkw, ns; };
 constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {
     {0, 0, 0, 0, 0, 0},
@@ -429,20 +519,26 @@ constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {
     {32, 32, 1, 1, 8, 2},     // VIDC_TILE_32x32_K8   (8 waves)
 };
 
-template <int BM, int BN, int WMW, int WNW, int WKW, int NS>
-int launch_tile(const ConvArgs& a, hipStream_t st) {
+template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC>
+int launch_tile_p(const ConvArgs& a, hipStream_t st) {
     constexpr int NT = 64 * WMW * WNW * WKW;
     constexpr size_t lds = (size_t)NS * (BM + BN) * BK * WKW * sizeof(float);
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
-        VIDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WMW, WNW, WKW, NS>),
+        VIDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WMW, WNW, WKW, NS, PREC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n * a.splitk * a.groups, 1, 1);
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WMW, WNW, WKW, NS>), grid, dim3(NT), lds, st, a);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WMW, WNW, WKW, NS, PREC>), grid, dim3(NT), lds, st, a);
     VIDC_CHECK_LAUNCH("conv_igemm_f32");
     return VIDC_OK;
+}
+
+template <int BM, int BN, int WMW, int WNW, int WKW, int NS>
+int launch_tile(const ConvArgs& a, hipStream_t st, int precision) {
+    return precision == VIDC_PREC_BF16X3 ? launch_tile_p<BM, BN, WMW, WNW, WKW, NS, 1>(a, st)
+                                         : launch_tile_p<BM, BN, WMW, WNW, WKW, NS, 0>(a, st);
 }
 
 int validate(const vidc_conv_desc* d) {
@@ -459,6 +555,7 @@ int validate(const vidc_conv_desc* d) {
     VIDC_REQUIRE(!(d->flags & VIDC_AFFINE2) || (d->scale2 && d->shift2), VIDC_ERR_NULL, "conv: AFFINE2 without scale2/shift2");
     VIDC_REQUIRE(!(d->flags & VIDC_RESIDUAL) || (d->residual && d->ldr >= d->Cout), VIDC_ERR_NULL, "conv: RESIDUAL without tensor");
     VIDC_REQUIRE(d->tile >= 0 && d->tile < VIDC_TILE_COUNT, VIDC_ERR_SHAPE, "conv: unknown tile id %d", d->tile);
+    VIDC_REQUIRE(d->precision == VIDC_PREC_FP32 || d->precision == VIDC_PREC_BF16X3, VIDC_ERR_SHAPE, "conv: unknown precision %d", d->precision);
     VIDC_REQUIRE(d->splitk == 1 || d->workspace, VIDC_ERR_NULL, "conv: split-K needs a workspace");
     VIDC_REQUIRE((long long)d->B * d->Ho * d->Wo < (1ll << 31), VIDC_ERR_SHAPE, "conv: M overflows int32");
     return VIDC_OK;
@@ -530,15 +627,15 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
     }
     hipStream_t st = vidc::as_stream(stream);
     switch (dd.tile) {
-        case VIDC_TILE_128x128:  rc = launch_tile<128, 128, 2, 2, 1, 2>(a, st); break;
-        case VIDC_TILE_128x64:   rc = launch_tile<128, 64, 2, 2, 1, 3>(a, st); break;
-        case VIDC_TILE_64x128:   rc = launch_tile<64, 128, 2, 2, 1, 3>(a, st); break;
-        case VIDC_TILE_64x64:    rc = launch_tile<64, 64, 2, 2, 1, 4>(a, st); break;
-        case VIDC_TILE_64x64_K2: rc = launch_tile<64, 64, 2, 2, 2, 3>(a, st); break;
-        case VIDC_TILE_32x64_K2: rc = launch_tile<32, 64, 1, 2, 2, 3>(a, st); break;
-        case VIDC_TILE_32x32_K4: rc = launch_tile<32, 32, 1, 1, 4, 3>(a, st); break;
-        case VIDC_TILE_32x128:   rc = launch_tile<32, 128, 1, 4, 1, 4>(a, st); break;
-        case VIDC_TILE_32x32_K8: rc = launch_tile<32, 32, 1, 1, 8, 2>(a, st); break;
+        case VIDC_TILE_128x128:  rc = launch_tile<128, 128, 2, 2, 1, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_128x64:   rc = launch_tile<128, 64, 2, 2, 1, 3>(a, st, dd.precision); break;
+        case VIDC_TILE_64x128:   rc = launch_tile<64, 128, 2, 2, 1, 3>(a, st, dd.precision); break;
+        case VIDC_TILE_64x64:    rc = launch_tile<64, 64, 2, 2, 1, 4>(a, st, dd.precision); break;
+        case VIDC_TILE_64x64_K2: rc = launch_tile<64, 64, 2, 2, 2, 3>(a, st, dd.precision); break;
+        case VIDC_TILE_32x64_K2: rc = launch_tile<32, 64, 1, 2, 2, 3>(a, st, dd.precision); break;
+        case VIDC_TILE_32x32_K4: rc = launch_tile<32, 32, 1, 1, 4, 3>(a, st, dd.precision); break;
+        case VIDC_TILE_32x128:   rc = launch_tile<32, 128, 1, 4, 1, 4>(a, st, dd.precision); break;
+        case VIDC_TILE_32x32_K8: rc = launch_tile<32, 32, 1, 1, 8, 2>(a, st, dd.precision); break;
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
     if (rc != VIDC_OK) return rc;
@@ -548,6 +645,26 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         hipLaunchKernelGGL(conv_splitk_finalize, grid, dim3(256), 0, st, a);
         VIDC_CHECK_LAUNCH("conv_splitk_finalize");
     }
+    return VIDC_OK;
+}
+
+extern "C" int vidc_split_bf16x3(const float* x, void* y, long long rows, int C, int ldx, vidc_stream_t stream) {
+    VIDC_REQUIRE(x && y, VIDC_ERR_NULL, "vidc_split_bf16x3: null pointer");
+    VIDC_REQUIRE(rows > 0 && C > 0 && C % 32 == 0 && ldx >= C && ldx % 4 == 0, VIDC_ERR_SHAPE, "vidc_split_bf16x3: C must be a multiple of 32");
+    const long long n = rows * (C / 8);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, vidc::as_stream(stream), x,
+                       reinterpret_cast<unsigned short*>(y), rows, C, ldx);
+    VIDC_CHECK_LAUNCH("split_rows_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_pack_conv_weight_bf16x3(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW, vidc_stream_t stream) {
+    VIDC_REQUIRE(w_oihw && w_packed, VIDC_ERR_NULL, "vidc_pack_conv_weight_bf16x3: null pointer");
+    VIDC_REQUIRE(Cout > 0 && Cin > 0 && Cin % 32 == 0 && KH > 0 && KW > 0, VIDC_ERR_SHAPE, "vidc_pack_conv_weight_bf16x3: Cin must be a multiple of 32");
+    const long long total = (long long)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vidc::as_stream(stream), w_oihw,
+                       reinterpret_cast<unsigned short*>(w_packed), Cout, Cin, KH, KW);
+    VIDC_CHECK_LAUNCH("pack_weight_bf16x3_kernel");
     return VIDC_OK;
 }
 

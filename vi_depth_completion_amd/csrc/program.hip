@@ -45,6 +45,10 @@ int launch_op(const vidc_op& op, hipStream_t st) {
         case VIDC_OP_WARP_INV:
             return vidc_warp2dof_inv_rot_norm((const float*)g.p[0], (const float*)g.p[1], (float*)g.p[2], g.i[0], g.i[1], g.i[2],
                                               g.f[0], g.f[1], g.i[3], g.i[4], s);
+        case VIDC_OP_SPLIT: {  // p[0] fp32 rows -> p[1] split-bf16 image; i[0..1] = rows (lo, hi), i[2] = C, i[3] = ldx
+            long long rows = (long long)(uint32_t)g.i[0] | ((long long)(uint32_t)g.i[1] << 32);
+            return vidc_split_bf16x3((const float*)g.p[0], const_cast<void*>(g.p[1]), rows, g.i[2], g.i[3], s);
+        }
         case VIDC_OP_COPY: {   // p[0] -> p[1], i[0..1] = byte count (lo, hi)
             size_t bytes = (size_t)(uint32_t)g.i[0] | ((size_t)(uint32_t)g.i[1] << 32);
             VIDC_HIP(hipMemcpyAsync(const_cast<void*>(g.p[1]), g.p[0], bytes, hipMemcpyDeviceToDevice, st));

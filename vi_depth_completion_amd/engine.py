@@ -65,9 +65,10 @@ class WeightStore:
     def raw(self, key):
         return self.sd()[key]
 
-    def packed(self, keys, dry_run=False):
-        """[G][Cout][KH][KW][Cin] fp32, packed by the C kernel."""
-        ck = ("w",) + tuple(keys)
+    def packed(self, keys, dry_run=False, precision=0):
+        """[G][Cout][KH][KW][Cin] fp32 (precision 0) or the split-bf16 image of the same bytes (precision 1), packed by
+        the C kernels."""
+        ck = ("w", precision) + tuple(keys)
         if ck not in self._cache:
             ws = [self.sd()[k + ".weight"].contiguous() for k in keys]
             co, ci, kh, kw = ws[0].shape
@@ -75,7 +76,8 @@ class WeightStore:
             for g, w in enumerate(ws):
                 assert tuple(w.shape) == (co, ci, kh, kw)
                 if not dry_run:
-                    L.check(L.lib().vidc_pack_conv_weight(L.ptr(w), L.ptr(out[g]), co, ci, kh, kw, L.current_stream()), "pack")
+                    fn = L.lib().vidc_pack_conv_weight_bf16x3 if precision == L.PREC_BF16X3 else L.lib().vidc_pack_conv_weight
+                    L.check(fn(L.ptr(w), L.ptr(out[g]), co, ci, kh, kw, L.current_stream()), "pack")
             if dry_run:
                 return out
             self._cache[ck] = out
@@ -116,6 +118,17 @@ def tuning_table():
     return _TUNING
 
 
+def precision_mode():
+    """VIDC_PRECISION=fp32  : every conv on fp32 MFMA (exact fp32; the reference mode).
+       VIDC_PRECISION=mixed : (default) compute-bound convs run split-bf16 3-pass MFMA (per-shape choice from the measured
+                              table, else by size); whole-path depth RMSE vs fp32 ~1.4e-5, bar 1e-3."""
+    return os.environ.get("VIDC_PRECISION", "mixed")
+
+
+def default_precision(flops):
+    return L.PREC_BF16X3 if flops >= 1.5e9 else L.PREC_FP32
+
+
 def conv_signature(d):
     return "M%d_N%d_K%d_k%ds%d_G%d" % (d.B * d.Ho * d.Wo, d.Cout, d.KH * d.KW * d.Cin, d.KH, d.stride, d.groups)
 
@@ -135,6 +148,8 @@ class Program:
         self.handle = None
         self.flops = 0           # executed conv FLOPs (2*M*N*K summed)
         self._keep = []
+        self._split_cache = {}   # (buf, ch_off, channels) -> T of the split-bf16 image
+        self.mode = precision_mode()
 
     # ---- buffers ----------------------------------------------------------------------------------------
     def _new_buf(self, elems, pinned=False):
@@ -181,17 +196,37 @@ class Program:
         Wo = (x.W + 2 * padding - kw) // stride + 1
         y = out if out is not None else self.nhwc(Ho, Wo, co, G)
         assert (y.H, y.W, y.C, y.G) == (Ho, Wo, co, G)
+        self._split_cache = {k: v for k, v in self._split_cache.items() if k[0] != y.buf}     # y is (re)written
         flags = (L.RELU1 if relu else 0) | (L.AFFINE2 if bn2 is not None else 0) | (L.RELU2 if relu2 else 0)
         if residual is not None:
             assert (residual.H, residual.W, residual.C, residual.G) == (Ho, Wo, co, G)
             flags |= L.RESIDUAL | (L.RELU3 if relu_after_residual else 0)
         if accumulate:
             flags |= L.ACCUM
-        self.flops += 2 * self.B * Ho * Wo * co * ci * kh * kw * G
-        self._emit("conv", [x, residual, y if accumulate else None], [y], x=x, y=y, keys=keys,
+        flops = 2 * self.B * Ho * Wo * co * ci * kh * kw * G
+        self.flops += flops
+        # precision: measured table entry if there is one, else by size
+        sig = "M%d_N%d_K%d_k%ds%d_G%d" % (self.B * Ho * Wo, co, kh * kw * ci, kh, stride, G)
+        prec = L.PREC_FP32
+        if self.mode == "mixed":
+            ent = tuning_table().get(sig)
+            prec = ent[2] if (ent is not None and len(ent) > 2) else default_precision(flops)
+        xin = self.split(x) if prec == L.PREC_BF16X3 else x
+        self._emit("conv", [xin, residual, y if accumulate else None], [y], x=xin, y=y, keys=keys, precision=prec,
                    bn=_keys(bn) if bn is not None else None, bn2=_keys(bn2) if bn2 is not None else None,
                    residual=residual, flags=flags, stride=stride, pad=padding, geom=(co, ci, kh, kw, Ho, Wo))
         return y
+
+    def split(self, x):
+        """Split-bf16 image of an fp32 activation tensor (same geometry / bytes), made once per tensor."""
+        ck = (x.buf, x.ch_off, x.C * x.G)
+        if ck not in self._split_cache:
+            assert not x.nchw and (x.C * x.G) % 32 == 0
+            y = T(self._new_buf(self.B * x.H * x.W * x.C * x.G), x.B, x.H, x.W, x.C, x.G)
+            self._emit("split", [x], [y], x=x, y=y)
+            self._split_cache[ck] = y.buf
+        # same storage, the caller's view of it (grouped and channel-concatenated views share one split image)
+        return T(self._split_cache[ck], x.B, x.H, x.W, x.C, x.G)
 
     def stem_conv(self, xs, key, relu=True, x_is_nchw=True):
         """xs: one NCHW tensor or a list (one per group, Cin may differ: 3,3,1)."""
@@ -312,7 +347,8 @@ class Program:
                 co, ci, kh, kwid, Ho, Wo = kw["geom"]
                 d = op.u.conv
                 op.kind = L.OP_CONV
-                wp = self.ws.packed([k for k in keys], dry_run)
+                prec = kw["precision"]
+                wp = self.ws.packed([k for k in keys], dry_run, prec)
                 s1, b1 = self.ws.affine(list(keys), list(kw["bn"]) if kw["bn"] is not None else None)
                 d.x, d.w, d.y = addr(x), wp.data_ptr(), addr(y)
                 d.scale1, d.shift1 = s1.data_ptr(), b1.data_ptr()
@@ -328,10 +364,13 @@ class Program:
                 d.KH, d.KW, d.stride, d.pad = kh, kwid, kw["stride"], kw["pad"]
                 d.flags, d.groups = kw["flags"], len(keys)
                 d.x_gs, d.w_gs, d.y_gs, d.p_gs = x.C, co * kh * kwid * ci, y.C, co
-                d.tile, d.splitk = 0, 1
+                d.tile, d.splitk, d.precision = 0, 1, prec
                 sig = conv_signature(d)
-                if sig in tuning_table():
-                    d.tile, d.splitk = tuning_table()[sig]
+                ent = tuning_table().get(sig)
+                if ent is not None and (len(ent) < 5 or prec == ent[2]):
+                    d.tile, d.splitk = ent[0], ent[1]
+                elif ent is not None and len(ent) >= 5:          # table holds the best fp32 config as well: [t, sk, prec, t32, sk32]
+                    d.tile, d.splitk = ent[3], ent[4]
                 else:
                     L.check(lib.vidc_conv2d_plan(C.byref(d)), "conv plan")
                 need = lib.vidc_conv2d_workspace_bytes(C.byref(d))
@@ -339,7 +378,7 @@ class Program:
                     ws_need[op.stream_id] = max(ws_need.get(op.stream_id, 0), need)
                 conv_ops.append(op)
                 self._keep += [wp, s1, b1]
-                self.op_names.append("conv:%s:%s:sk%d %s" % (keys[0], L.TILE_NAMES[d.tile], d.splitk, sig))
+                self.op_names.append("conv:%s:%s:sk%d:%s %s" % (keys[0], L.TILE_NAMES[d.tile], d.splitk, "bf16x3" if prec else "fp32", sig))
             elif kind == "stem":
                 x, y = kw["x"], kw["y"]
                 w = self.ws.raw(kw["key"] + ".weight").contiguous()
@@ -396,6 +435,13 @@ class Program:
                     g.i[j] = v
                 g.f[0], g.f[1] = it.cx, it.cy
                 self.op_names.append("warp_inv_rot_norm")
+            elif kind == "split":
+                x, y = kw["x"], kw["y"]
+                rows = x.B * x.H * x.W
+                op.kind = L.OP_SPLIT
+                g.p[0], g.p[1] = addr(x), addr(y)
+                g.i[0], g.i[1], g.i[2], g.i[3] = rows & 0xFFFFFFFF, rows >> 32, x.C * x.G, x.ld
+                self.op_names.append("split:%dx%d" % (rows, x.C * x.G))
             elif kind == "copy":
                 src, dst = kw["src"], kw["dst"]
                 nbytes = min(self.buf_elems[src.buf], self.buf_elems[dst.buf]) * 4

@@ -26,11 +26,35 @@ def pack_conv_weight(w_oihw):
     return out
 
 
+def pack_conv_weight_bf16x3(w_oihw):
+    """OIHW fp32 -> split-bf16 packed weights; returned as a float32-typed (Cout, K) tensor (same bytes: each 32-wide
+    K unit is [32 x bf16 hi | 32 x bf16 lo])."""
+    _dev(w_oihw)
+    w = w_oihw.contiguous().float()
+    co, ci, kh, kw = w.shape
+    out = torch.empty((co, kh * kw * ci), dtype=torch.float32, device=w.device)
+    L.check(L.lib().vidc_pack_conv_weight_bf16x3(L.ptr(w), L.ptr(out), co, ci, kh, kw, L.current_stream()), "pack_conv_weight_bf16x3")
+    return out
+
+
+def split_bf16x3(x_nhwc):
+    """fp32 NHWC -> split-bf16 image of the same shape/bytes (float32-typed storage)."""
+    _dev(x_nhwc)
+    x = x_nhwc.contiguous().float()
+    Cc = x.shape[-1]
+    out = torch.empty_like(x)
+    L.check(L.lib().vidc_split_bf16x3(L.ptr(x), L.ptr(out), x.numel() // Cc, Cc, Cc, L.current_stream()), "split_bf16x3")
+    return out
+
+
 def conv2d_bn_act(x, w_packed, scale1, shift1, kh, kw, stride=1, pad=0, relu1=False, scale2=None, shift2=None, relu2=False,
-                  residual=None, relu3=False, accumulate_into=None, tile=0, splitk=1, groups=1):
-    """x: NHWC (B,H,W,G*Cin) contiguous; w_packed: (G,Cout,kh*kw*Cin) or (Cout,K); returns NHWC (B,Ho,Wo,G*Cout)."""
+                  residual=None, relu3=False, accumulate_into=None, tile=0, splitk=1, groups=1, precision=0):
+    """x: NHWC (B,H,W,G*Cin) contiguous; w_packed: (G,Cout,kh*kw*Cin) or (Cout,K); returns NHWC (B,Ho,Wo,G*Cout).
+    precision=1 (bf16x3): x is split here; w_packed must come from pack_conv_weight_bf16x3."""
     _dev(x, w_packed, scale1, shift1)
     x = x.contiguous()
+    if precision == L.PREC_BF16X3:
+        x = split_bf16x3(x)
     B, H, W, ld = x.shape
     G = groups
     cin = ld // G
@@ -59,7 +83,7 @@ def conv2d_bn_act(x, w_packed, scale1, shift1, kh, kw, stride=1, pad=0, relu1=Fa
     d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, cout, G * cout
     d.KH, d.KW, d.stride, d.pad, d.flags, d.groups = kh, kw, stride, pad, flags, G
     d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, cout * kh * kw * cin, cout, cout
-    d.tile, d.splitk = tile, splitk
+    d.tile, d.splitk, d.precision = tile, splitk, precision
     if tile == 0:
         L.check(L.lib().vidc_conv2d_plan(C.byref(d)), "conv2d_plan")
         if splitk > 1:
