@@ -13,6 +13,7 @@ Frames shard over ranks with no data-path collective (weak scaling: every rank r
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -26,6 +27,7 @@ from vi_depth_completion_amd import sharding, synthetic as S   # noqa: E402
 
 FLOPS_PER_FRAME = {(240, 320): 293.88e9, (256, 320): 311.63e9}   # SURVEY.md §8d, reference formulation, 2 FLOP/MAC
 PEAK_F32_MFMA_TFLOPS = 157.3                                       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0                                     # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def parse():
@@ -55,12 +57,24 @@ def build_pipeline(H, W, dev):
     return pipe, sn_sd, dc_sd, cc
 
 
-def conv_stack_time_ms(prog, iters=5):
-    """Sum of the fused-conv launch durations of one program execution (HIP events between consecutive ops on the
-    launch stream, eager mode, averaged over `iters`), plus the number of conv launches."""
+def _sig_flops(name):
+    m = re.search(r"M(\d+)_N(\d+)_K(\d+)_k\ds\d_G(\d+)", name)
+    M, N, K, G = (int(v) for v in m.groups())
+    return 2.0 * M * N * K * G
+
+
+def conv_stack_times(prog, iters=5):
+    """Per-op durations of one program execution: HIP events recorded between consecutive ops on the launch stream
+    (eager mode, averaged over `iters`).  Returns {mode: (ms, launches, algorithmic_flops)} for the fused-conv launches
+    of each arithmetic mode, the program total, and the (name, ms) table."""
     total, per = prog.time(iters=iters, use_graph=False, per_op=True)
-    conv = [(n, t) for n, t in zip(prog.op_names, per) if n.startswith("conv:")]
-    return sum(t for _, t in conv), len(conv), total, list(zip(prog.op_names, per))
+    out = {}
+    for n, t in zip(prog.op_names, per):
+        if n.startswith("conv:"):
+            mode = "bf16x3" if ":bf16x3 " in n else "fp32"
+            ms, cnt, fl = out.get(mode, (0.0, 0, 0.0))
+            out[mode] = (ms + t, cnt + 1, fl + _sig_flops(n))
+    return out, total, list(zip(prog.op_names, per))
 
 
 def main():
@@ -107,6 +121,55 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
+    # ---- roofline of the dominant kernel (fused conv), measured live with HIP events -- before the
+    #      CPU baseline, whose OpenMP workers keep spinning and would slow the launching thread ---------------------
+    roofline = None
+    extra = {}
+    if rank == 0:
+        sn_prog = pipe.surface_normal_cnn.program(B, dev)
+        dc_prog = pipe.cnn.program(B, H, W, dev)
+        sn_t, sn_total, sn_ops = conv_stack_times(sn_prog)
+        dc_t, dc_total, dc_ops = conv_stack_times(dc_prog)
+        flops = FLOPS_PER_FRAME.get((H, W), 293.88e9 * H * W / (240.0 * 320.0)) * B
+        modes = {}
+        for d in (sn_t, dc_t):
+            for k, (ms, cnt, fl) in d.items():
+                a0, a1, a2 = modes.get(k, (0.0, 0, 0.0))
+                modes[k] = (a0 + ms, a1 + cnt, a2 + fl)
+        conv_ms = sum(v[0] for v in modes.values())
+        n_launch = sum(v[1] for v in modes.values())
+
+        def roof(mode):
+            ms, cnt, fl = modes[mode]
+            ach = fl / (ms * 1e-3) / 1e12
+            if mode == "fp32":
+                return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "kernel": "conv_igemm_f32<...,PREC=0> (v_mfma_f32_32x32x2_f32) + conv_splitk_finalize",
+                        "launches_per_frame": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
+                        "algorithmic_gflop_per_frame": round(fl / 1e9, 2), "ms_per_frame": round(ms, 3)}
+            return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "conv_igemm_f32<...,PREC=1> (bf16x3: 3 x v_mfma_f32_32x32x16_bf16 per product) + conv_splitk_finalize",
+                    "launches_per_frame": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
+                    "algorithmic_gflop_per_frame": round(fl / 1e9, 2), "ms_per_frame": round(ms, 3),
+                    "executed_tflops": round(3 * ach, 2), "frac_executed": round(3 * ach / PEAK_BF16_MFMA_TFLOPS, 4)}
+
+        dominant = max(modes, key=lambda k: modes[k][0])
+        roofline = roof(dominant)
+        extra = {"program_ms": {"surface_normal": round(sn_total, 3), "depth_completion": round(dc_total, 3)},
+                 "conv_ms_per_frame": round(conv_ms, 3), "conv_launches_per_frame": n_launch,
+                 "conv_stack_tflops_algorithmic": round(flops / (conv_ms * 1e-3) / 1e12, 2),
+                 "precision_mode": os.environ.get("VIDC_PRECISION", "mixed")}
+        for k in modes:
+            if k != dominant:
+                extra["roofline_" + k] = roof(k)
+        if args.per_op:
+            with open(args.per_op, "w") as f:
+                for name, ops in (("surface_normal", sn_ops), ("depth_completion", dc_ops)):
+                    for n, t in ops:
+                        f.write("%s\t%.2f\t%s\n" % (name, t * 1e3, n))
+
     # ---- parity of what was just timed: frame 0 of this rank against the CPU oracle (outside the timed region) ----
     rec = torch.zeros(4, dtype=torch.float64, device=dev)   # frames, seconds, sum sq err, n px
     rec[0], rec[1] = args.steps * B, elapsed
@@ -135,31 +198,6 @@ def main():
                                                                                     torch.get_num_threads(), os.cpu_count())}
     rec[2], rec[3] = sq_err, n_px
 
-    # ---- roofline of the dominant kernel (fused conv, fp32 MFMA), measured live with HIP events ---------------------
-    roofline = None
-    extra = {}
-    if rank == 0:
-        sn_prog = pipe.surface_normal_cnn.program(B, dev)
-        dc_prog = pipe.cnn.program(B, H, W, dev)
-        sn_ms, sn_n, sn_total, sn_ops = conv_stack_time_ms(sn_prog)
-        dc_ms, dc_n, dc_total, dc_ops = conv_stack_time_ms(dc_prog)
-        flops = FLOPS_PER_FRAME.get((H, W), 293.88e9 * H * W / (240.0 * 320.0)) * B
-        conv_ms = sn_ms + dc_ms
-        achieved = flops / (conv_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "kernel": "conv_igemm_f32 (+conv_splitk_finalize)", "launches_per_frame": sn_n + dc_n,
-                    "avg_launch_us": round(1e3 * conv_ms / (sn_n + dc_n), 2),
-                    "algorithmic_gflop_per_frame": round(flops / 1e9, 2),
-                    "executed_gflop_per_frame": round((sn_prog.flops + dc_prog.flops) / 1e9, 2)}
-        extra = {"program_ms": {"surface_normal": round(sn_total, 3), "depth_completion": round(dc_total, 3)},
-                 "conv_ms_per_frame": round(conv_ms, 3)}
-        if args.per_op:
-            with open(args.per_op, "w") as f:
-                for name, ops in (("surface_normal", sn_ops), ("depth_completion", dc_ops)):
-                    for n, t in ops:
-                        f.write("%s\t%.2f\t%s\n" % (name, t * 1e3, n))
-
     allrec = sharding.gather_records(rec)                 # the only collective: 4 doubles per rank over RCCL/xGMI
     if rank == 0:
         job = sharding.combine(allrec)
@@ -167,7 +205,8 @@ def main():
         line = {
             "metric": "frames/sec", "value": round(frames / t_max, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32" if os.environ.get("VIDC_PRECISION", "mixed") == "fp32" else "f32+bf16x3"), "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic %dx%d RGB + 200-pt sparse depth, batch %d per GPU, plane mask "
                                    "fixed; warp + surface-normal net + plane block/enrichment + depth-completion net" % (W, H, B),
                        "height": H, "width": W, "batch_per_gpu": B, "weights": "seeded random-init (seed 1234)",

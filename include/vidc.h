@@ -75,7 +75,10 @@ enum vidc_conv_flags {
     VIDC_RELU2 = 4,        /* relu after the second affine                                    */
     VIDC_RESIDUAL = 8,     /* += residual (Bottleneck identity)                               */
     VIDC_RELU3 = 16,       /* relu after the residual add                                     */
-    VIDC_ACCUM = 32        /* y += result (z1+z2+z3+z4, surface_normal.py:168)                */
+    VIDC_ACCUM = 32,       /* y += result (z1+z2+z3+z4, surface_normal.py:168)                */
+    VIDC_SPLIT_OUT = 64,   /* also write the split-bf16 image of the result to y_split (layout of y,
+                              same channel stride) so a following bf16x3 conv needs no split pass */
+    VIDC_NO_F32_OUT = 128  /* with SPLIT_OUT: skip the fp32 store (nobody reads it)              */
 };
 
 /* Fused nn.Conv2d(+bias) -> BatchNorm2d(eval) -> ReLU [-> BatchNorm2d -> ReLU] [+ identity -> ReLU].
@@ -104,6 +107,7 @@ typedef struct vidc_conv_desc {
                               hi|lo bf16 images made by vidc_split_bf16x3 /
                               vidc_pack_conv_weight_bf16x3 (same strides as fp32)     */
     int32_t reserved0;
+    void* y_split;         /* split-bf16 image of y (VIDC_SPLIT_OUT), or NULL         */
 } vidc_conv_desc;
 
 /* Workgroup tilings (BM x BN output tile; _Kn = n k-slices reduced inside the workgroup through LDS). */

@@ -31,8 +31,8 @@ def test_header_symbols_exported(lib):
 
 
 def test_struct_layout_matches_header():
-    # vidc_conv_desc: 9 pointers, 16 int32, 5 int64, 4 int32  (natural alignment)
-    assert C.sizeof(L.ConvDesc) == 9 * 8 + 16 * 4 + 5 * 8 + 4 * 4
+    # vidc_conv_desc: 9 pointers, 16 int32, 5 int64, 4 int32, 1 pointer  (natural alignment)
+    assert C.sizeof(L.ConvDesc) == 9 * 8 + 16 * 4 + 5 * 8 + 4 * 4 + 8
     assert C.sizeof(L.GenericArgs) == 6 * 8 + 16 * 4 + 8 * 4
     assert C.sizeof(L.Op) == 16 + max(C.sizeof(L.ConvDesc), C.sizeof(L.GenericArgs))
 
@@ -132,7 +132,11 @@ def test_mixed_precision_program_structure(recorded_programs):
                     assert kw["geom"][1] % 32 == 0
                 else:
                     assert kw["x"].buf not in split_out
+                if kw.get("split_out") is not None:               # split fused into this conv's epilogue
+                    split_out[kw["split_out"].buf] = kw["y"].buf
+                    assert kw["flags"] & L.SPLIT_OUT
         assert n_bf >= 3 and len(split_out) <= n_bf
+        assert prog.n_fused_splits >= 1
     # the 54-GFLOP-class layer (dc.feature1_upsamping.0) must be on the fast path
     dc = recorded_programs[1]
     big = [kw for kind, _, _, kw in dc.ops if kind == "conv" and kw["keys"][0] == "feature1_upsamping.0"][0]

@@ -205,6 +205,29 @@ def test_conv_bf16x3(shape, tile):
     assert (got - ref).abs().max().item() < 5e-4          # |x|~1, |w|~sqrt(2/K): 2^-16 * sum|x w| stays far below this
 
 
+@pytest.mark.parametrize("cfg", [(0, 1, 1), (1, 1, 1), (0, 4, 3), (1, 2, 3)])
+def test_conv_fused_split_output(cfg):
+    """VIDC_SPLIT_OUT: the split-bf16 image written by the conv / split-K finalize epilogue is bit-identical to splitting
+    the fp32 output afterwards; VIDC_NO_F32_OUT leaves the fp32 tensor untouched."""
+    from vi_depth_completion_amd import ops
+    prec, splitk, groups = cfg
+    x, w, s1, b1 = _conv_case(17, 1, 15, 20, 256, 128, 3, 1, groups)
+    pack = ops.pack_conv_weight_bf16x3 if prec else ops.pack_conv_weight
+    wp = torch.stack([pack(wg.to(DEV)) for wg in w])
+    xd = nhwc(x).to(DEV)
+    y = ops.conv2d_bn_act(xd, wp, s1.to(DEV), b1.to(DEV), 3, 3, 1, 1, relu1=True, tile=4, splitk=splitk, groups=groups, precision=prec)
+    img = torch.full_like(y, 7.0)
+    y2 = ops.conv2d_bn_act(xd, wp, s1.to(DEV), b1.to(DEV), 3, 3, 1, 1, relu1=True, tile=4, splitk=splitk, groups=groups, precision=prec,
+                           split_out=img)
+    assert torch.equal(y, y2)
+    assert torch.equal(img.view(torch.int32), ops.split_bf16x3(y).view(torch.int32))
+    keep = torch.full_like(y, -3.0)
+    img2 = torch.zeros_like(y)
+    ops.conv2d_bn_act(xd, wp, s1.to(DEV), b1.to(DEV), 3, 3, 1, 1, relu1=True, tile=4, splitk=splitk, groups=groups, precision=prec,
+                      split_out=img2, no_f32_out=True, accumulate_into=None if True else keep)
+    assert torch.equal(img2.view(torch.int32), img.view(torch.int32))
+
+
 def test_split_bf16x3_layout():
     from vi_depth_completion_amd import ops
     x = S.normal01(21, "split.x", (2, 5, 7, 64)).float()

@@ -17,7 +17,7 @@ PLANE_RECORD = 16
 MAX_STREAMS = 4
 
 # vidc_conv_flags / vidc_up_flags / vidc_op_kind / vidc_conv_tile
-RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM = 1, 2, 4, 8, 16, 32
+RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM, SPLIT_OUT, NO_F32_OUT = 1, 2, 4, 8, 16, 32, 64, 128
 UP_RELU, UP_ACCUM = 1, 2
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY, OP_SPLIT = range(1, 11)
 TILE_AUTO = 0
@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("flags", C.c_int32), ("groups", C.c_int32),
         ("x_gs", C.c_int64), ("w_gs", C.c_int64), ("y_gs", C.c_int64), ("r_gs", C.c_int64), ("p_gs", C.c_int64),
         ("tile", C.c_int32), ("splitk", C.c_int32), ("precision", C.c_int32), ("reserved0", C.c_int32),
+        ("y_split", C.c_void_p),
     ]
 
 

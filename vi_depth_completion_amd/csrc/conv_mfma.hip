@@ -25,7 +25,7 @@ constexpr int LDS_LD = 36;   // padded LDS row (floats): 144 B keeps b128 reads 
 struct ConvArgs {
     const float* x; const float* w; float* y;
     const float* scale1; const float* shift1; const float* scale2; const float* shift2;
-    const float* residual; float* ws;
+    const float* residual; float* ws; unsigned short* y_split;
     int B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, ldr, KH, KW, stride, pad, flags, groups;
     long long x_gs, w_gs, y_gs, r_gs, p_gs;
     int M, K, ksteps, splitk, tiles_m, tiles_n;
@@ -45,6 +45,26 @@ __device__ inline float epilogue(float v, int n, size_t off_r, size_t off_y, con
     }
     if (a.flags & VIDC_ACCUM) v += y[off_y];
     return v;
+}
+
+// ---- bf16 split helpers ------------------------------------------------------------------------------------------------
+__device__ inline unsigned short bf16_rne(float x) {          // round-to-nearest-even, like torch's .to(bfloat16) (no NaN inputs here)
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ inline void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
+    hi = bf16_rne(x);
+    lo = bf16_rne(x - __uint_as_float((unsigned)hi << 16));
+}
+
+// Writes the split-bf16 image element (m, n) of a tensor with `ld` channels per row: unit n/32 = [32 x hi | 32 x lo].
+__device__ inline void store_split(unsigned short* img, size_t m, int ld, int n, float v) {
+    unsigned short hi, lo;
+    split_bf16(v, hi, lo);
+    unsigned short* u = img + (m * ld + (n & ~31)) * 2 + (n & 31);
+    u[0] = hi;
+    u[32] = lo;
 }
 
 // Zero source for LDS-DMA lanes whose row is padding (conv halo, M tail, Cout tail, K tail).
@@ -407,7 +427,8 @@ conv_igemm_f32(const ConvArgs a) {
                     }
                     const size_t oy = (size_t)m * a.ldy + n;
                     if (a.flags & VIDC_ACCUM) v += yg[oy];
-                    yg[oy] = v;
+                    if (!(a.flags & VIDC_NO_F32_OUT)) yg[oy] = v;
+                    if (a.flags & VIDC_SPLIT_OUT) store_split(a.y_split + (size_t)g * a.y_gs * 2, (size_t)m, a.ldy, n, v);
                 }
             }
         }
@@ -439,7 +460,9 @@ __global__ void __launch_bounds__(256) conv_splitk_finalize(const ConvArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         size_t oy = (size_t)m * a.ldy + n + t;
-        yg[oy] = epilogue(v[t], n + t, (size_t)m * a.ldr + n + t, oy, a, s1, b1, s2, b2, res, yg);
+        const float o = epilogue(v[t], n + t, (size_t)m * a.ldr + n + t, oy, a, s1, b1, s2, b2, res, yg);
+        if (!(a.flags & VIDC_NO_F32_OUT)) yg[oy] = o;
+        if (a.flags & VIDC_SPLIT_OUT) store_split(a.y_split + (size_t)g * a.y_gs * 2, (size_t)m, a.ldy, n + t, o);
     }
 }
 
@@ -457,17 +480,7 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
     wp[idx] = w[(((long long)o * Cin + c) * KH + kh) * KW + kw];
 }
 
-// ---- bf16x3 operand preparation -------------------------------------------------------------------------------------------
-__device__ inline unsigned short bf16_rne(float x) {          // round-to-nearest-even, like torch's .to(bfloat16) (no NaN inputs here)
-    unsigned u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ inline void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
-    hi = bf16_rne(x);
-    lo = bf16_rne(x - __uint_as_float((unsigned)hi << 16));
-}
-
+// ---- bf16x3 operand preparation kernels ---------------------------------------------------------------------------------
 // fp32 NHWC rows [rows][ldx] (C channels used) -> [rows][C/32][ hi: 32 x bf16 | lo: 32 x bf16 ]; one thread per 8 channels.
 __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long long rows,
                                                          int C, int ldx) {
@@ -557,6 +570,9 @@ int validate(const vidc_conv_desc* d) {
     VIDC_REQUIRE(d->tile >= 0 && d->tile < VIDC_TILE_COUNT, VIDC_ERR_SHAPE, "conv: unknown tile id %d", d->tile);
     VIDC_REQUIRE(d->precision == VIDC_PREC_FP32 || d->precision == VIDC_PREC_BF16X3, VIDC_ERR_SHAPE, "conv: unknown precision %d", d->precision);
     VIDC_REQUIRE(d->splitk == 1 || d->workspace, VIDC_ERR_NULL, "conv: split-K needs a workspace");
+    VIDC_REQUIRE(!(d->flags & VIDC_SPLIT_OUT) || (d->y_split && d->Cout % 32 == 0 && d->ldy % 32 == 0), VIDC_ERR_NULL,
+                 "conv: SPLIT_OUT needs y_split and Cout, ldy multiples of 32");
+    VIDC_REQUIRE(!(d->flags & VIDC_NO_F32_OUT) || (d->flags & VIDC_SPLIT_OUT), VIDC_ERR_SHAPE, "conv: NO_F32_OUT without SPLIT_OUT writes nothing");
     VIDC_REQUIRE((long long)d->B * d->Ho * d->Wo < (1ll << 31), VIDC_ERR_SHAPE, "conv: M overflows int32");
     return VIDC_OK;
 }
@@ -612,7 +628,7 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
     }
     ConvArgs a;
     a.x = dd.x; a.w = dd.w; a.y = dd.y; a.scale1 = dd.scale1; a.shift1 = dd.shift1; a.scale2 = dd.scale2; a.shift2 = dd.shift2;
-    a.residual = dd.residual; a.ws = dd.workspace;
+    a.residual = dd.residual; a.ws = dd.workspace; a.y_split = reinterpret_cast<unsigned short*>(dd.y_split);
     a.B = dd.B; a.H = dd.H; a.W = dd.W; a.Cin = dd.Cin; a.ldx = dd.ldx; a.Ho = dd.Ho; a.Wo = dd.Wo; a.Cout = dd.Cout;
     a.ldy = dd.ldy; a.ldr = dd.ldr; a.KH = dd.KH; a.KW = dd.KW; a.stride = dd.stride; a.pad = dd.pad; a.flags = dd.flags;
     a.groups = dd.groups; a.x_gs = dd.x_gs; a.w_gs = dd.w_gs; a.y_gs = dd.y_gs; a.r_gs = dd.r_gs; a.p_gs = dd.p_gs;

@@ -286,6 +286,35 @@ class Program:
         self._emit("copy", [src], [dst], src=src, dst=dst)
 
     # ---- planning ----------------------------------------------------------------------------------------
+    def _fuse_splits(self):
+        """A split op whose input was just produced by a fused conv is folded into that conv's epilogue (VIDC_SPLIT_OUT);
+        when nothing else reads the fp32 result the conv does not store it at all (VIDC_NO_F32_OUT)."""
+        n = len(self.ops)
+        drop = set()
+        for i, (kind, _r, _w, kw) in enumerate(self.ops):
+            if kind != "split":
+                continue
+            xs = kw["x"]
+            j = next((t for t in range(i - 1, -1, -1) if xs.buf in self.ops[t][2]), None)
+            if j is None or self.ops[j][0] != "conv":
+                continue
+            pk = self.ops[j][3]
+            y = pk["y"]
+            if y.ch_off != 0 or y.C * y.G != xs.C * xs.G or y.ld != y.C * y.G or pk.get("split_out") is not None:
+                continue
+            pk["split_out"] = kw["y"]
+            pk["flags"] |= L.SPLIT_OUT
+            self.ops[j][2].append(kw["y"].buf)
+            drop.add(i)
+        for j, (kind, _r, _w, kw) in enumerate(self.ops):
+            if kind == "conv" and kw.get("split_out") is not None and kw["y"].buf not in self.pinned:
+                yb = kw["y"].buf
+                used = any(t not in drop and (yb in self.ops[t][1] or yb in self.ops[t][2]) for t in range(j + 1, n))
+                if not used:
+                    kw["flags"] |= L.NO_F32_OUT
+        self.n_fused_splits = len(drop)
+        self.ops = [op for i, op in enumerate(self.ops) if i not in drop]
+
     def _plan_buffers(self):
         n = len(self.buf_elems)
         multi_stream = any(kw["stream_id"] != 0 for _, _, _, kw in self.ops)
@@ -327,6 +356,8 @@ class Program:
     def finalize(self, dry_run=False):
         """Plans buffers and builds the C op array.  dry_run=True stops before any HIP call (host-logic tests on CPU)."""
         lib = L.lib()
+        if os.environ.get("VIDC_FUSE_SPLIT", "1") == "1":
+            self._fuse_splits()
         storage = self._plan_buffers()
         self.storage = storage
         self.bytes_allocated = sum({t.data_ptr(): t.numel() * 4 for t in storage if t is not None}.values())
@@ -363,6 +394,8 @@ class Program:
                 d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, co, y.ld
                 d.KH, d.KW, d.stride, d.pad = kh, kwid, kw["stride"], kw["pad"]
                 d.flags, d.groups = kw["flags"], len(keys)
+                if kw.get("split_out") is not None:
+                    d.y_split = addr(kw["split_out"])
                 d.x_gs, d.w_gs, d.y_gs, d.p_gs = x.C, co * kh * kwid * ci, y.C, co
                 d.tile, d.splitk, d.precision = 0, 1, prec
                 sig = conv_signature(d)

@@ -48,7 +48,8 @@ def split_bf16x3(x_nhwc):
 
 
 def conv2d_bn_act(x, w_packed, scale1, shift1, kh, kw, stride=1, pad=0, relu1=False, scale2=None, shift2=None, relu2=False,
-                  residual=None, relu3=False, accumulate_into=None, tile=0, splitk=1, groups=1, precision=0):
+                  residual=None, relu3=False, accumulate_into=None, tile=0, splitk=1, groups=1, precision=0, split_out=None,
+                  no_f32_out=False):
     """x: NHWC (B,H,W,G*Cin) contiguous; w_packed: (G,Cout,kh*kw*Cin) or (Cout,K); returns NHWC (B,Ho,Wo,G*Cout).
     precision=1 (bf16x3): x is split here; w_packed must come from pack_conv_weight_bf16x3."""
     _dev(x, w_packed, scale1, shift1)
@@ -79,6 +80,9 @@ def conv2d_bn_act(x, w_packed, scale1, shift1, kh, kw, stride=1, pad=0, relu1=Fa
         flags |= L.RESIDUAL | (L.RELU3 if relu3 else 0)
     if accumulate_into is not None:
         flags |= L.ACCUM
+    if split_out is not None:       # float32-typed tensor of y's shape receiving the split-bf16 image of the result
+        d.y_split = L.ptr(split_out)
+        flags |= L.SPLIT_OUT | (L.NO_F32_OUT if no_f32_out else 0)
     d.B, d.H, d.W, d.Cin, d.ldx = B, H, W, cin, ld
     d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, cout, G * cout
     d.KH, d.KW, d.stride, d.pad, d.flags, d.groups = kh, kw, stride, pad, flags, G
