@@ -66,7 +66,8 @@ int vidc_warp2dof_inv_rot_norm(const float* x, const float* params, float* z, in
  * conv + BN + ReLU stacks           (networks/surface_normal.py:10-145, networks/depth_completion.py:16-147)
  * ---------------------------------------------------------------------------------------------- */
 
-/* OIHW -> packed [G][Cout][KH][KW][Cin] (K-contiguous rows for the implicit GEMM), one group per call. */
+/* OIHW -> packed [Cout][Cin/32][KH][KW][32] (K-contiguous rows for the implicit GEMM; channel-unit major, tap minor so
+ * the taps of a unit re-read the same pixels back to back), one group per call.  Cin % 32 == 0. */
 int vidc_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, vidc_stream_t stream);
 
 enum vidc_conv_flags {
@@ -87,7 +88,7 @@ enum vidc_conv_flags {
  * ModifiedFPN, depth_completion.py:155-157); group g uses x + g*x_gs, w + g*w_gs, y + g*y_gs, ... */
 typedef struct vidc_conv_desc {
     const float* x;        /* NHWC input,  channel stride ldx                         */
-    const float* w;        /* packed weights [Cout][KH*KW*Cin]                        */
+    const float* w;        /* packed weights [Cout][KH*KW*Cin] (vidc_pack_conv_weight) */
     float* y;              /* NHWC output, channel stride ldy                         */
     const float* scale1;   /* [Cout] gamma/sqrt(var+eps)            (1 if no BN)      */
     const float* shift1;   /* [Cout] beta - mean*scale + bias*scale (bias if no BN)   */
@@ -123,7 +124,7 @@ enum vidc_conv_tile { VIDC_TILE_AUTO = 0, VIDC_TILE_128x128 = 1, VIDC_TILE_128x6
 enum vidc_conv_precision { VIDC_PREC_FP32 = 0, VIDC_PREC_BF16X3 = 1 };
 /* fp32 NHWC rows [rows][ldx] (first C channels) -> split image [rows][C/32][hi|lo]; C % 32 == 0. */
 int vidc_split_bf16x3(const float* x, void* y, long long rows, int C, int ldx, vidc_stream_t stream);
-/* OIHW fp32 -> split packed weights [Cout][KH*KW*Cin/32][hi|lo] (one group per call). */
+/* OIHW fp32 -> split packed weights [Cout][Cin/32][KH][KW][hi|lo] (one group per call). */
 int vidc_pack_conv_weight_bf16x3(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW, vidc_stream_t stream);
 
 int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream);

@@ -74,7 +74,7 @@ def run(shape, tile, splitk, iters=20, check=False, precision=0):
         xc = x.cpu().permute(0, 3, 1, 2)
         outs = []
         for g in range(G):
-            wg = w[g].cpu().view(cout, k, k, cin).permute(0, 3, 1, 2)
+            wg = w[g].cpu().view(cout, cin // 32, k, k, 32).permute(0, 1, 4, 2, 3).reshape(cout, cin, k, k)
             outs.append(F.relu(F.conv2d(xc[:, g * cin:(g + 1) * cin], wg, None, stride, pad)))
         ref = torch.cat(outs, 1).permute(0, 2, 3, 1)
         err = (y.cpu() - ref).abs().max().item()

@@ -14,18 +14,19 @@ from vi_depth_completion_amd import _lib as L          # noqa: E402
 L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libvidc_timing.so")
 from vi_depth_completion_amd import synthetic as S     # noqa: E402
 
-SHAPES = {  # name: (H, W, cin, cout, k, G, tile)
-    "l3_1x1_1024to256_G3": (16, 20, 1024, 256, 1, 3, 7),
-    "l3_3x3_G3": (16, 20, 256, 256, 3, 3, 9),
-    "l3_1x1_256to1024_G1": (16, 20, 256, 1024, 1, 1, 6),
-    "f1_3x3_768": (64, 80, 768, 768, 3, 1, 1),
+SHAPES = {  # name: (H, W, cin, cout, k, G, tile, precision)
+    "l3_1x1_1024to256_G3": (16, 20, 1024, 256, 1, 3, 7, 1),
+    "l3_3x3_G3": (16, 20, 256, 256, 3, 3, 7, 1),
+    "l3_1x1_256to1024_G3": (16, 20, 256, 1024, 1, 3, 6, 1),
+    "l3_1x1_256to1024_G1": (16, 20, 256, 1024, 1, 1, 6, 1),
+    "f1_3x3_768": (64, 80, 768, 768, 3, 1, 3, 1),
 }
 
 
 def main():
     dev = "cuda"
     lib = L.lib()
-    for name, (H, W, cin, cout, k, G, tile) in SHAPES.items():
+    for name, (H, W, cin, cout, k, G, tile, prec) in SHAPES.items():
         x = S.normal01(1, "x", (1, H, W, G * cin)).float().to(dev)
         w = S.normal01(1, "w", (G, cout, k * k * cin), scale=0.05).float().to(dev)
         s1, b1 = torch.ones(G, cout, device=dev), torch.zeros(G, cout, device=dev)
@@ -35,7 +36,7 @@ def main():
         d.B, d.H, d.W, d.Cin, d.ldx, d.Ho, d.Wo, d.Cout, d.ldy = 1, H, W, cin, G * cin, H, W, cout, G * cout
         d.KH, d.KW, d.stride, d.pad, d.flags, d.groups = k, k, 1, k // 2, L.RELU1, G
         d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, cout * k * k * cin, cout, cout
-        d.tile, d.splitk = tile, 1
+        d.tile, d.splitk, d.precision = tile, 1, prec
         dbg = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
         d.workspace = dbg.data_ptr()
         st = torch.cuda.current_stream().cuda_stream

@@ -4,7 +4,7 @@
 // Replaces the nn.Conv2d -> nn.BatchNorm2d -> nn.ReLU chains of networks/surface_normal.py:10-145 and
 // networks/depth_completion.py:16-147 (on the reference: one cuDNN/ATen call per layer, 462 convs + 458 BNs per frame).
 //
-//   M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin, activations NHWC fp32, weights packed [Cout][KH][KW][Cin].
+//   M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin, activations NHWC fp32, weights packed [Cout][Cin/32][KH][KW][32].
 //   Workgroup tile BM x BN, K unit 32 floats (one (kh,kw) tap, 32 input channels = 128 contiguous bytes per pixel row).
 //   Global -> LDS by DMA (global_load_lds, 16 B/lane) into an NS-deep ring with counted vmcnt waits and raw barriers,
 //   so NS-1 stages of weights/activations are in flight per workgroup (weights are always HBM-cold: 1.5 GB per frame).
@@ -193,10 +193,14 @@ conv_igemm_f32(const ConvArgs a) {
         const int n = n0 + (j * WPK + wq) * 8 + lrow;
         b_off[j] = n < a.Cout ? (unsigned)((n * a.K + csw) * 4) : OOB;
     }
-    // this wave's K unit -> (kh, kw, channel chunk), advanced by WKW units per stage
-    const int cpt = a.Cin / BK;
+    // K order: unit u = cu * (KH*KW) + tap -- channel unit major, tap minor -- so the KH*KW taps of one 32-channel unit run
+    // back to back and the shifted re-reads of the same pixels hit L2 (tap-major order re-read every pixel KH*KW times with
+    // ~10 MB of other traffic per XCD in between: 23x over-fetch measured on the 3x3, K=6912 layer).  This wave's unit
+    // advances by WKW per stage.
+    const int ntaps = a.KH * a.KW;
     int unit = st_begin * WKW + kq;
-    int tap = unit / cpt, cc = unit - tap * cpt;
+    int cc = unit / ntaps;
+    int tap = unit - cc * ntaps;
     int kh = tap / a.KW, kw = tap - kh * a.KW;
     const int unit_end = min(units, st_end * WKW);      // past this workgroup's K range every DMA lane fetches zeros
 
@@ -222,8 +226,9 @@ conv_igemm_f32(const ConvArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t*)dst, 16, (int)(b_off[j] + uoff), 0, 0, 0);
         }
         unit += WKW;
-        cc += WKW;
-        while (cc >= cpt) { cc -= cpt; if (++kw == a.KW) { kw = 0; ++kh; } }
+#pragma unroll
+        for (int t = 0; t < WKW; ++t)
+            if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++cc; } }
     };
     auto issue_stage = [&](int slot) { issue_a(slot); issue_b(slot); };
 
@@ -468,15 +473,14 @@ __global__ void __launch_bounds__(256) conv_splitk_finalize(const ConvArgs a) {
 
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
                                                           int KH, int KW) {
-    // wp[o][kh][kw][c] = w[o][c][kh][kw]
+    // wp[o][c/32][kh][kw][c%32] = w[o][c][kh][kw]   (K order of the conv kernel: channel unit major, tap minor)
     const long long total = (long long)Cout * Cin * KH * KW;
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    int c = (int)(idx % Cin);
-    long long t = idx / Cin;
-    int kw = (int)(t % KW); t /= KW;
-    int kh = (int)(t % KH);
-    int o = (int)(t / KH);
+    const int K = Cin * KH * KW;
+    const int o = (int)(idx / K), k = (int)(idx - (long long)o * K);
+    const int ci = k & 31, u = k >> 5, taps = KH * KW;
+    const int cu = u / taps, tap = u - cu * taps, kh = tap / KW, kw = tap - kh * KW, c = cu * 32 + ci;
     wp[idx] = w[(((long long)o * Cin + c) * KH + kh) * KW + kw];
 }
 
@@ -502,7 +506,7 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
     *reinterpret_cast<uint4*>(base + 32) = Lo;
 }
 
-// OIHW fp32 -> packed [Cout][K/32][hi 32 | lo 32] with k = (kh*KW + kw)*Cin + c
+// OIHW fp32 -> packed [Cout][Cin/32][KH][KW][hi 32 | lo 32]
 __global__ void __launch_bounds__(256) pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cout,
                                                                  int Cin, int KH, int KW) {
     const long long total = (long long)Cout * Cin * KH * KW;
@@ -510,7 +514,8 @@ __global__ void __launch_bounds__(256) pack_weight_bf16x3_kernel(const float* __
     if (idx >= total) return;
     const int K = Cin * KH * KW;
     const int o = (int)(idx / K), k = (int)(idx - (long long)o * K);
-    const int c = k % Cin, t = k / Cin, kw = t % KW, kh = t / KW;
+    const int ci = k & 31, u = k >> 5, taps = KH * KW;
+    const int cu = u / taps, tap = u - cu * taps, kh = tap / KW, kw = tap - kh * KW, c = cu * 32 + ci;
     unsigned short hi, lo;
     split_bf16(w[(((long long)o * Cin + c) * KH + kh) * KW + kw], hi, lo);
     unsigned short* base = wp + ((long long)o * (K / 32) + k / 32) * 64 + (k & 31);
