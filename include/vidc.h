@@ -114,7 +114,10 @@ typedef struct vidc_conv_desc {
 /* Workgroup tilings (BM x BN output tile; _Kn = n k-slices reduced inside the workgroup through LDS). */
 enum vidc_conv_tile { VIDC_TILE_AUTO = 0, VIDC_TILE_128x128 = 1, VIDC_TILE_128x64 = 2, VIDC_TILE_64x128 = 3,
                       VIDC_TILE_64x64 = 4, VIDC_TILE_64x64_K2 = 5, VIDC_TILE_32x64_K2 = 6, VIDC_TILE_32x32_K4 = 7,
-                      VIDC_TILE_32x128 = 8, VIDC_TILE_32x32_K8 = 9, VIDC_TILE_COUNT = 10 };
+                      VIDC_TILE_32x128 = 8, VIDC_TILE_32x32_K8 = 9,
+                      /* same tilings with deeper LDS rings (_Dn = n stages) */
+                      VIDC_TILE_32x64_K2_D5 = 10, VIDC_TILE_32x32_K4_D4 = 11, VIDC_TILE_32x128_D6 = 12, VIDC_TILE_64x64_K2_D4 = 13,
+                      VIDC_TILE_COUNT = 14 };
 
 /* Arithmetic of the contraction.  FP32: v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32, the reference mode).
  * BF16X3: every operand is split as x = hi + lo (bf16 each, round-to-nearest-even) and each product is computed as

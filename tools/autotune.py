@@ -24,7 +24,8 @@ from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN   # no
 from vi_depth_completion_amd.networks.surface_normal import SurfaceNormalPrediction   # noqa: E402
 
 OUT = os.path.join(ROOT, "vi_depth_completion_amd", "conv_tuning.json")
-TILE_DIMS = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (64, 64), 6: (32, 64), 7: (32, 32), 8: (32, 128), 9: (32, 32)}
+TILE_DIMS = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (64, 64), 6: (32, 64), 7: (32, 32), 8: (32, 128), 9: (32, 32),
+             10: (32, 64), 11: (32, 32), 12: (32, 128), 13: (64, 64)}
 
 
 def time_desc(lib, d, st, copies=20):

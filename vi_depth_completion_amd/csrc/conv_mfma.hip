@@ -14,6 +14,7 @@
 //   at a channel offset (concat-free skip connections).  Split-K writes fp32 partials and a finalize kernel applies
 //   the same epilogue.  `groups` (blockIdx.z) runs the three ModifiedFPN pyramids in one launch.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -79,6 +80,32 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n in [0, MAXN]; the instruction needs an immediate.  Tested from MAXN
+// downwards: the steady-state value is MAXN, so a main-loop iteration pays one scalar compare.  Waiting for a smaller
+// count than necessary is always safe.
+template <int MAXN, int N = MAXN>
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+    if constexpr (N > 0) {
+        if (n >= N) { wait_vmcnt<N>(); return; }
+        wait_vmcnt_dyn<MAXN, N - 1>(n);
+    } else {
+        wait_vmcnt<0>();
+    }
+}
+
+// Stage s has landed when only DMA groups younger than its own are outstanding.  Issue order: prologue B_0..B_{PRO-1},
+// A_0..A_{PRO-1} (PRO = NS-1; always issued, zero-sourced past the K range), then one (A, B) pair per main-loop iteration
+// s = 0 .. nst-NS; the last NS-1 iterations issue nothing.
+template <int NS, int A_J, int LPS>
+__device__ __forceinline__ void wait_stage(int s, int nst) {
+    constexpr int PRO = NS - 1;
+    const int n_main = nst > PRO ? nst - PRO : 0;
+    const int loop_issued = s < n_main ? s : n_main;                    // (A, B) pairs issued by the loop before this wait
+    int younger;
+    if (s < PRO) younger = (PRO - 1 - s) * A_J + loop_issued * LPS;     // its A group is in the prologue's A run
+    else         younger = (loop_issued - (s - PRO) - 1) * LPS;         // stage s was issued by loop iteration s-PRO
+    wait_vmcnt_dyn<(NS - 2) * LPS>(younger);      // younger <= (NS-2)*LPS always (A_J <= LPS)
 }
 template <int N>
 __device__ __forceinline__ void wait_lgkmcnt() {
@@ -165,28 +192,8 @@ conv_igemm_f32(const ConvArgs a) {
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.w + g * a.w_gs), 0, w_bytes, 0x00020000);
     const int lrow = lane >> 3;
     const int csw = ((lane & 7) ^ lrow) * 4;            // swizzled 16-byte chunk this lane fetches (row & 7 == lane >> 3)
-    int a_off[A_J];                                      // byte offset of (pixel, tap (0,0), channel csw); may be negative
-    unsigned a_taps[A_J];                                // bit t set: tap t = kh*KW+kw of this row reads a real pixel
-    const int HoWo = a.Ho * a.Wo;
-    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)a.Wo;
-#pragma unroll
-    for (int j = 0; j < A_J; ++j) {
-        const int m = m0 + (j * WPK + wq) * 8 + lrow;
-        const bool ok = m < a.M;
-        const int mm = ok ? m : 0;
-        int b = (int)((float)mm * inv_howo);             // float reciprocal + fix-up: exact for M < 2^23
-        int rem = mm - b * HoWo;
-        if (rem < 0) { --b; rem += HoWo; } else if (rem >= HoWo) { ++b; rem -= HoWo; }
-        int oy = (int)((float)rem * inv_wo);
-        int ox = rem - oy * a.Wo;
-        if (ox < 0) { --oy; ox += a.Wo; } else if (ox >= a.Wo) { ++oy; ox -= a.Wo; }
-        const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-        unsigned colm = 0, taps = 0;                     // KH + KW steps instead of KH * KW
-        for (int tw = 0; tw < a.KW; ++tw) colm |= ((unsigned)(ix0 + tw) < (unsigned)a.W) ? 1u << tw : 0u;
-        for (int th = 0; th < a.KH; ++th) taps |= ((unsigned)(iy0 + th) < (unsigned)a.H) ? colm << (th * a.KW) : 0u;
-        a_taps[j] = ok ? taps : 0u;
-        a_off[j] = (((b * a.H + iy0) * a.W + ix0) * a.ldx + csw) * 4;
-    }
+    // ---- weights first: their DMAs need only (n, K unit) and they are the HBM-cold operand, so the prologue stages of B are in
+    //      flight while the activation rows are decoded below ----------------------------------------------------------------
     unsigned b_off[B_J];
 #pragma unroll
     for (int j = 0; j < B_J; ++j) {
@@ -202,8 +209,51 @@ conv_igemm_f32(const ConvArgs a) {
     int cc = unit / ntaps;
     int tap = unit - cc * ntaps;
     int kh = tap / a.KW, kw = tap - kh * a.KW;
-    const int unit_end = min(units, st_end * WKW);      // past this workgroup's K range every DMA lane fetches zeros
 
+    const int unit_end = min(units, st_end * WKW);      // past this workgroup's K range every DMA lane fetches zeros
+    constexpr int PRO = NS - 1;                      // stages issued before the main loop
+    {
+        int ub = unit;
+#pragma unroll
+        for (int s = 0; s < PRO; ++s) {
+            const unsigned uoff = ub < unit_end ? (unsigned)(ub * BK * 4) : OOB;
+#pragma unroll
+            for (int j = 0; j < B_J; ++j) {
+                float* dst = smem + s * STAGE + (WKW * BM + kq * BN + (j * WPK + wq) * 8) * BK;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t*)dst, 16, (int)(b_off[j] + uoff), 0, 0, 0);
+            }
+            ub += WKW;
+        }
+    }
+
+    int a_off[A_J];                                      // byte offset of (pixel, tap (0,0), channel csw); may be negative
+    unsigned a_taps[A_J];                                // bit t set: tap t = kh*KW+kw of this row reads a real pixel
+    const int HoWo = a.Ho * a.Wo;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)a.Wo;
+    const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;    // input pixel index == output pixel index
+#pragma unroll
+    for (int j = 0; j < A_J; ++j) {
+        const int m = m0 + (j * WPK + wq) * 8 + lrow;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        if (pointwise) {
+            a_taps[j] = ok ? 1u : 0u;
+            a_off[j] = (mm * a.ldx + csw) * 4;
+            continue;
+        }
+        int b = (int)((float)mm * inv_howo);             // float reciprocal + fix-up: exact for M < 2^23
+        int rem = mm - b * HoWo;
+        if (rem < 0) { --b; rem += HoWo; } else if (rem >= HoWo) { ++b; rem -= HoWo; }
+        int oy = (int)((float)rem * inv_wo);
+        int ox = rem - oy * a.Wo;
+        if (ox < 0) { --oy; ox += a.Wo; } else if (ox >= a.Wo) { ++oy; ox -= a.Wo; }
+        const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+        unsigned colm = 0, taps = 0;                     // KH + KW steps instead of KH * KW
+        for (int tw = 0; tw < a.KW; ++tw) colm |= ((unsigned)(ix0 + tw) < (unsigned)a.W) ? 1u << tw : 0u;
+        for (int th = 0; th < a.KH; ++th) taps |= ((unsigned)(iy0 + th) < (unsigned)a.H) ? colm << (th * a.KW) : 0u;
+        a_taps[j] = ok ? taps : 0u;
+        a_off[j] = (((b * a.H + iy0) * a.W + ix0) * a.ldx + csw) * 4;
+    }
     // One pipeline stage = A_J + B_J DMA instructions per wave, issued in two halves that the main loop places inside
     // groups of MFMAs (branch-free, so the scheduler can interleave them with the 64-clk MFMA issue slots).
     auto issue_a = [&](int slot) {
@@ -225,12 +275,13 @@ conv_igemm_f32(const ConvArgs a) {
             float* dst = sbase + (WKW * BM + kq * BN + (j * WPK + wq) * 8) * BK;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t*)dst, 16, (int)(b_off[j] + uoff), 0, 0, 0);
         }
+    };
+    auto advance = [&]() {
         unit += WKW;
 #pragma unroll
         for (int t = 0; t < WKW; ++t)
             if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++cc; } }
     };
-    auto issue_stage = [&](int slot) { issue_a(slot); issue_b(slot); };
 
     // ---- epilogue operands, fetched now so their (cold) latency hides under the main loop --------------------------
     const int li = lane & 31, lh = lane >> 5;
@@ -281,7 +332,7 @@ conv_igemm_f32(const ConvArgs a) {
     // and can be scheduled between MFMAs, and the vmcnt distance is the same in every iteration.
     VIDC_STAMP(0);      // setup done
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue_stage(s);
+    for (int s = 0; s < PRO; ++s) { issue_a(s); advance(); }     // the B halves of these stages are already in flight
     VIDC_STAMP(1);      // prologue DMAs issued
 
     // Fragment reads are inline asm: hipcc cannot prove that a ds_read does not alias an in-flight LDS-DMA and would
@@ -295,10 +346,15 @@ conv_igemm_f32(const ConvArgs a) {
 #pragma unroll
     for (int sub = 0; sub < BK / 8; ++sub) coff[sub] = (unsigned)(((sub * 2 + lh) ^ sw) * 16);
 
+    // One pipeline iteration.  `issue_tag` = true_type: refill the ring (branch-free, so the DMA issue can be scheduled
+    // between MFMAs); false_type: the last NS-1 iterations, which consume what is already in flight and issue nothing --
+    // so no DMA is outstanding when the loop ends and the epilogue does not have to drain any.
     int slot = 0;
-    for (int s = 0; s < nst; ++s) {
-        // stage s has landed once at most the (NS-2) younger stages are still in flight
-        wait_vmcnt<(NS - 2) * LPS>();
+    auto iteration = [&](int s, auto issue_tag) {
+        // DMA issue order: prologue B_0..B_{PRO-1}, A_0..A_{PRO-1}, then per iteration A, B.  Stage s < PRO has landed when
+        // only the (PRO-1-s) younger prologue A groups and the s stages issued by the loop remain; from s = PRO on, when at
+        // most NS-2 whole stages remain.
+        wait_stage<NS, A_J, LPS>(s, nst);
         __builtin_amdgcn_s_barrier();     // every wave's pieces of stage s are in LDS; everyone finished stage s-1
         if (s == 0) VIDC_STAMP(2);      // first stage landed
         int fill = slot + NS - 1; if (fill >= NS) fill -= NS;     // the slot read in iteration s-1: free since the barrier
@@ -326,7 +382,7 @@ conv_igemm_f32(const ConvArgs a) {
             for (int t = 0; t < 2; ++t) {
                 if (t == 0) wait_lgkmcnt<2 * (TM + TN)>(); else wait_lgkmcnt<0>();
                 __builtin_amdgcn_sched_barrier(0);
-                if (t == 0) issue_a(fill); else issue_b(fill);      // scheduled among the MFMAs below
+                if constexpr (decltype(issue_tag)::value) { if (t == 0) issue_a(fill); else { issue_b(fill); advance(); } }   // among the MFMAs
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -359,7 +415,7 @@ conv_igemm_f32(const ConvArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (sub == 0) issue_a(fill);     // scheduled among the MFMAs below
-                if (sub == 1) issue_b(fill);
+                if (sub == 1) { issue_b(fill); advance(); }
     #pragma unroll
                 for (int i = 0; i < TM; ++i)
     #pragma unroll
@@ -373,11 +429,12 @@ conv_igemm_f32(const ConvArgs a) {
             }
         }
         if (++slot == NS) slot = 0;
-    }
+    };
+    const int n_main = nst > NS - 1 ? nst - (NS - 1) : 0;
+    for (int s = 0; s < n_main; ++s) iteration(s, std::true_type{});
+    for (int s = n_main; s < nst; ++s) iteration(s, std::false_type{});
 
-    // ---- in-workgroup K reduction (k-slices 1.. add into slice 0, fixed order) ---------------------------------------
     VIDC_STAMP(3);      // main loop done
-    wait_vmcnt<0>();                     // drain the (zero-sourced) tail DMAs before LDS is reused / the wave ends
     if (WKW > 1) {
         __syncthreads();
         float* red = smem;
@@ -404,38 +461,75 @@ conv_igemm_f32(const ConvArgs a) {
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -----------
+    // All flag tests are wave-uniform and hoisted; the arithmetic is branch-free (ReLU off = max with -inf).
+    const float lo1 = (a.flags & VIDC_RELU1) ? 0.f : -INFINITY;
+    const float lo2 = (a.flags & VIDC_RELU2) ? 0.f : -INFINITY;
+    const float lo3 = (a.flags & VIDC_RELU3) ? 0.f : -INFINITY;
+    const bool aff2 = a.flags & VIDC_AFFINE2, has_res = a.flags & VIDC_RESIDUAL, accum = a.flags & VIDC_ACCUM;
+    const bool st_f32 = !(a.flags & VIDC_NO_F32_OUT), st_split = a.flags & VIDC_SPLIT_OUT;
+    unsigned short* ysp = st_split ? a.y_split + (size_t)g * a.y_gs * 2 : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * 32 * TN + j * 32 + li;
-            if (n >= a.Cout) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= a.M) continue;
+            const int nb = n0 + wn * 32 * TN + j * 32;             // first channel of this 32-wide tile (wave-uniform)
+            if (nb >= a.Cout) continue;
+            const int n = nb + li;
+            const int mb = m0 + wm * 32 * TM + i * 32;             // first row of this tile (wave-uniform)
+            const int mrow = mb + 4 * lh;
+            const bool full = mb + 32 <= a.M;
 #ifndef VIDC_CONV_TIMING
-                if (a.splitk > 1) {
-                    a.ws[((size_t)(kz * a.groups + g) * a.M + m) * a.Cout + n] = acc[i][j][r];
-                } else
-#endif
-                {
-                    float v = acc[i][j][r] * e_s1[j] + e_b1[j];
-                    if (a.flags & VIDC_RELU1) v = fmaxf(v, 0.f);
-                    if (a.flags & VIDC_AFFINE2) {
-                        v = v * e_s2[j] + e_b2[j];
-                        if (a.flags & VIDC_RELU2) v = fmaxf(v, 0.f);
-                    }
-                    if (a.flags & VIDC_RESIDUAL) {
-                        v += e_res[i][j][r];
-                        if (a.flags & VIDC_RELU3) v = fmaxf(v, 0.f);
-                    }
-                    const size_t oy = (size_t)m * a.ldy + n;
-                    if (a.flags & VIDC_ACCUM) v += yg[oy];
-                    if (!(a.flags & VIDC_NO_F32_OUT)) yg[oy] = v;
-                    if (a.flags & VIDC_SPLIT_OUT) store_split(a.y_split + (size_t)g * a.y_gs * 2, (size_t)m, a.ldy, n, v);
+            if (a.splitk > 1) {
+                float* wsp = a.ws + ((size_t)(kz * a.groups + g) * a.M) * a.Cout + n;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mrow + (r & 3) + 8 * (r >> 2);
+                    if (full || m < a.M) wsp[(size_t)m * a.Cout] = acc[i][j][r];
                 }
+                continue;
             }
+#endif
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[i][j][r] * e_s1[j] + e_b1[j], lo1);
+            if (aff2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r] * e_s2[j] + e_b2[j], lo2);
+            }
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r] + e_res[i][j][r], lo3);
+            }
+            const unsigned o0 = (unsigned)mrow * (unsigned)a.ldy + (unsigned)n;     // element offset of (mrow, n): M*ldy < 2^31
+            // `full_tag` = true_type: all 32 rows of the tile exist (every tile but the last m-tile): no per-row predicate
+            auto finish = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                if (accum) {
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dm = (r & 3) + 8 * (r >> 2);
+                        old[r] = (FULL || mrow + dm < a.M) ? yg[o0 + (unsigned)(dm * a.ldy)] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += old[r];
+                }
+                if (st_f32) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dm = (r & 3) + 8 * (r >> 2);
+                        if (FULL || mrow + dm < a.M) yg[o0 + (unsigned)(dm * a.ldy)] = v[r];
+                    }
+                }
+                if (st_split) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dm = (r & 3) + 8 * (r >> 2);
+                        if (FULL || mrow + dm < a.M) store_split(ysp, (size_t)(mrow + dm), a.ldy, n, v[r]);
+                    }
+                }
+            };
+            if (full) finish(std::true_type{}); else finish(std::false_type{});
         }
     VIDC_STAMP(4);      // epilogue stores issued
 #ifdef VIDC_CONV_TIMING
@@ -535,6 +629,10 @@ constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {
     {32, 32, 1, 1, 4, 3},     // VIDC_TILE_32x32_K4
     {32, 128, 1, 4, 1, 4},    // VIDC_TILE_32x128
     {32, 32, 1, 1, 8, 2},     // VIDC_TILE_32x32_K8   (8 waves)
+    {32, 64, 1, 2, 2, 5},     // VIDC_TILE_32x64_K2_D5  deeper rings for the DMA-latency-bound small layers
+    {32, 32, 1, 1, 4, 4},     // VIDC_TILE_32x32_K4_D4
+    {32, 128, 1, 4, 1, 6},    // VIDC_TILE_32x128_D6
+    {64, 64, 2, 2, 2, 4},     // VIDC_TILE_64x64_K2_D4
 };
 
 template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC>
@@ -579,6 +677,8 @@ int validate(const vidc_conv_desc* d) {
                  "conv: SPLIT_OUT needs y_split and Cout, ldy multiples of 32");
     VIDC_REQUIRE(!(d->flags & VIDC_NO_F32_OUT) || (d->flags & VIDC_SPLIT_OUT), VIDC_ERR_SHAPE, "conv: NO_F32_OUT without SPLIT_OUT writes nothing");
     VIDC_REQUIRE((long long)d->B * d->Ho * d->Wo < (1ll << 31), VIDC_ERR_SHAPE, "conv: M overflows int32");
+    VIDC_REQUIRE((long long)d->B * d->Ho * d->Wo * d->ldy < (1ll << 31) && (long long)d->B * d->H * d->W * d->ldx < (1ll << 29),
+                 VIDC_ERR_SHAPE, "conv: tensor too large for 32-bit offsets (M*ldy < 2^31 elements, input < 2 GiB)");
     return VIDC_OK;
 }
 
@@ -657,6 +757,10 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         case VIDC_TILE_32x32_K4: rc = launch_tile<32, 32, 1, 1, 4, 3>(a, st, dd.precision); break;
         case VIDC_TILE_32x128:   rc = launch_tile<32, 128, 1, 4, 1, 4>(a, st, dd.precision); break;
         case VIDC_TILE_32x32_K8: rc = launch_tile<32, 32, 1, 1, 8, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_32x64_K2_D5: rc = launch_tile<32, 64, 1, 2, 2, 5>(a, st, dd.precision); break;
+        case VIDC_TILE_32x32_K4_D4: rc = launch_tile<32, 32, 1, 1, 4, 4>(a, st, dd.precision); break;
+        case VIDC_TILE_32x128_D6:   rc = launch_tile<32, 128, 1, 4, 1, 6>(a, st, dd.precision); break;
+        case VIDC_TILE_64x64_K2_D4: rc = launch_tile<64, 64, 2, 2, 2, 4>(a, st, dd.precision); break;
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
     if (rc != VIDC_OK) return rc;
