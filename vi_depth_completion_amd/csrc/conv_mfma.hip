@@ -30,7 +30,25 @@ struct ConvArgs {
     int B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, ldr, KH, KW, stride, pad, flags, groups;
     long long x_gs, w_gs, y_gs, r_gs, p_gs;
     int M, K, ksteps, splitk, tiles_m, tiles_n;
+    unsigned dv_tiles_m[3], dv_splitk[3], dv_tiles_n[3], dv_ntaps[3], dv_kw[3];   // {multiplier, shift, d == 1 mask} of fast_div()
 };
+
+// Division of a wave-uniform n < 2^31 by a launch constant d without the ~40-instruction emulated divide: the host stores
+// mul = ceil(2^(31+l) / d), l = ceil(log2 d); n / d == umulhi(n, mul) >> (l - 1), exact for every n < 2^31 (d >= 2).
+// d == 1 is encoded as mul = 0 plus an all-ones mask that passes n through, so the device side is branch-free (a branch
+// would also split the prologue into basic blocks, each with its own kernel-argument s_load + wait).
+__host__ inline void fast_div_init(unsigned d, unsigned out[3]) {
+    if (d <= 1) { out[0] = 0; out[1] = 0; out[2] = 0xFFFFFFFFu; return; }
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    const unsigned long long num = 1ull << (31 + l);
+    out[0] = (unsigned)((num + d - 1) / d);
+    out[1] = l - 1;
+    out[2] = 0;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned n, const unsigned dv[3]) {
+    return (__umulhi(n, dv[0]) >> dv[1]) + (n & dv[2]);
+}
 
 __device__ inline float epilogue(float v, int n, size_t off_r, size_t off_y, const ConvArgs& a, const float* s1, const float* b1,
                                  const float* s2, const float* b2, const float* res, const float* y) {
@@ -161,17 +179,19 @@ conv_igemm_f32(const ConvArgs a) {
     {
         const int W = gridDim.x, w = blockIdx.x;
         const int xcd = w & 7, j = w >> 3, q = W >> 3, r = W & 7;
-        int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-        tile_m = v % a.tiles_m; v /= a.tiles_m;
-        kz = v % a.splitk; v /= a.splitk;
-        tile_n = v % a.tiles_n;
-        g = v / a.tiles_n;
+        const unsigned v0 = (unsigned)(xcd * q + min(xcd, r) + j);      // XCDs 0..r-1 own q+1 items, the rest q
+        const unsigned v1 = fast_div(v0, a.dv_tiles_m);
+        const unsigned v2 = fast_div(v1, a.dv_splitk);
+        tile_m = (int)(v0 - v1 * a.tiles_m);
+        kz = (int)(v1 - v2 * a.splitk);
+        g = (int)fast_div(v2, a.dv_tiles_n);
+        tile_n = (int)(v2 - g * a.tiles_n);
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int units = a.ksteps;                                       // K in units of 32 floats
     const int stages_total = (units + WKW - 1) / WKW;
-    const int st_begin = (int)(((long long)stages_total * kz) / a.splitk);
-    const int st_end = (int)(((long long)stages_total * (kz + 1)) / a.splitk);
+    const int st_begin = (int)fast_div((unsigned)(stages_total * kz), a.dv_splitk);          // stages_total * splitk < 2^31
+    const int st_end = (int)fast_div((unsigned)(stages_total * (kz + 1)), a.dv_splitk);
     const int nst = st_end - st_begin;
 
     // ---- per-lane DMA source coordinates -----------------------------------------------------------------
@@ -206,9 +226,8 @@ conv_igemm_f32(const ConvArgs a) {
     // advances by WKW per stage.
     const int ntaps = a.KH * a.KW;
     int unit = st_begin * WKW + kq;
-    int cc = unit / ntaps;
+    int cc = (int)fast_div((unsigned)unit, a.dv_ntaps);
     int tap = unit - cc * ntaps;
-    int kh = tap / a.KW, kw = tap - kh * a.KW;
 
     const int unit_end = min(units, st_end * WKW);      // past this workgroup's K range every DMA lane fetches zeros
     constexpr int PRO = NS - 1;                      // stages issued before the main loop
@@ -248,9 +267,11 @@ conv_igemm_f32(const ConvArgs a) {
         int ox = rem - oy * a.Wo;
         if (ox < 0) { --oy; ox += a.Wo; } else if (ox >= a.Wo) { ++oy; ox -= a.Wo; }
         const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-        unsigned colm = 0, taps = 0;                     // KH + KW steps instead of KH * KW
-        for (int tw = 0; tw < a.KW; ++tw) colm |= ((unsigned)(ix0 + tw) < (unsigned)a.W) ? 1u << tw : 0u;
-        for (int th = 0; th < a.KH; ++th) taps |= ((unsigned)(iy0 + th) < (unsigned)a.H) ? colm << (th * a.KW) : 0u;
+        unsigned colm = 0, taps = 0;                     // KH + KW steps instead of KH * KW; KH, KW <= 3 (validate())
+#pragma unroll
+        for (int tw = 0; tw < 3; ++tw) colm |= (tw < a.KW && (unsigned)(ix0 + tw) < (unsigned)a.W) ? 1u << tw : 0u;
+#pragma unroll
+        for (int th = 0; th < 3; ++th) taps |= (th < a.KH && (unsigned)(iy0 + th) < (unsigned)a.H) ? colm << (th * a.KW) : 0u;
         a_taps[j] = ok ? taps : 0u;
         a_off[j] = (((b * a.H + iy0) * a.W + ix0) * a.ldx + csw) * 4;
     }
@@ -258,7 +279,8 @@ conv_igemm_f32(const ConvArgs a) {
     // groups of MFMAs (branch-free, so the scheduler can interleave them with the 64-clk MFMA issue slots).
     auto issue_a = [&](int slot) {
         float* sbase = smem + slot * STAGE;
-        const unsigned tapbit = unit < unit_end ? 1u << (kh * a.KW + kw) : 0u;
+        const unsigned tapbit = unit < unit_end ? 1u << tap : 0u;
+        const int kh = (int)fast_div((unsigned)tap, a.dv_kw), kw = tap - kh * a.KW;
         const int tap_off = (((kh * a.W + kw) * a.ldx) + cc * BK) * 4;
 #pragma unroll
         for (int j = 0; j < A_J; ++j) {
@@ -276,11 +298,14 @@ conv_igemm_f32(const ConvArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t*)dst, 16, (int)(b_off[j] + uoff), 0, 0, 0);
         }
     };
+    // K position after one stage (this wave's unit advances by WKW): branch-free, so it can sit between the MFMAs of the loop
+    const int step_cc = (int)fast_div((unsigned)WKW, a.dv_ntaps), step_tap = WKW - step_cc * ntaps;
     auto advance = [&]() {
         unit += WKW;
-#pragma unroll
-        for (int t = 0; t < WKW; ++t)
-            if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++cc; } }
+        tap += step_tap;
+        const int wrap = tap >= ntaps ? 1 : 0;
+        tap -= wrap ? ntaps : 0;
+        cc += step_cc + wrap;
     };
 
     // ---- epilogue operands, fetched now so their (cold) latency hides under the main loop --------------------------
@@ -664,7 +689,8 @@ int validate(const vidc_conv_desc* d) {
     VIDC_REQUIRE(d->Cin > 0 && d->Cin % BK == 0, VIDC_ERR_SHAPE, "conv: Cin=%d must be a multiple of %d", d->Cin, BK);
     VIDC_REQUIRE(d->Cout > 0 && d->Cout % 4 == 0, VIDC_ERR_SHAPE, "conv: Cout=%d must be a multiple of 4", d->Cout);
     VIDC_REQUIRE(d->ldx >= d->Cin && d->ldy >= d->Cout && d->ldx % 4 == 0, VIDC_ERR_SHAPE, "conv: bad channel strides");
-    VIDC_REQUIRE(d->KH >= 1 && d->KW >= 1 && d->stride >= 1 && d->pad >= 0, VIDC_ERR_SHAPE, "conv: bad kernel geometry");
+    VIDC_REQUIRE(d->KH >= 1 && d->KW >= 1 && d->KH <= 3 && d->KW <= 3 && d->stride >= 1 && d->pad >= 0, VIDC_ERR_SHAPE,
+                 "conv: bad kernel geometry (kernels up to 3x3)");
     VIDC_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
                  VIDC_ERR_SHAPE, "conv: Ho/Wo inconsistent with H/W, kernel, stride, pad");
     VIDC_REQUIRE(d->groups >= 1 && d->splitk >= 1, VIDC_ERR_SHAPE, "conv: groups/splitk must be >= 1");
@@ -746,6 +772,12 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         const int stages = (a.ksteps + ti.wkw - 1) / ti.wkw;
         if (a.splitk > stages) a.splitk = stages;
     }
+    fast_div_init((unsigned)a.tiles_m, a.dv_tiles_m);
+    fast_div_init((unsigned)a.splitk, a.dv_splitk);
+    fast_div_init((unsigned)a.tiles_n, a.dv_tiles_n);
+    fast_div_init((unsigned)(a.KH * a.KW), a.dv_ntaps);
+    fast_div_init((unsigned)a.KW, a.dv_kw);
+    VIDC_REQUIRE((long long)a.tiles_m * a.tiles_n * a.splitk * a.groups < (1ll << 31), VIDC_ERR_SHAPE, "conv: grid too large");
     hipStream_t st = vidc::as_stream(stream);
     switch (dd.tile) {
         case VIDC_TILE_128x128:  rc = launch_tile<128, 128, 2, 2, 1, 2>(a, st, dd.precision); break;
