@@ -42,7 +42,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--per-op", type=str, default="", help="write the per-op timing table to this file")
-    ap.add_argument("--in-flight", type=int, default=2, help="frames executing concurrently on separate HIP streams (1 = strictly sequential _call_cnn)")
+    ap.add_argument("--mode", choices=("interleaved", "streams", "sequential"), default="interleaved",
+                    help="interleaved: software pipeline over frames (pipeline.run_interleaved: tick t = surface-normal net of frame t "
+                         "+ depth-completion net of frame t-1 as one 4-group program); streams: --in-flight frames on separate HIP "
+                         "streams; sequential: back-to-back _call_cnn")
+    ap.add_argument("--in-flight", type=int, default=2, help="frames executing concurrently in --mode streams")
     return ap.parse_args()
 
 
@@ -100,11 +104,14 @@ def main():
 
     def run(n):
         """n steps (= n frames of batch B through the whole hot path); all n outputs are complete on return."""
-        if args.in_flight <= 1:
+        if args.mode == "sequential" or (args.mode == "streams" and args.in_flight <= 1):
             for i in range(n):
                 out = pipe._call_cnn(pool[i % len(pool)])
-        else:
+        elif args.mode == "streams":
             for out in pipe.run_stream((pool[i % len(pool)] for i in range(n)), in_flight=args.in_flight):
+                pass
+        else:       # n frames = n + 1 pipeline ticks, all inside the timed region
+            for out in pipe.run_interleaved(pool[i % len(pool)] for i in range(n)):
                 pass
         return out
 
@@ -126,10 +133,15 @@ def main():
     roofline = None
     extra = {}
     if rank == 0:
-        sn_prog = pipe.surface_normal_cnn.program(B, dev)
-        dc_prog = pipe.cnn.program(B, H, W, dev)
-        sn_t, sn_total, sn_ops = conv_stack_times(sn_prog)
-        dc_t, dc_total, dc_ops = conv_stack_times(dc_prog)
+        if args.mode == "interleaved":     # the program that was timed: one tick = both networks, 4-group pyramid launches
+            fp = pipe.frame_program(B, H, W)
+            sn_t, sn_total, sn_ops = conv_stack_times(fp)
+            dc_t, dc_total, dc_ops = {}, 0.0, []
+        else:
+            sn_prog = pipe.surface_normal_cnn.program(B, dev)
+            dc_prog = pipe.cnn.program(B, H, W, dev)
+            sn_t, sn_total, sn_ops = conv_stack_times(sn_prog)
+            dc_t, dc_total, dc_ops = conv_stack_times(dc_prog)
         flops = FLOPS_PER_FRAME.get((H, W), 293.88e9 * H * W / (240.0 * 320.0)) * B
         modes = {}
         for d in (sn_t, dc_t):
@@ -157,7 +169,8 @@ def main():
 
         dominant = max(modes, key=lambda k: modes[k][0])
         roofline = roof(dominant)
-        extra = {"program_ms": {"surface_normal": round(sn_total, 3), "depth_completion": round(dc_total, 3)},
+        extra = {"program_ms": ({"frame_program_tick": round(sn_total, 3)} if args.mode == "interleaved" else
+                                {"surface_normal": round(sn_total, 3), "depth_completion": round(dc_total, 3)}),
                  "conv_ms_per_frame": round(conv_ms, 3), "conv_launches_per_frame": n_launch,
                  "conv_stack_tflops_algorithmic": round(flops / (conv_ms * 1e-3) / 1e12, 2),
                  "precision_mode": os.environ.get("VIDC_PRECISION", "mixed")}
@@ -166,7 +179,7 @@ def main():
                 extra["roofline_" + k] = roof(k)
         if args.per_op:
             with open(args.per_op, "w") as f:
-                for name, ops in (("surface_normal", sn_ops), ("depth_completion", dc_ops)):
+                for name, ops in ((("frame_program" if args.mode == "interleaved" else "surface_normal"), sn_ops), ("depth_completion", dc_ops)):
                     for n, t in ops:
                         f.write("%s\t%.2f\t%s\n" % (name, t * 1e3, n))
 
@@ -210,7 +223,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: synthetic %dx%d RGB + 200-pt sparse depth, batch %d per GPU, plane mask "
                                    "fixed; warp + surface-normal net + plane block/enrichment + depth-completion net" % (W, H, B),
                        "height": H, "width": W, "batch_per_gpu": B, "weights": "seeded random-init (seed 1234)",
-                       "frames_in_flight": args.in_flight,
+                       "mode": args.mode, "frames_in_flight": (2 if args.mode == "interleaved" else args.in_flight if args.mode == "streams" else 1),
                        "sharding": "frames round-robin over %d rank(s), no data-path collective" % world},
             "rmse_vs_oracle": (round(job["rmse"], 8) if job["rmse"] is not None else None),
             "roofline": roofline, "cpu_baseline": cpu_baseline,

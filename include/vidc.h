@@ -238,12 +238,19 @@ typedef struct vidc_op {
 } vidc_op;
 
 #define VIDC_MAX_STREAMS 4
+#define VIDC_MAX_SEGMENTS 4
 
 typedef struct vidc_program vidc_program;
 int vidc_program_create(const vidc_op* ops, int n_ops, vidc_program** out);
 int vidc_program_run(vidc_program* p, vidc_stream_t stream);          /* eager: one launch per op            */
 int vidc_program_capture(vidc_program* p, vidc_stream_t stream);      /* records a hipGraph of the program    */
 int vidc_program_launch(vidc_program* p, vidc_stream_t stream);       /* replays the captured graph           */
+/* Segments: ops [begin, end) of one planned program as their own eager run / hipGraph (segment 0..VIDC_MAX_SEGMENTS-1), so the
+ * host can place other launches between parts of a program -- the reference does the same thing implicitly: its plane block
+ * and enrichment loop (main.py:277-294) sit between the two networks of one _call_cnn. */
+int vidc_program_run_range(vidc_program* p, vidc_stream_t stream, int begin, int end);
+int vidc_program_capture_range(vidc_program* p, vidc_stream_t stream, int begin, int end, int segment);
+int vidc_program_launch_segment(vidc_program* p, vidc_stream_t stream, int segment);
 /* Times `iters` back-to-back executions with hipEvents on `stream`; ms_out[0] = average ms per execution,
  * and (if per_op_ms != NULL, eager mode) per-op average durations. */
 int vidc_program_time(vidc_program* p, vidc_stream_t stream, int iters, int use_graph, float* ms_out, float* per_op_ms);

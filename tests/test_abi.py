@@ -99,6 +99,54 @@ def recorded_programs(lib):
     return sn.build_program(1, torch.device("cpu"), dry_run=True), dc.build_program(1, 240, 320, torch.device("cpu"), dry_run=True)
 
 
+@pytest.fixture(scope="module")
+def recorded_frame_program(lib):
+    """The software-pipelined tick program (surface-normal net of frame i+1 + depth-completion net of frame i, four
+    pyramids per grouped launch), recorded on CPU in dry-run mode."""
+    import torch
+    os.environ["VIDC_PRECISION"] = "mixed"
+    from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
+    from vi_depth_completion_amd.networks.surface_normal import SurfaceNormalPrediction
+    from vi_depth_completion_amd.pipeline import build_frame_program
+    sn = SurfaceNormalPrediction(fc_img=np.array([202.0, 202.0])).eval()
+    dc = ModifiedFPN().eval()
+    return build_frame_program(sn, dc, 1, 240, 320, torch.device("cpu"), dry_run=True)
+
+
+def test_frame_program_structure(recorded_frame_program, recorded_programs):
+    """Same convolutions as the two separate programs, but the four pyramids share their launches (4 groups), and the
+    program is cut into two segments at the surface-normal output."""
+    fp = recorded_frame_program
+    sn, dc = recorded_programs
+    kinds = [k for k, _, _, _ in fp.ops]
+    assert kinds.count("stem") == 4 and kinds.count("head") == 2 and kinds.count("maxpool") == 1
+    assert kinds.count("warp_fwd") == 1 and kinds.count("warp_inv") == 1 and kinds.count("upsample") == 12
+    # 105 grouped pyramid convs + 18 surface-normal decoder/head convs + 18 depth-completion ones
+    assert kinds.count("conv") == 105 + 18 + 18
+    pyr = [kw for k, _, _, kw in fp.ops if k == "conv" and len(kw["keys"]) == 4]
+    assert len(pyr) == 105 and all(kw["keys"][0].startswith("sn/resnet_pyramids.") and kw["keys"][3].startswith("dc/resnet_depth.") for kw in pyr)
+    assert fp.flops == sn.flops + dc.flops
+    segs = fp.segments()
+    assert len(segs) == 2 and segs[0][1] == segs[1][0]
+    # segment 0 ends with the inverse warp (the normals the plane block needs); segment 1 holds only depth-completion decoder ops
+    assert fp.ops[segs[0][1] - 1][0] == "warp_inv"
+    for k, _, _, kw in fp.ops[segs[1][0]:]:
+        if k == "conv":
+            assert kw["keys"][0].startswith("dc/feature")
+    # the decoders read channel slices of the 4-group pyramid levels: group 0 -> surface normal, groups 1..3 -> depth completion
+    first_sn = next(kw for k, _, _, kw in fp.ops if k == "conv" and kw["keys"][0] == "sn/feature1_upsamping.0")
+    first_dc = next(kw for k, _, _, kw in fp.ops if k == "conv" and kw["keys"][0] == "dc/feature1_upsamping.0")
+    assert first_sn["geom"][1] == 256 and first_dc["geom"][1] == 768
+    assert first_sn["x"].ch_off == 0 and first_dc["x"].ch_off == 256 and first_sn["x"].ld == first_dc["x"].ld == 1024
+
+
+def test_joint_weight_store_addresses_both_modules(recorded_frame_program):
+    ws = recorded_frame_program.ws
+    assert tuple(ws.raw("sn/resnet_pyramids.conv1.conv1_1.weight").shape) == (64, 3, 3, 3)
+    assert tuple(ws.raw("dc/resnet_depth.conv1.conv1_1.weight").shape) == (64, 1, 3, 3)
+    assert tuple(ws.raw("dc/feature_concat.2.weight").shape) == (1, 192, 1, 1)
+
+
 def test_program_recording_matches_reference_op_counts(recorded_programs):
     """125 + 337 convs, 293.88 GFLOP per 320x240 frame (46.29 SN + 247.58 DC)."""
     sn, dc = recorded_programs
@@ -116,10 +164,10 @@ def test_program_recording_matches_reference_op_counts(recorded_programs):
     assert abs(dc_flops / 1e9 - 247.58) < 0.01, dc_flops
 
 
-def test_mixed_precision_program_structure(recorded_programs):
+def test_mixed_precision_program_structure(recorded_programs, recorded_frame_program):
     """bf16x3 convs read a split image that is produced by exactly one preceding split op of the right tensor, and no
     fp32-mode conv reads a split image."""
-    for prog in recorded_programs:
+    for prog in tuple(recorded_programs) + (recorded_frame_program,):
         split_out = {}
         n_bf = 0
         for kind, reads, writes, kw in prog.ops:
@@ -143,9 +191,9 @@ def test_mixed_precision_program_structure(recorded_programs):
     assert big["precision"] == L.PREC_BF16X3
 
 
-def test_program_buffer_reuse_is_safe(recorded_programs):
+def test_program_buffer_reuse_is_safe(recorded_programs, recorded_frame_program):
     """No op may read and write the same storage, and pinned inputs/outputs never alias anything."""
-    for prog in recorded_programs:
+    for prog in tuple(recorded_programs) + (recorded_frame_program,):
         st = prog.storage
         for kind, reads, writes, kw in prog.ops:
             accum = kind in ("conv", "upsample") and kw.get("flags", 0) & (32 if kind == "conv" else 2)

@@ -32,6 +32,9 @@ KEY_SHAPES = [
     ((32, 40), 128, 128, 3, 1, 3, 3),
     ((8, 10), 512, 512, 3, 1, 3, 2),
     ((8, 10), 512, 2048, 1, 1, 3, 3),
+    ((16, 20), 256, 256, 3, 1, 4, 22),     # joint 4-pyramid launch (pipeline.run_stream software pipelining)
+    ((16, 20), 256, 1024, 1, 1, 4, 23),
+    ((16, 20), 1024, 256, 1, 1, 4, 22),
 ]
 
 

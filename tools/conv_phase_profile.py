@@ -50,14 +50,15 @@ def main():
             L.check(lib.vidc_conv2d_bn_act(C.byref(d), st), "conv")
             e1.record()
             torch.cuda.synchronize()
-            t = dbg.cpu().numpy().reshape(-1, 8)
+            t = dbg.cpu().numpy().reshape(-1, 16)
             nb = int((t[:, 7] != 0).sum())
             t = t[:nb]
             start = (t[:, 6] - t[:, 6].min()) / 100.0          # us, 100 MHz clock
             end = (t[:, 7] - t[:, 6].min()) / 100.0
             print("%-22s tile %-8s wgs %4d  event %.1f us | start skew max %.2f us, last end %.2f us | cycles: setup %.0f  issued %.0f  "
-                  "first-data %.0f  loop-done %.0f  end %.0f" % (name, L.TILE_NAMES[tile], nb, e0.elapsed_time(e1) * 1e3, start.max(), end.max(),
-                                                                  t[:, 0].mean(), t[:, 1].mean(), t[:, 2].mean(), t[:, 3].mean(), t[:, 4].mean()))
+                  "first-data %.0f  loop-done %.0f  end %.0f | sub: args %.0f  B-issued %.0f  A-decoded %.0f  affine-loads %.0f" % (name, L.TILE_NAMES[tile], nb, e0.elapsed_time(e1) * 1e3, start.max(), end.max(),
+                                                                  t[:, 0].mean(), t[:, 1].mean(), t[:, 2].mean(), t[:, 3].mean(), t[:, 4].mean(),
+                                                                  t[:, 8].mean(), t[:, 9].mean(), t[:, 10].mean(), t[:, 11].mean()))
 
 
 if __name__ == "__main__":

@@ -15,6 +15,7 @@ WARP_PARAMS = 32
 MAX_HYP = 300
 PLANE_RECORD = 16
 MAX_STREAMS = 4
+MAX_SEGMENTS = 4
 
 # vidc_conv_flags / vidc_up_flags / vidc_op_kind / vidc_conv_tile
 RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM, SPLIT_OUT, NO_F32_OUT = 1, 2, 4, 8, 16, 32, 64, 128
@@ -87,6 +88,9 @@ SIGNATURES = {
     "vidc_program_run": (C.c_int, [_vp, _vp]),
     "vidc_program_capture": (C.c_int, [_vp, _vp]),
     "vidc_program_launch": (C.c_int, [_vp, _vp]),
+    "vidc_program_run_range": (C.c_int, [_vp, _vp, _i, _i]),
+    "vidc_program_capture_range": (C.c_int, [_vp, _vp, _i, _i, _i]),
+    "vidc_program_launch_segment": (C.c_int, [_vp, _vp, _i]),
     "vidc_program_time": (C.c_int, [_vp, _vp, _i, _i, _f32p, _f32p]),
     "vidc_program_destroy": (C.c_int, [_vp]),
 }

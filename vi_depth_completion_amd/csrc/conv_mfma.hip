@@ -159,7 +159,7 @@ conv_igemm_f32(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef VIDC_CONV_TIMING
     // debug build only: per-workgroup phase stamps (shader clock + 100 MHz wall clock) into a.ws
-    long long* dbg = reinterpret_cast<long long*>(a.ws) + (size_t)blockIdx.x * 8;
+    long long* dbg = reinterpret_cast<long long*>(a.ws) + (size_t)blockIdx.x * 16;
     const long long t_begin = __builtin_readcyclecounter();
 #define VIDC_STAMP(k) do { if (threadIdx.x == 0) dbg[k] = __builtin_readcyclecounter() - t_begin; } while (0)
     if (threadIdx.x == 0) dbg[6] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -188,6 +188,7 @@ conv_igemm_f32(const ConvArgs a) {
         tile_n = (int)(v2 - g * a.tiles_n);
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    VIDC_STAMP(8);      // kernel arguments arrived, work item decoded
     const int units = a.ksteps;                                       // K in units of 32 floats
     const int stages_total = (units + WKW - 1) / WKW;
     const int st_begin = (int)fast_div((unsigned)(stages_total * kz), a.dv_splitk);          // stages_total * splitk < 2^31
@@ -245,6 +246,7 @@ conv_igemm_f32(const ConvArgs a) {
         }
     }
 
+    VIDC_STAMP(9);      // weight prologue DMAs issued
     int a_off[A_J];                                      // byte offset of (pixel, tap (0,0), channel csw); may be negative
     unsigned a_taps[A_J];                                // bit t set: tap t = kh*KW+kw of this row reads a real pixel
     const int HoWo = a.Ho * a.Wo;
@@ -275,6 +277,7 @@ conv_igemm_f32(const ConvArgs a) {
         a_taps[j] = ok ? taps : 0u;
         a_off[j] = (((b * a.H + iy0) * a.W + ix0) * a.ldx + csw) * 4;
     }
+    VIDC_STAMP(10);     // activation rows decoded
     // One pipeline stage = A_J + B_J DMA instructions per wave, issued in two halves that the main loop places inside
     // groups of MFMAs (branch-free, so the scheduler can interleave them with the 64-clk MFMA issue slots).
     auto issue_a = [&](int slot) {
@@ -322,6 +325,7 @@ conv_igemm_f32(const ConvArgs a) {
         e_s2[j] = 1.f; e_b2[j] = 0.f;
         if (a.flags & VIDC_AFFINE2) { e_s2[j] = a.scale2[ni]; e_b2[j] = a.shift2[ni]; }
     }
+    VIDC_STAMP(11);     // scale/shift loads issued
     float e_res[TM][TN][16];
     if ((a.flags & VIDC_RESIDUAL) && a.splitk == 1) {    // uniform branch; indices clamped so every load is unconditional
 #pragma unroll

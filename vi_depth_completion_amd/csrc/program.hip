@@ -11,8 +11,8 @@ struct vidc_program {
     hipEvent_t ev[VIDC_MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr;
     int n_streams = 1;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph[VIDC_MAX_SEGMENTS] = {};      // [0] = the whole program (vidc_program_capture) or segment 0
+    hipGraphExec_t exec[VIDC_MAX_SEGMENTS] = {};
     std::vector<hipEvent_t> op_ev;   // per-op timing events (eager timing mode)
 };
 
@@ -63,13 +63,14 @@ int launch_op(const vidc_op& op, hipStream_t st) {
 // Issues every op; ops with stream_id k>0 go to the program's side stream k.  Dependencies across stream ids are
 // expressed by wait_mask (join on everything issued so far on those ids).  Works identically under stream capture,
 // where the event record/wait pairs become graph edges.
-int issue(vidc_program* p, hipStream_t main, bool timing) {
+int issue(vidc_program* p, hipStream_t main, bool timing, size_t begin = 0, size_t end = (size_t)-1) {
+    if (end > p->ops.size()) end = p->ops.size();
     hipStream_t st[VIDC_MAX_STREAMS];
     st[0] = main;
     for (int k = 1; k < VIDC_MAX_STREAMS; ++k) st[k] = p->side[k];
     bool forked[VIDC_MAX_STREAMS] = {true, false, false, false};
     bool dirty[VIDC_MAX_STREAMS] = {false, false, false, false};
-    for (size_t i = 0; i < p->ops.size(); ++i) {
+    for (size_t i = begin; i < end; ++i) {
         const vidc_op& op = p->ops[i];
         const int sid = op.stream_id;
         if (!forked[sid]) {   // side stream joins the main stream's history on first use
@@ -88,7 +89,7 @@ int issue(vidc_program* p, hipStream_t main, bool timing) {
         if (rc != VIDC_OK) return rc;
         dirty[sid] = true;
     }
-    if (timing) VIDC_HIP(hipEventRecord(p->op_ev[p->ops.size()], main));
+    if (timing) VIDC_HIP(hipEventRecord(p->op_ev[end], main));
     for (int k = 1; k < p->n_streams; ++k)   // final join: the caller's stream owns everything afterwards
         if (forked[k] && dirty[k]) {
             VIDC_HIP(hipEventRecord(p->ev[k], st[k]));
@@ -124,26 +125,56 @@ extern "C" int vidc_program_run(vidc_program* p, vidc_stream_t stream) {
     return issue(p, vidc::as_stream(stream), false);
 }
 
-extern "C" int vidc_program_capture(vidc_program* p, vidc_stream_t stream) {
-    VIDC_REQUIRE(p, VIDC_ERR_STATE, "vidc_program_capture: null program");
-    hipStream_t st = vidc::as_stream(stream);
-    VIDC_REQUIRE(st != nullptr, VIDC_ERR_STATE, "vidc_program_capture: needs a non-default stream");
-    if (p->exec) { hipGraphExecDestroy(p->exec); p->exec = nullptr; }
-    if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
+namespace {
+int capture_range(vidc_program* p, hipStream_t st, size_t begin, size_t end, int seg) {
+    if (p->exec[seg]) { hipGraphExecDestroy(p->exec[seg]); p->exec[seg] = nullptr; }
+    if (p->graph[seg]) { hipGraphDestroy(p->graph[seg]); p->graph[seg] = nullptr; }
     VIDC_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc = issue(p, st, false);
+    int rc = issue(p, st, false, begin, end);
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(st, &g);
     if (rc != VIDC_OK) { if (g) hipGraphDestroy(g); return rc; }
     if (e != hipSuccess) { vidc::set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return VIDC_ERR_HIP; }
-    p->graph = g;
-    VIDC_HIP(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+    p->graph[seg] = g;
+    VIDC_HIP(hipGraphInstantiate(&p->exec[seg], p->graph[seg], nullptr, nullptr, 0));
     return VIDC_OK;
+}
+}  // namespace
+
+extern "C" int vidc_program_capture(vidc_program* p, vidc_stream_t stream) {
+    VIDC_REQUIRE(p, VIDC_ERR_STATE, "vidc_program_capture: null program");
+    hipStream_t st = vidc::as_stream(stream);
+    VIDC_REQUIRE(st != nullptr, VIDC_ERR_STATE, "vidc_program_capture: needs a non-default stream");
+    return capture_range(p, st, 0, p->ops.size(), 0);
 }
 
 extern "C" int vidc_program_launch(vidc_program* p, vidc_stream_t stream) {
-    VIDC_REQUIRE(p && p->exec, VIDC_ERR_STATE, "vidc_program_launch: program not captured");
-    VIDC_HIP(hipGraphLaunch(p->exec, vidc::as_stream(stream)));
+    VIDC_REQUIRE(p && p->exec[0], VIDC_ERR_STATE, "vidc_program_launch: program not captured");
+    VIDC_HIP(hipGraphLaunch(p->exec[0], vidc::as_stream(stream)));
+    return VIDC_OK;
+}
+
+// Segments: ops [begin, end) of a program as their own eager run / hipGraph, so the host can interleave other work
+// (the plane block and its device->host read) between parts of one planned program.
+extern "C" int vidc_program_run_range(vidc_program* p, vidc_stream_t stream, int begin, int end) {
+    VIDC_REQUIRE(p, VIDC_ERR_STATE, "vidc_program_run_range: null program");
+    VIDC_REQUIRE(begin >= 0 && begin < end && (size_t)end <= p->ops.size(), VIDC_ERR_SHAPE, "vidc_program_run_range: bad range [%d, %d)", begin, end);
+    return issue(p, vidc::as_stream(stream), false, (size_t)begin, (size_t)end);
+}
+
+extern "C" int vidc_program_capture_range(vidc_program* p, vidc_stream_t stream, int begin, int end, int segment) {
+    VIDC_REQUIRE(p, VIDC_ERR_STATE, "vidc_program_capture_range: null program");
+    VIDC_REQUIRE(begin >= 0 && begin < end && (size_t)end <= p->ops.size(), VIDC_ERR_SHAPE, "vidc_program_capture_range: bad range [%d, %d)", begin, end);
+    VIDC_REQUIRE(segment >= 0 && segment < VIDC_MAX_SEGMENTS, VIDC_ERR_SHAPE, "vidc_program_capture_range: segment %d out of range", segment);
+    hipStream_t st = vidc::as_stream(stream);
+    VIDC_REQUIRE(st != nullptr, VIDC_ERR_STATE, "vidc_program_capture_range: needs a non-default stream");
+    return capture_range(p, st, (size_t)begin, (size_t)end, segment);
+}
+
+extern "C" int vidc_program_launch_segment(vidc_program* p, vidc_stream_t stream, int segment) {
+    VIDC_REQUIRE(p && segment >= 0 && segment < VIDC_MAX_SEGMENTS && p->exec[segment], VIDC_ERR_STATE,
+                 "vidc_program_launch_segment: segment not captured");
+    VIDC_HIP(hipGraphLaunch(p->exec[segment], vidc::as_stream(stream)));
     return VIDC_OK;
 }
 
@@ -194,8 +225,10 @@ extern "C" int vidc_program_time(vidc_program* p, vidc_stream_t stream, int iter
 
 extern "C" int vidc_program_destroy(vidc_program* p) {
     if (!p) return VIDC_OK;
-    if (p->exec) hipGraphExecDestroy(p->exec);
-    if (p->graph) hipGraphDestroy(p->graph);
+    for (int k = 0; k < VIDC_MAX_SEGMENTS; ++k) {
+        if (p->exec[k]) hipGraphExecDestroy(p->exec[k]);
+        if (p->graph[k]) hipGraphDestroy(p->graph[k]);
+    }
     for (int k = 1; k < VIDC_MAX_STREAMS; ++k) if (p->side[k]) hipStreamDestroy(p->side[k]);
     for (int k = 0; k < VIDC_MAX_STREAMS; ++k) if (p->ev[k]) hipEventDestroy(p->ev[k]);
     if (p->fork_ev) hipEventDestroy(p->fork_ev);

@@ -106,6 +106,22 @@ class WeightStore:
         return self._cache[ck]
 
 
+class JointWeightStore(WeightStore):
+    """Derived parameters of several modules behind one key space: key "name/param" resolves to `modules[name]`'s
+    state_dict entry "param".  Lets one Program (one grouped launch per layer) span networks -- the software-pipelined
+    frame program of pipeline.InterleavedPrograms runs the surface-normal pyramid of frame i+1 and the three
+    depth-completion pyramids of frame i as four groups of the same launches."""
+
+    def __init__(self, modules):
+        super().__init__(None)
+        self.modules = dict(modules)
+
+    def sd(self):
+        if self._sd is None:
+            self._sd = {"%s/%s" % (name, k): v.detach() for name, m in self.modules.items() for k, v in m.state_dict().items()}
+        return self._sd
+
+
 _TUNING = None
 
 
@@ -148,7 +164,9 @@ class Program:
         self.handle = None
         self.flops = 0           # executed conv FLOPs (2*M*N*K summed)
         self._keep = []
-        self._split_cache = {}   # (buf, ch_off, channels) -> T of the split-bf16 image
+        self._split_cache = {}   # (buf, ch_off, channels) -> buffer id of the split-bf16 image
+        self.cuts = []           # op indices where a new segment starts (see cut()); filled by finalize()
+        self._cut_markers = []
         self.mode = precision_mode()
 
     # ---- buffers ----------------------------------------------------------------------------------------
@@ -174,6 +192,12 @@ class Program:
 
     def nhwc(self, H, W, Cc, G=1):
         return T(self._new_buf(self.B * H * W * G * Cc), self.B, H, W, Cc, G)
+
+    def cut(self):
+        """Starts a new segment: the ops recorded so far and the ops that follow can be captured / launched separately
+        (capture_segments / launch_segment), with host-enqueued work in between."""
+        assert self.ops, "cut() before the first op"
+        self._cut_markers.append(self.ops[-1])      # identity of the last op of the segment (op indices shift in _fuse_splits)
 
     def on_stream(self, sid, wait_mask=0):
         self.stream_id, self.wait_mask = sid, wait_mask
@@ -222,11 +246,17 @@ class Program:
         ck = (x.buf, x.ch_off, x.C * x.G)
         if ck not in self._split_cache:
             assert not x.nchw and (x.C * x.G) % 32 == 0
+            # a channel slice of a tensor whose split image exists is a slice of that image: the split layout keeps every
+            # 32-channel unit in place ([32 x hi | 32 x lo] = the same 128 bytes), so only ch_off (a multiple of 32) moves
+            for (b0, off0, ch0), (sbuf, ld0) in self._split_cache.items():
+                if b0 == x.buf and off0 <= x.ch_off and x.ch_off + x.C * x.G <= off0 + ch0 and (x.ch_off - off0) % 32 == 0 and ld0 == ch0:
+                    return T(sbuf, x.B, x.H, x.W, x.C, x.G, ld=ld0, ch_off=x.ch_off - off0)
             y = T(self._new_buf(self.B * x.H * x.W * x.C * x.G), x.B, x.H, x.W, x.C, x.G)
             self._emit("split", [x], [y], x=x, y=y)
-            self._split_cache[ck] = y.buf
+            self._split_cache[ck] = (y.buf, x.C * x.G)
         # same storage, the caller's view of it (grouped and channel-concatenated views share one split image)
-        return T(self._split_cache[ck], x.B, x.H, x.W, x.C, x.G)
+        sbuf, ld0 = self._split_cache[ck]
+        return T(sbuf, x.B, x.H, x.W, x.C, x.G, ld=ld0)
 
     def stem_conv(self, xs, key, relu=True, x_is_nchw=True):
         """xs: one NCHW tensor or a list (one per group, Cin may differ: 3,3,1)."""
@@ -358,6 +388,8 @@ class Program:
         lib = L.lib()
         if os.environ.get("VIDC_FUSE_SPLIT", "1") == "1":
             self._fuse_splits()
+        self.cuts = [next(i for i, op in enumerate(self.ops) if op is mk) + 1 for mk in self._cut_markers]
+        assert len(self.cuts) < L.MAX_SEGMENTS and self.cuts == sorted(set(self.cuts))
         storage = self._plan_buffers()
         self.storage = storage
         self.bytes_allocated = sum({t.data_ptr(): t.numel() * 4 for t in storage if t is not None}.values())
@@ -513,6 +545,24 @@ class Program:
     def capture(self, stream=None):
         L.check(L.lib().vidc_program_capture(self.handle, stream if stream is not None else L.current_stream()), "program_capture")
         self.captured = True
+
+    def segments(self):
+        """[(begin, end)] op ranges separated by cut()."""
+        edges = [0] + list(self.cuts) + [len(self.ops)]
+        return [(edges[i], edges[i + 1]) for i in range(len(edges) - 1)]
+
+    def run_segment(self, k, stream=None):
+        b, e = self.segments()[k]
+        L.check(L.lib().vidc_program_run_range(self.handle, stream if stream is not None else L.current_stream(), b, e), "program_run_range")
+
+    def capture_segments(self, stream=None):
+        st = stream if stream is not None else L.current_stream()
+        for k, (b, e) in enumerate(self.segments()):
+            L.check(L.lib().vidc_program_capture_range(self.handle, st, b, e, k), "program_capture_range")
+        self.captured = True
+
+    def launch_segment(self, k, stream=None):
+        L.check(L.lib().vidc_program_launch_segment(self.handle, stream if stream is not None else L.current_stream(), k), "program_launch_segment")
 
     def launch(self, stream=None):
         L.check(L.lib().vidc_program_launch(self.handle, stream if stream is not None else L.current_stream()), "program_launch")

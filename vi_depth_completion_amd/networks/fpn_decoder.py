@@ -62,15 +62,16 @@ def emit_branch(prog, seq, prefix, x, level_sizes, zsum):
     return t
 
 
-def emit_decoder(prog, module, levels):
-    """levels: [x1..x4] program tensors (possibly grouped = channel-concatenated).  Returns z1+z2+z3+z4."""
+def emit_decoder(prog, module, levels, key_prefix=""):
+    """levels: [x1..x4] program tensors (possibly grouped = channel-concatenated).  Returns z1+z2+z3+z4.
+    key_prefix: prepended to the parameter names (a Program over an engine.JointWeightStore addresses "name/param")."""
     from ..engine import T
     flat = [T(t.buf, t.B, t.H, t.W, t.C * t.G, 1, t.ld, t.ch_off) for t in levels]   # concat view: groups -> channels
     sizes = {i + 1: (t.H, t.W) for i, t in enumerate(flat)}
     zsum = None
     for b in (1, 2, 3, 4):
         seq = getattr(module, "feature%d_upsamping" % b)
-        z = emit_branch(prog, seq, "feature%d_upsamping." % b, flat[b - 1], sizes, zsum)
+        z = emit_branch(prog, seq, "%sfeature%d_upsamping." % (key_prefix, b), flat[b - 1], sizes, zsum)
         if zsum is None:
             zsum = z
     return zsum

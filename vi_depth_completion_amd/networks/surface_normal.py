@@ -20,11 +20,13 @@ class _HipModule(nn.Module):
     def _init_engine(self):
         self._weights = engine.WeightStore(self)
         self._programs = {}
+        self._version = 0          # bumped whenever the parameters may have changed (programs spanning modules key on it)
         self.register_load_state_dict_post_hook(lambda m, keys: m._invalidate())
 
     def _invalidate(self):
         self._weights.invalidate()
         self._programs.clear()
+        self._version += 1
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)

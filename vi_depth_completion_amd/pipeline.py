@@ -26,6 +26,52 @@ class FixedPlaneMask:
         return self.id_map
 
 
+def build_frame_program(sn, dc, B, H, W, device, dry_run=False):
+    """ONE planned program for a pipeline tick: the surface-normal network of frame i+1 and the depth-completion
+    network of frame i.  Their four ResNet-101 pyramids have identical layer shapes, so each pyramid layer is one
+    grouped launch over (sn, dc.rgb, dc.normal, dc.depth) instead of a 1-group and a 3-group launch -- at batch 1
+    these ~210 launches are latency-bound, not throughput-bound, so the 1-group ones are almost free riders.
+    Segment 0 = warp + pyramids + surface-normal decoder + inverse warp; segment 1 = depth-completion decoder (the
+    host enqueues the plane block of frame i+1 between them and reads its counts back while segment 1 runs)."""
+    from . import engine
+    from .engine import T
+    from .networks.fpn_decoder import emit_decoder
+    wp = sn.warp_2dof_alignment
+    assert (wp.H, wp.W) == (H, W), "frame size %dx%d does not match the warp intrinsics (%dx%d)" % (W, H, wp.W, wp.H)
+    ws = engine.JointWeightStore({"sn": sn, "dc": dc})
+    prog = engine.Program(ws, device, B)
+    x = prog.input_nchw("sn_image", 3, H, W)
+    g = prog.input_raw("gravity", B * 3)
+    a = prog.input_raw("aligned", B * 3)
+    kinv = prog.input_raw("kinv", 9)
+    img = prog.input_nchw("dc_image", 3, H, W)
+    nrm = prog.input_nchw("dc_normal", 3, H, W)
+    dep = prog.input_nchw("dc_depth", 1, H, W)
+    params = prog.warp_params(g, a, wp, kinv)
+    xw = prog.warp_fwd(x, params, wp, wp.align_corners)
+    levels = sn.resnet_pyramids.emit(prog, [xw, img, nrm, dep],
+                                     engine.K(("sn/resnet_pyramids.", "dc/resnet_rgb.", "dc/resnet_normal.", "dc/resnet_depth.")))
+    if prog.mode == "mixed":
+        for t in levels:             # ONE split image per level, written by the producing conv's epilogue; the next pyramid
+            prog.split(t)            # stage and both decoders read (channel slices of) it
+    sn_levels = [T(t.buf, t.B, t.H, t.W, t.C, 1, t.ld, t.ch_off) for t in levels]
+    dc_levels = [T(t.buf, t.B, t.H, t.W, 3 * t.C, 1, t.ld, t.ch_off + t.C) for t in levels]
+    zs = emit_decoder(prog, sn, sn_levels, "sn/")
+    h = prog.conv(zs, "sn/feature_concat.0", relu=True, padding=1)
+    y, _low = prog.head(h, "sn/feature_concat.2", 0, (H, W), relu=False)
+    z = prog.warp_inv(y, params, wp, wp.align_corners, normalize=True)
+    prog.mark_output("normals", z)
+    prog.cut()
+    zd = emit_decoder(prog, dc, dc_levels, "dc/")
+    h = prog.conv(zd, "dc/feature_concat.0", relu=True, padding=1)
+    yd, _low = prog.head(h, "dc/feature_concat.2", 1, (H, W), relu=True)
+    prog.mark_output("depth", yd)
+    prog.finalize(dry_run)
+    if not dry_run:
+        prog.storage[kinv.buf][:9].copy_(wp.kinv(device))
+    return prog
+
+
 class DepthCompletionPipeline:
     def __init__(self, enriched_samples=200, fc_img=(202.0, 202.0), cc_img=(0.5 * 319.87654, 0.5 * 239.87603),
                  align_corners=False, device="cuda", network_class_creator=ModifiedFPN, rng=np.random):
@@ -99,6 +145,75 @@ class DepthCompletionPipeline:
             if st["di"] is not None:
                 taps.update(plane_depth=st["di"], enriched=st["enriched"], records=self.planes.last_records)
         return out
+
+    # ---- software-pipelined throughput mode ------------------------------------------------------------------------
+    def frame_program(self, B, H, W):
+        key = (B, H, W, self.surface_normal_cnn._version, self.cnn._version, self.surface_normal_cnn.warp_2dof_alignment.align_corners)
+        if getattr(self, "_frame_prog_key", None) != key:
+            self._frame_prog = build_frame_program(self.surface_normal_cnn, self.cnn, B, H, W, self.device)
+            self._frame_prog_key = key
+        return self._frame_prog
+
+    @torch.no_grad()
+    def run_interleaved(self, batches):
+        """Throughput mode, software-pipelined over frames: tick t runs the surface-normal network + plane block of frame
+        t and the depth-completion network of frame t-1 as ONE program (build_frame_program).  Yields the depth map of
+        every batch, in order; n batches take n+1 ticks.  Per frame the arithmetic is that of `_call_cnn` (same kernels;
+        the 4-group launches may use another tile than the 1-/3-group ones, i.e. fp32 sums in a different order), and the
+        RANSAC / enrichment draws come off `self.rng` in the same order as back-to-back `_call_cnn` calls."""
+        import itertools
+        import os
+        dev = self.device
+        prog = None
+        prev = None            # frame waiting for its depth network: dict(rgb, enriched)
+        for batch in itertools.chain(batches, [None]):
+            cur = None
+            if batch is not None:
+                rgb = batch["image"].to(dev, non_blocking=True)
+                ds = batch["sparse_depth"].to(dev, non_blocking=True)
+                B, _, H, W = rgb.shape
+                if prog is None:
+                    prog = self.frame_program(B, H, W)
+                    self.surface_normal_cnn._check(rgb)
+                    self.cnn._check(rgb)
+                    if not prog.captured and os.environ.get("VIDC_EXEC", "graph") == "graph":
+                        side = torch.cuda.Stream()
+                        side.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(side):
+                            prog.run()            # warm-up outside capture (sets kernel attributes)
+                            prog.capture_segments()
+                        torch.cuda.current_stream().wait_stream(side)
+            elif prog is None:
+                return
+            graph = prog.captured
+            if prev is not None:      # inputs of frame t-1's depth network; `normals` still holds frame t-1's output here
+                prog.tensor(prog.inputs["dc_image"]).copy_(prev["rgb"], non_blocking=True)
+                prog.tensor(prog.inputs["dc_normal"]).copy_(prog.tensor(prog.outputs["normals"]), non_blocking=True)
+                prog.tensor(prog.inputs["dc_depth"]).copy_(prev["depth_in"], non_blocking=True)
+            if batch is not None:
+                prog.tensor(prog.inputs["sn_image"]).copy_(rgb, non_blocking=True)
+                prog.storage[prog.inputs["gravity"].buf][: B * 3].copy_(batch["gravity"].to(dev).reshape(-1), non_blocking=True)
+                prog.storage[prog.inputs["aligned"].buf][: B * 3].copy_(batch["aligned_direction"].to(dev).reshape(-1), non_blocking=True)
+                prog.launch_segment(0) if graph else prog.run_segment(0)
+                normals = prog.tensor(prog.outputs["normals"])
+                cur = {"rgb": rgb, "depth_in": ds}
+                pending = None
+                if self.args.enriched_samples != 0:
+                    homo = batch["homogeneous_coordinates"].to(dev, non_blocking=True)
+                    masks = [np.asarray(self.plane_masks_extraction.run_on_tensor(batch["image"][i])).reshape(H, W) for i in range(B)]
+                    di, info = self.planes.plane_depth(normals, masks, ds, homo, rng=self.rng)
+                    pending = (di, info, self.planes.read_info_async(info))
+            elif prev is not None:
+                # drain tick: no new frame; the pyramids still run 4 groups (group 0 recomputes the last frame's features)
+                prog.launch_segment(0) if graph else prog.run_segment(0)
+            if prev is not None:
+                prog.launch_segment(1) if graph else prog.run_segment(1)
+            if batch is not None and pending is not None:
+                di, info, info_host = pending       # the host waits for the counts while segment 1 keeps the GPU busy
+                cur["depth_in"] = self.planes.enrich(ds, di, info, self.args.enriched_samples, rng=self.rng, info_host=info_host)
+            if prev is not None:
+                yield prog.tensor(prog.outputs["depth"]).clone()
+            prev = cur
 
     @torch.no_grad()
     def run_stream(self, batches, in_flight=2, frame_rng=None):

@@ -106,13 +106,28 @@ class PlaneBlock:
         L.check(lib.vidc_plane_finalize(L.ptr(ds), L.ptr(di), B, HW, L.ptr(rec), n_slots, L.ptr(info), st), "plane_finalize")
         return di.view(B, 1, H, W), info
 
-    def enrich(self, sparse_depth, di, info, goal, rng=np.random):
+    def read_info_async(self, info):
+        """Starts the device->host read of `info` on the current stream; returns (pinned host tensor, event).  Work enqueued
+        after this call does not delay the read: `enrich(..., info_host=...)` waits for the event only."""
+        if getattr(self, "_info_pinned", None) is None or self._info_pinned.numel() != info.numel():
+            self._info_pinned = torch.empty(info.numel(), dtype=torch.int32, pin_memory=True)
+            self._info_event = torch.cuda.Event()
+        self._info_pinned.copy_(info, non_blocking=True)
+        self._info_event.record()
+        return self._info_pinned, self._info_event
+
+    def enrich(self, sparse_depth, di, info, goal, rng=np.random, info_host=None):
         """main.py:285-294.  One device->host read (the reference syncs on torch.nonzero here): per-chunk candidate counts
         + the flag for planes that would need the >300-point host permutation (main.py:78), which is not done on device."""
         lib, st = L.lib(), L.current_stream()
         B, _, H, W = sparse_depth.shape
         dev = sparse_depth.device
-        info_h = info.cpu().numpy()
+        if info_host is not None:
+            pinned, ev = info_host
+            ev.synchronize()
+            info_h = pinned.numpy().copy()
+        else:
+            info_h = info.cpu().numpy()
         if info_h[-1] != 0:
             raise NotImplementedError("a plane has more than %d sparse depth points; the subsampled plane-offset RANSAC "
                                       "(main.py:78) is not implemented on device" % L.MAX_HYP)
