@@ -138,15 +138,19 @@ int vidc_conv2d_plan(vidc_conv_desc* d);
 /* Stem conv 3x3 stride 2 pad 1, Cin in {1,3}, no BN, optional ReLU (conv1_1, surface_normal.py:17-18).
  * x: NCHW [B][Cin][H][W] -> y: NHWC [B][Ho][Wo][ldy].  w: OIHW as in the checkpoint. */
 int vidc_stem_conv3x3s2(const float* x, const float* w_oihw, float* y, int B, int Cin, int H, int W, int Cout, int ldy,
-                        int relu, vidc_stream_t stream);
+                        int relu, void* y_split, int split_ch0, vidc_stream_t stream);
 
 /* nn.MaxPool2d(3, 2, 1) on NHWC (surface_normal.py:44). */
-int vidc_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, vidc_stream_t stream);
+int vidc_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, void* y_split, vidc_stream_t stream);
 
-enum vidc_up_flags { VIDC_UP_RELU = 1, VIDC_UP_ACCUM = 2 };
+enum vidc_up_flags { VIDC_UP_RELU = 1, VIDC_UP_ACCUM = 2, VIDC_UP_NO_F32_OUT = 4 };
 /* nn.UpsamplingBilinear2d(size) == bilinear, align_corners=True, on NHWC (surface_normal.py:88 ...). */
 int vidc_upsample_bilinear_ac(const float* x, float* y, int B, int h, int w, int C, int ldx, int H, int W, int ldy,
-                              int flags, vidc_stream_t stream);
+                              int flags, void* y_split, vidc_stream_t stream);
+/* y_split (stem / maxpool / upsample; may be NULL): additionally write the result as the split-bf16 image that the bf16x3
+ * convs read (layout: vidc_split_bf16x3), with the same row stride ldy (a multiple of 32) -- saves the separate split
+ * launch.  maxpool / stem: y may then be NULL (no fp32 copy); upsample: VIDC_UP_NO_F32_OUT.  stem: y_split is the image of
+ * the whole [.., ldy] tensor and split_ch0 the first channel this launch writes (y itself points at that channel). */
 
 /* Prediction head tail: 1x1 conv Cin -> Cout (Cout <= 4) with zero padding `pad` (the reference's
  * Conv2d(192,1,1,1,1), depth_completion.py:144, pads a 1x1 conv -> 62x82 map whose border equals the bias),

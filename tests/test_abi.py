@@ -125,7 +125,7 @@ def test_frame_program_structure(recorded_frame_program, recorded_programs):
     assert kinds.count("conv") == 105 + 18 + 18
     pyr = [kw for k, _, _, kw in fp.ops if k == "conv" and len(kw["keys"]) == 4]
     assert len(pyr) == 105 and all(kw["keys"][0].startswith("sn/resnet_pyramids.") and kw["keys"][3].startswith("dc/resnet_depth.") for kw in pyr)
-    assert fp.flops == sn.flops + dc.flops
+    assert fp.flops == sn.flops + dc.flops and fp.ref_flops == sn.ref_flops + dc.ref_flops
     segs = fp.segments()
     assert len(segs) == 2 and segs[0][1] == segs[1][0]
     # segment 0 ends with the inverse warp (the normals the plane block needs); segment 1 holds only depth-completion decoder ops
@@ -158,10 +158,14 @@ def test_program_recording_matches_reference_op_counts(recorded_programs):
     assert kinds(dc).count("stem") == 3 and kinds(dc).count("conv") == 123 and kinds(dc).count("head") == 1
     stem = lambda cin: 2 * 120 * 160 * 64 * cin * 9
     head = lambda cin, co, h, w: 2 * h * w * cin * co
-    sn_flops = sn.flops + stem(3) + head(64, 3, 60, 80)
-    dc_flops = dc.flops + 2 * stem(3) + stem(1) + head(192, 1, 60, 80)
+    sn_flops = sn.ref_flops + stem(3) + head(64, 3, 60, 80)
+    dc_flops = dc.ref_flops + 2 * stem(3) + stem(1) + head(192, 1, 60, 80)
     assert abs(sn_flops / 1e9 - 46.29) < 0.01, sn_flops
     assert abs(dc_flops / 1e9 - 247.58) < 0.01, dc_flops
+    # executed: the six 1x1 convs per network that follow an upsample in the reference run BEFORE it here (4x fewer MACs each)
+    assert sn.flops < sn.ref_flops and dc.flops < dc.ref_flops
+    # five of them 4x (30x40->60x80, 15x20->30x40), one 3.75x (8x10 -> 15x20), each 2.8312 GFLOP in the reference formulation
+    assert abs((dc.ref_flops - dc.flops) / 1e9 - 2.8312 * (5 * 0.75 + (1 - 80 / 300.0))) < 0.01
 
 
 def test_mixed_precision_program_structure(recorded_programs, recorded_frame_program):
@@ -183,8 +187,12 @@ def test_mixed_precision_program_structure(recorded_programs, recorded_frame_pro
                 if kw.get("split_out") is not None:               # split fused into this conv's epilogue
                     split_out[kw["split_out"].buf] = kw["y"].buf
                     assert kw["flags"] & L.SPLIT_OUT
+            elif kind in ("stem", "maxpool", "upsample") and kw.get("split_out") is not None:   # ... or into a glue kernel
+                split_out[kw["split_out"].buf] = kw["y"].buf
         assert n_bf >= 3 and len(split_out) <= n_bf
         assert prog.n_fused_splits >= 1
+        # every split is written by its producer: no standalone split launch is left in these programs
+        assert sum(1 for kind, _, _, _ in prog.ops if kind == "split") == 0
     # the 54-GFLOP-class layer (dc.feature1_upsamping.0) must be on the fast path
     dc = recorded_programs[1]
     big = [kw for kind, _, _, kw in dc.ops if kind == "conv" and kw["keys"][0] == "feature1_upsamping.0"][0]

@@ -294,6 +294,68 @@ def test_upsample(sizes):
     assert (nchw(acc).cpu() - (base + F.relu(ref))).abs().max() < 2e-5
 
 
+def test_glue_kernels_write_split_images():
+    """stem / max-pool / upsample can write the split-bf16 image of their result themselves (saves the split launch in
+    front of a bf16x3 conv): bit-identical to vidc_split_bf16x3 of the fp32 result, also when the fp32 store is skipped."""
+    from vi_depth_completion_amd import ops
+    # stem: 64 output channels = two 32-channel units
+    x = S.normal01(2, "stem.x", (2, 3, 30, 40)).float().to(DEV)
+    w = S.normal01(2, "stem.w", (64, 3, 3, 3), scale=0.3).float().to(DEV)
+    y0 = ops.stem_conv3x3s2(x, w, relu=True)
+    sp = torch.zeros_like(y0)
+    y1 = ops.stem_conv3x3s2(x, w, relu=True, split_out=sp)
+    assert torch.equal(y0, y1) and torch.equal(sp.view(torch.int32), ops.split_bf16x3(y0).view(torch.int32))
+    # max-pool
+    x = nhwc(S.normal01(4, "mp.x", (2, 128, 14, 18)).float()).to(DEV)
+    y0 = ops.maxpool3x3s2(x)
+    sp = torch.zeros_like(y0)
+    y1 = ops.maxpool3x3s2(x, split_out=sp)
+    assert torch.equal(y0, y1) and torch.equal(sp.view(torch.int32), ops.split_bf16x3(y0).view(torch.int32))
+    # upsample (+ReLU), with and without the fp32 copy, and accumulating
+    x = nhwc(S.normal01(6, "up.x", (2, 96, 8, 10)).float()).to(DEV)
+    y0 = ops.upsample_bilinear_ac(x, (16, 20), relu=True)
+    sp = torch.zeros_like(y0)
+    y1 = ops.upsample_bilinear_ac(x, (16, 20), relu=True, split_out=sp)
+    want = ops.split_bf16x3(y0).view(torch.int32)
+    assert torch.equal(y0, y1) and torch.equal(sp.view(torch.int32), want)
+    sp2 = torch.zeros_like(y0)
+    junk = torch.full_like(y0, 7.0)
+    ops.upsample_bilinear_ac(x, (16, 20), relu=True, split_out=sp2, store_f32=False, accumulate_into=None)
+    assert torch.equal(sp2.view(torch.int32), want)
+    acc = nhwc(S.normal01(6, "up.base", (2, 96, 16, 20)).float()).to(DEV)
+    want_acc = acc + y0
+    sp3 = torch.zeros_like(y0)
+    ops.upsample_bilinear_ac(x, (16, 20), relu=True, accumulate_into=acc, split_out=sp3)
+    assert torch.equal(acc, want_acc) and torch.equal(sp3.view(torch.int32), ops.split_bf16x3(want_acc).view(torch.int32))
+    del junk
+
+
+def test_decoder_upsample_commute_is_exact_enough(seeded_weights):
+    """The decoders run UpsamplingBilinear2d -> Conv1x1 -> BN -> ReLU as Conv1x1+BN (low-res) -> upsample -> ReLU.  Both
+    orders on the GPU (commute on/off, same weights and inputs) must agree to the rounding of the arithmetic mode: max
+    |diff| 3e-4 and RMSE 3e-5 on metre-scale depth (the bf16x3 mode itself sits at RMSE ~1.4e-5 vs fp32)."""
+    import importlib
+    from vi_depth_completion_amd.networks import fpn_decoder
+    from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
+    batch = S.synthetic_batch(1, 240, 320, 1234, frame0=2)
+    img = batch["image"].to(DEV)
+    nrm = F.normalize(S.normal01(9, "cm.n", (1, 3, 240, 320)).float(), dim=1).to(DEV)
+    dep = batch["sparse_depth"].to(DEV)
+    outs = []
+    saved = fpn_decoder.COMMUTE_UPSAMPLE
+    try:
+        for flag in (True, False):
+            fpn_decoder.COMMUTE_UPSAMPLE = flag
+            dc = ModifiedFPN().to(DEV).eval()
+            dc.load_state_dict(seeded_weights["dc"])
+            outs.append(dc(img, nrm, dep).cpu())
+            del dc
+    finally:
+        fpn_decoder.COMMUTE_UPSAMPLE = saved
+    d = outs[0] - outs[1]
+    assert d.abs().max() < 3e-4 and d.pow(2).mean().sqrt() < 3e-5, (d.abs().max(), d.pow(2).mean().sqrt())
+
+
 @pytest.mark.parametrize("cfg", [(64, 3, 0, False), (192, 1, 1, True)])
 def test_head(cfg):
     from vi_depth_completion_amd import ops

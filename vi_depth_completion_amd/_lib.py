@@ -19,7 +19,7 @@ MAX_SEGMENTS = 4
 
 # vidc_conv_flags / vidc_up_flags / vidc_op_kind / vidc_conv_tile
 RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM, SPLIT_OUT, NO_F32_OUT = 1, 2, 4, 8, 16, 32, 64, 128
-UP_RELU, UP_ACCUM = 1, 2
+UP_RELU, UP_ACCUM, UP_NO_F32_OUT = 1, 2, 4
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY, OP_SPLIT = range(1, 11)
 TILE_AUTO = 0
 TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "64x64k2", 6: "32x64k2", 7: "32x32k4", 8: "32x128",
@@ -73,9 +73,9 @@ SIGNATURES = {
     "vidc_conv2d_bn_act": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "vidc_conv2d_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "vidc_conv2d_plan": (C.c_int, [C.POINTER(ConvDesc)]),
-    "vidc_stem_conv3x3s2": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "vidc_maxpool3x3s2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "vidc_upsample_bilinear_ac": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vidc_stem_conv3x3s2": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "vidc_maxpool3x3s2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "vidc_upsample_bilinear_ac": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vidc_head_conv1x1_upsample": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_plane_scratch_bytes": (C.c_size_t, [_i, _i, _i]),
     "vidc_plane_ransac_normal": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),

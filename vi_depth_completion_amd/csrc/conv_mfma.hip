@@ -66,25 +66,9 @@ __device__ inline float epilogue(float v, int n, size_t off_r, size_t off_y, con
     return v;
 }
 
-// ---- bf16 split helpers ------------------------------------------------------------------------------------------------
-__device__ inline unsigned short bf16_rne(float x) {          // round-to-nearest-even, like torch's .to(bfloat16) (no NaN inputs here)
-    unsigned u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ inline void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
-    hi = bf16_rne(x);
-    lo = bf16_rne(x - __uint_as_float((unsigned)hi << 16));
-}
-
-// Writes the split-bf16 image element (m, n) of a tensor with `ld` channels per row: unit n/32 = [32 x hi | 32 x lo].
-__device__ inline void store_split(unsigned short* img, size_t m, int ld, int n, float v) {
-    unsigned short hi, lo;
-    split_bf16(v, hi, lo);
-    unsigned short* u = img + (m * ld + (n & ~31)) * 2 + (n & 31);
-    u[0] = hi;
-    u[32] = lo;
-}
+using vidc::bf16_rne;
+using vidc::split_bf16;
+using vidc::store_split;
 
 // Zero source for LDS-DMA lanes whose row is padding (conv halo, M tail, Cout tail, K tail).
 __device__ float g_zero_chunk[64] = {0};

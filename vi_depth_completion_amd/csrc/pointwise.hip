@@ -11,7 +11,7 @@ namespace {
 template <int CIN>
 __global__ void __launch_bounds__(256)
 stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int H, int W, int Ho, int Wo,
-                 int Cout, int ldy, int relu) {
+                 int Cout, int ldy, int relu, unsigned short* __restrict__ ysp, int ch0) {
     constexpr int PIX = 64;                 // output pixels per workgroup (along X)
     constexpr int PW = 2 * PIX + 1;         // input patch width
     __shared__ float patch[CIN][3][PW + 3];
@@ -47,14 +47,17 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
 #pragma unroll
                     for (int s = 0; s < 3; ++s) acc += patch[c][r][2 * p + s] * wr[(c * 3 + r) * 3 + s];
             if (relu) acc = fmaxf(acc, 0.f);
-            y[((size_t)(b * Ho + oy) * Wo + ox) * ldy + c_out] = acc;
+            const size_t row = (size_t)(b * Ho + oy) * Wo + ox;
+            if (y) y[row * ldy + c_out] = acc;
+            if (ysp) vidc::store_split(ysp, row, ldy, ch0 + c_out, acc);      // ysp is the image of the whole [.., ldy] tensor
         }
     }
 }
 
 // ---- max-pool 3x3 stride 2 pad 1, NHWC -----------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int ldx, int Ho, int Wo, int ldy) {
+maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int ldx, int Ho, int Wo, int ldy,
+               unsigned short* __restrict__ ysp) {
     const int q = C / 4;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)B * Ho * Wo * q;
@@ -77,7 +80,9 @@ maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H,
             m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
         }
     }
-    *reinterpret_cast<float4*>(&y[((size_t)(b * Ho + oy) * Wo + ox) * ldy + c]) = m;
+    const size_t row = (size_t)(b * Ho + oy) * Wo + ox;
+    if (y) *reinterpret_cast<float4*>(&y[row * ldy + c]) = m;
+    if (ysp) vidc::store_split4(ysp, row, ldy, c, m);
 }
 
 // ---- bilinear upsample, align_corners=True (nn.UpsamplingBilinear2d), NHWC ---------------------------------------
@@ -93,7 +98,7 @@ __device__ inline void src_index(int dst, int in, int out, int& i0, int& i1, flo
 
 __global__ void __launch_bounds__(256)
 upsample_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int h, int w, int C, int ldx, int H, int W, int ldy,
-                int flags) {
+                int flags, unsigned short* __restrict__ ysp) {
     const int q = C / 4;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)B * H * W * q;
@@ -118,9 +123,11 @@ upsample_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int h
     o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
     o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
     if (flags & VIDC_UP_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    float4* dst = reinterpret_cast<float4*>(&y[((size_t)(b * H + oy) * W + ox) * ldy + c]);
+    const size_t row = (size_t)(b * H + oy) * W + ox;
+    float4* dst = reinterpret_cast<float4*>(&y[row * ldy + c]);
     if (flags & VIDC_UP_ACCUM) { float4 p = *dst; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-    *dst = o;
+    if (!(flags & VIDC_UP_NO_F32_OUT)) *dst = o;
+    if (ysp) vidc::store_split4(ysp, row, ldy, c, o);
 }
 
 // ---- head: 1x1 conv to <=4 channels with zero padding, one wavefront per low-res pixel ------------------------------
@@ -171,40 +178,46 @@ head_upsample_kernel(const float* __restrict__ low, float* __restrict__ y, int B
 }  // namespace
 
 extern "C" int vidc_stem_conv3x3s2(const float* x, const float* w_oihw, float* y, int B, int Cin, int H, int W, int Cout, int ldy,
-                                   int relu, vidc_stream_t stream) {
-    VIDC_REQUIRE(x && w_oihw && y, VIDC_ERR_NULL, "vidc_stem_conv3x3s2: null pointer");
+                                   int relu, void* y_split, int split_ch0, vidc_stream_t stream) {
+    VIDC_REQUIRE(x && w_oihw && (y || y_split), VIDC_ERR_NULL, "vidc_stem_conv3x3s2: null pointer");
+    VIDC_REQUIRE(!y_split || (ldy % 32 == 0 && split_ch0 >= 0), VIDC_ERR_SHAPE, "vidc_stem_conv3x3s2: split output needs ldy % 32 == 0");
+    unsigned short* ysp = reinterpret_cast<unsigned short*>(y_split);
     VIDC_REQUIRE((Cin == 1 || Cin == 3) && B > 0 && H > 2 && W > 2 && Cout > 0 && ldy >= Cout, VIDC_ERR_SHAPE,
                  "vidc_stem_conv3x3s2: unsupported shape (Cin=%d must be 1 or 3)", Cin);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     dim3 grid(vidc::cdiv(Wo, 64), Ho, B);
     if (Cin == 3)
-        hipLaunchKernelGGL(stem_conv_kernel<3>, grid, dim3(256), 0, vidc::as_stream(stream), x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu);
+        hipLaunchKernelGGL(stem_conv_kernel<3>, grid, dim3(256), 0, vidc::as_stream(stream), x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0);
     else
-        hipLaunchKernelGGL(stem_conv_kernel<1>, grid, dim3(256), 0, vidc::as_stream(stream), x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu);
+        hipLaunchKernelGGL(stem_conv_kernel<1>, grid, dim3(256), 0, vidc::as_stream(stream), x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0);
     VIDC_CHECK_LAUNCH("stem_conv_kernel");
     return VIDC_OK;
 }
 
-extern "C" int vidc_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, vidc_stream_t stream) {
-    VIDC_REQUIRE(x && y, VIDC_ERR_NULL, "vidc_maxpool3x3s2: null pointer");
+extern "C" int vidc_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, void* y_split,
+                                 vidc_stream_t stream) {
+    VIDC_REQUIRE(x && (y || y_split), VIDC_ERR_NULL, "vidc_maxpool3x3s2: null pointer");
+    VIDC_REQUIRE(!y_split || ldy % 32 == 0, VIDC_ERR_SHAPE, "vidc_maxpool3x3s2: split output needs ldy % 32 == 0");
     VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C,
                  VIDC_ERR_SHAPE, "vidc_maxpool3x3s2: bad shape (C, ldx, ldy must be multiples of 4)");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     long long total = (long long)B * Ho * Wo * (C / 4);
     hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vidc::as_stream(stream), x, y, B, H, W,
-                       C, ldx, Ho, Wo, ldy);
+                       C, ldx, Ho, Wo, ldy, reinterpret_cast<unsigned short*>(y_split));
     VIDC_CHECK_LAUNCH("maxpool_kernel");
     return VIDC_OK;
 }
 
 extern "C" int vidc_upsample_bilinear_ac(const float* x, float* y, int B, int h, int w, int C, int ldx, int H, int W, int ldy,
-                                         int flags, vidc_stream_t stream) {
+                                         int flags, void* y_split, vidc_stream_t stream) {
     VIDC_REQUIRE(x && y, VIDC_ERR_NULL, "vidc_upsample_bilinear_ac: null pointer");
+    VIDC_REQUIRE(!y_split || ldy % 32 == 0, VIDC_ERR_SHAPE, "vidc_upsample_bilinear_ac: split output needs ldy % 32 == 0");
+    VIDC_REQUIRE(!(flags & VIDC_UP_NO_F32_OUT) || y_split, VIDC_ERR_SHAPE, "vidc_upsample_bilinear_ac: NO_F32_OUT without y_split writes nothing");
     VIDC_REQUIRE(B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, VIDC_ERR_SHAPE,
                  "vidc_upsample_bilinear_ac: bad shape");
     long long total = (long long)B * H * W * (C / 4);
     hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vidc::as_stream(stream), x, y, B, h, w,
-                       C, ldx, H, W, ldy, flags);
+                       C, ldx, H, W, ldy, flags, reinterpret_cast<unsigned short*>(y_split));
     VIDC_CHECK_LAUNCH("upsample_kernel");
     return VIDC_OK;
 }

@@ -26,12 +26,13 @@ int launch_op(const vidc_op& op, hipStream_t st) {
             return vidc_conv2d_bn_act(&op.u.conv, s);
         case VIDC_OP_STEM:
             return vidc_stem_conv3x3s2((const float*)g.p[0], (const float*)g.p[1], (float*)g.p[2], g.i[0], g.i[1], g.i[2], g.i[3],
-                                       g.i[4], g.i[5], g.i[6], s);
+                                       g.i[4], g.i[5], g.i[6], const_cast<void*>(g.p[3]), g.i[7], s);
         case VIDC_OP_MAXPOOL:
-            return vidc_maxpool3x3s2((const float*)g.p[0], (float*)g.p[1], g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.i[5], s);
+            return vidc_maxpool3x3s2((const float*)g.p[0], (float*)g.p[1], g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.i[5],
+                                     const_cast<void*>(g.p[2]), s);
         case VIDC_OP_UPSAMPLE:
             return vidc_upsample_bilinear_ac((const float*)g.p[0], (float*)g.p[1], g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.i[5],
-                                             g.i[6], g.i[7], g.i[8], s);
+                                             g.i[6], g.i[7], g.i[8], const_cast<void*>(g.p[2]), s);
         case VIDC_OP_HEAD:
             return vidc_head_conv1x1_upsample((const float*)g.p[0], (const float*)g.p[1], (const float*)g.p[2], (float*)g.p[3],
                                               (float*)g.p[4], g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.i[5], g.i[6], g.i[7],

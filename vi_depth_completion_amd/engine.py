@@ -163,6 +163,7 @@ class Program:
         self.wait_mask = 0
         self.handle = None
         self.flops = 0           # executed conv FLOPs (2*M*N*K summed)
+        self.ref_flops = 0       # the same layers in the reference's formulation (1x1 convs AFTER their upsample: SURVEY §8d)
         self._keep = []
         self._split_cache = {}   # (buf, ch_off, channels) -> buffer id of the split-bf16 image
         self.cuts = []           # op indices where a new segment starts (see cut()); filled by finalize()
@@ -209,7 +210,7 @@ class Program:
 
     # ---- ops ---------------------------------------------------------------------------------------------
     def conv(self, x, key, bn=None, relu=False, stride=1, padding=0, bn2=None, relu2=False, residual=None,
-             relu_after_residual=False, out=None, accumulate=False):
+             relu_after_residual=False, out=None, accumulate=False, ref_flops_scale=1.0):
         keys = _keys(key)
         G = len(keys)
         assert x.G == G and not x.nchw
@@ -229,6 +230,7 @@ class Program:
             flags |= L.ACCUM
         flops = 2 * self.B * Ho * Wo * co * ci * kh * kw * G
         self.flops += flops
+        self.ref_flops += int(round(flops * ref_flops_scale))
         # precision: measured table entry if there is one, else by size
         sig = "M%d_N%d_K%d_k%ds%d_G%d" % (self.B * Ho * Wo, co, kh * kw * ci, kh, stride, G)
         prec = L.PREC_FP32
@@ -317,8 +319,9 @@ class Program:
 
     # ---- planning ----------------------------------------------------------------------------------------
     def _fuse_splits(self):
-        """A split op whose input was just produced by a fused conv is folded into that conv's epilogue (VIDC_SPLIT_OUT);
-        when nothing else reads the fp32 result the conv does not store it at all (VIDC_NO_F32_OUT)."""
+        """A split op whose input was just produced by a fused conv -- or by a stem / max-pool / upsample kernel -- is folded into
+        that producer (VIDC_SPLIT_OUT / the y_split argument of the glue kernels); when nothing else reads the fp32 result
+        the producer does not store it at all (VIDC_NO_F32_OUT, VIDC_UP_NO_F32_OUT, y = NULL)."""
         n = len(self.ops)
         drop = set()
         for i, (kind, _r, _w, kw) in enumerate(self.ops):
@@ -326,22 +329,41 @@ class Program:
                 continue
             xs = kw["x"]
             j = next((t for t in range(i - 1, -1, -1) if xs.buf in self.ops[t][2]), None)
-            if j is None or self.ops[j][0] != "conv":
+            if j is None or self.ops[j][0] not in ("conv", "maxpool", "upsample", "stem"):
                 continue
-            pk = self.ops[j][3]
+            pkind, pk = self.ops[j][0], self.ops[j][3]
             y = pk["y"]
-            if y.ch_off != 0 or y.C * y.G != xs.C * xs.G or y.ld != y.C * y.G or pk.get("split_out") is not None:
+            if pkind == "stem":
+                # G launches write the channel slices of one tensor: all of them get the image of the whole tensor
+                writers = [t for t in range(j + 1) if self.ops[t][0] == "stem" and self.ops[t][3]["y"].buf == y.buf]
+                if xs.ch_off != 0 or xs.C * xs.G != y.C * y.G or y.ld != y.C * y.G or y.ld % 32 or y.C % 32 or \
+                        any(self.ops[t][3].get("split_out") is not None for t in writers) or len(writers) != y.G:
+                    continue
+                for t in writers:
+                    self.ops[t][3]["split_out"] = kw["y"]
+                    self.ops[t][2].append(kw["y"].buf)
+                drop.add(i)
+                continue
+            if y.ch_off != 0 or y.C * y.G != xs.C * xs.G or y.ld != y.C * y.G or y.ld % 32 or pk.get("split_out") is not None:
                 continue
             pk["split_out"] = kw["y"]
-            pk["flags"] |= L.SPLIT_OUT
+            if pkind == "conv":
+                pk["flags"] |= L.SPLIT_OUT
             self.ops[j][2].append(kw["y"].buf)
             drop.add(i)
         for j, (kind, _r, _w, kw) in enumerate(self.ops):
-            if kind == "conv" and kw.get("split_out") is not None and kw["y"].buf not in self.pinned:
+            if kind in ("conv", "maxpool", "upsample", "stem") and kw.get("split_out") is not None and kw["y"].buf not in self.pinned:
                 yb = kw["y"].buf
-                used = any(t not in drop and (yb in self.ops[t][1] or yb in self.ops[t][2]) for t in range(j + 1, n))
+                used = any(t not in drop and yb in self.ops[t][1] for t in range(j + 1, n))
+                # a later writer of the same buffer that accumulates into it needs the fp32 values too (reads cover that); a
+                # later plain writer of ANOTHER slice of the buffer (stem groups) does not
                 if not used:
-                    kw["flags"] |= L.NO_F32_OUT
+                    if kind == "conv":
+                        kw["flags"] |= L.NO_F32_OUT
+                    elif kind == "upsample":
+                        kw["flags"] |= L.UP_NO_F32_OUT
+                    else:
+                        kw["no_f32"] = True
         self.n_fused_splits = len(drop)
         self.ops = [op for i, op in enumerate(self.ops) if i not in drop]
 
@@ -449,16 +471,20 @@ class Program:
                 w = self.ws.raw(kw["key"] + ".weight").contiguous()
                 self._keep.append(w)
                 op.kind = L.OP_STEM
-                g.p[0], g.p[1], g.p[2] = addr(x), w.data_ptr(), addr(y, kw["g"] * y.C)
-                for j, v in enumerate((x.B, x.C, x.H, x.W, y.C, y.ld, int(kw["relu"]))):
+                g.p[0], g.p[1], g.p[2] = addr(x), w.data_ptr(), (0 if kw.get("no_f32") else addr(y, kw["g"] * y.C))
+                for j, v in enumerate((x.B, x.C, x.H, x.W, y.C, y.ld, int(kw["relu"]), kw["g"] * y.C)):
                     g.i[j] = v
+                if kw.get("split_out") is not None:
+                    g.p[3] = addr(kw["split_out"])
                 self.op_names.append("stem:" + kw["key"])
             elif kind == "maxpool":
                 x, y = kw["x"], kw["y"]
                 op.kind = L.OP_MAXPOOL
-                g.p[0], g.p[1] = addr(x), addr(y)
+                g.p[0], g.p[1] = addr(x), (0 if kw.get("no_f32") else addr(y))
                 for j, v in enumerate((x.B, x.H, x.W, x.C * x.G, x.ld, y.ld)):
                     g.i[j] = v
+                if kw.get("split_out") is not None:
+                    g.p[2] = addr(kw["split_out"])
                 self.op_names.append("maxpool")
             elif kind == "upsample":
                 x, y = kw["x"], kw["y"]
@@ -466,6 +492,8 @@ class Program:
                 g.p[0], g.p[1] = addr(x), addr(y)
                 for j, v in enumerate((x.B, x.H, x.W, x.C * x.G, x.ld, y.H, y.W, y.ld, kw["flags"])):
                     g.i[j] = v
+                if kw.get("split_out") is not None:
+                    g.p[2] = addr(kw["split_out"])
                 self.op_names.append("upsample:%dx%dx%d->%dx%d" % (x.H, x.W, x.C * x.G, y.H, y.W))
             elif kind == "head":
                 x, low, y = kw["x"], kw["low"], kw["y"]

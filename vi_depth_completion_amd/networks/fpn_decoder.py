@@ -2,6 +2,8 @@
 times wider, networks/depth_completion.py:75-147): parameter containers with the reference's Sequential
 indices, and the walk that turns them into fused engine ops.
 """
+import os
+
 import torch.nn as nn
 
 # per pyramid level: (kernel, cout multiple of 128*m) for each conv, 'u' = upsample to the next finer level
@@ -11,6 +13,7 @@ _BRANCH_PLAN = {
     3: [(1, 4), (3, 4), "u", (1, 2), (3, 2), "u", (1, 1)],
     4: [(1, 8), (3, 8), "u", (1, 4), (3, 4), "u", (1, 2), (3, 2), "u", (1, 1)],
 }
+COMMUTE_UPSAMPLE = os.environ.get("VIDC_COMMUTE_UPSAMPLE", "1") == "1"
 _LEVEL_SIZES_240 = {1: (60, 80), 2: (30, 40), 3: (15, 20)}   # the reference's literals, used only as nn metadata
 
 
@@ -33,7 +36,12 @@ def build_branch(level, m):
 
 def emit_branch(prog, seq, prefix, x, level_sizes, zsum):
     """Walks one branch.  Conv2d+BatchNorm2d+ReLU triples become one fused conv; the last conv of the branch writes
-    (branch 1) or accumulates (branches 2-4) into `zsum`, which implements z1+z2+z3+z4 without add kernels."""
+    (branch 1) or accumulates (branches 2-4) into `zsum`, which implements z1+z2+z3+z4 without add kernels.
+
+    UpsamplingBilinear2d -> Conv2d(1x1) -> BatchNorm2d -> ReLU (every upsample of the reference is followed by exactly that,
+    surface_normal.py:88-91 ...) is executed as conv1x1+BN at the LOW resolution -> upsample -> ReLU: a 1x1 conv and a
+    per-channel affine commute with bilinear interpolation (its weights sum to 1), so the result is the same up to fp32
+    rounding while the conv does 4x fewer MACs and the upsample moves half the channels."""
     mods = list(seq)
     n_conv = sum(isinstance(mm, nn.Conv2d) for mm in mods)
     seen = 0
@@ -55,8 +63,19 @@ def emit_branch(prog, seq, prefix, x, level_sizes, zsum):
         elif isinstance(mm, nn.UpsamplingBilinear2d):
             # target size = the next finer pyramid level of *this* input resolution (the reference hard-codes 240x320)
             level = [lv for lv, sz in level_sizes.items() if sz == (t.H, t.W)][0] - 1
-            t = prog.upsample(t, level_sizes[level])
-            i += 1
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if COMMUTE_UPSAMPLE and isinstance(nxt, nn.Conv2d) and nxt.kernel_size == (1, 1):
+                assert isinstance(mods[i + 2], nn.BatchNorm2d) and isinstance(mods[i + 3], nn.ReLU)
+                seen += 1
+                last = seen == n_conv
+                Hn, Wn = level_sizes[level]
+                t = prog.conv(t, "%s%d" % (prefix, i + 1), bn="%s%d" % (prefix, i + 2), relu=False,        # low resolution
+                              ref_flops_scale=(Hn * Wn) / float(t.H * t.W))
+                t = prog.upsample(t, level_sizes[level], relu=True, into=zsum if (last and zsum is not None) else None)
+                i += 4
+            else:
+                t = prog.upsample(t, level_sizes[level])
+                i += 1
         else:
             raise TypeError(type(mm))
     return t

@@ -101,34 +101,36 @@ def conv2d_bn_act(x, w_packed, scale1, shift1, kh, kw, stride=1, pad=0, relu1=Fa
     return y
 
 
-def stem_conv3x3s2(x_nchw, w_oihw, relu=True):
+def stem_conv3x3s2(x_nchw, w_oihw, relu=True, split_out=None):
+    """split_out: optional float32-typed tensor of y's shape receiving the split-bf16 image of the result (Cout % 32 == 0)."""
     _dev(x_nchw, w_oihw)
     x, w = x_nchw.contiguous().float(), w_oihw.contiguous().float()
     B, cin, H, W = x.shape
     co = w.shape[0]
     Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
     y = torch.empty((B, Ho, Wo, co), dtype=torch.float32, device=x.device)
-    L.check(L.lib().vidc_stem_conv3x3s2(L.ptr(x), L.ptr(w), L.ptr(y), B, cin, H, W, co, co, int(relu), L.current_stream()), "stem")
+    L.check(L.lib().vidc_stem_conv3x3s2(L.ptr(x), L.ptr(w), L.ptr(y), B, cin, H, W, co, co, int(relu), L.ptr(split_out), 0,
+                                        L.current_stream()), "stem")
     return y
 
 
-def maxpool3x3s2(x):
+def maxpool3x3s2(x, split_out=None):
     _dev(x)
     x = x.contiguous()
     B, H, W, Cc = x.shape
     Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
     y = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
-    L.check(L.lib().vidc_maxpool3x3s2(L.ptr(x), L.ptr(y), B, H, W, Cc, Cc, Cc, L.current_stream()), "maxpool")
+    L.check(L.lib().vidc_maxpool3x3s2(L.ptr(x), L.ptr(y), B, H, W, Cc, Cc, Cc, L.ptr(split_out), L.current_stream()), "maxpool")
     return y
 
 
-def upsample_bilinear_ac(x, size, relu=False, accumulate_into=None):
+def upsample_bilinear_ac(x, size, relu=False, accumulate_into=None, split_out=None, store_f32=True):
     _dev(x)
     x = x.contiguous()
     B, h, w, Cc = x.shape
     y = accumulate_into if accumulate_into is not None else torch.empty((B, size[0], size[1], Cc), dtype=torch.float32, device=x.device)
-    flags = (L.UP_RELU if relu else 0) | (L.UP_ACCUM if accumulate_into is not None else 0)
-    L.check(L.lib().vidc_upsample_bilinear_ac(L.ptr(x), L.ptr(y), B, h, w, Cc, Cc, size[0], size[1], Cc, flags,
+    flags = (L.UP_RELU if relu else 0) | (L.UP_ACCUM if accumulate_into is not None else 0) | (0 if store_f32 else L.UP_NO_F32_OUT)
+    L.check(L.lib().vidc_upsample_bilinear_ac(L.ptr(x), L.ptr(y), B, h, w, Cc, Cc, size[0], size[1], Cc, flags, L.ptr(split_out),
                                               L.current_stream()), "upsample")
     return y
 
