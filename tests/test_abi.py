@@ -54,7 +54,8 @@ def test_conv_plan_is_sane(lib, M, N, K):
     d.B, d.Ho, d.Wo, d.Cout, d.Cin, d.KH, d.KW, d.groups = 1, 1, M, N, K, 1, 1, 1
     assert lib.vidc_conv2d_plan(C.byref(d)) == 0
     assert 1 <= d.tile < L.TILE_COUNT and d.splitk >= 1
-    bm, bn = [int(v) for v in L.TILE_NAMES[d.tile].split("k")[0].split("d")[0].split("x")]
+    import re
+    bm, bn = [int(v) for v in re.match(r"(\d+)x(\d+)", L.TILE_NAMES[d.tile]).groups()]
     wgs = -(-M // bm) * -(-N // bn) * d.splitk
     assert wgs >= min(64, (M // 32) * (N // 64))        # the planner must not leave most of the 256 CUs idle
     if d.splitk > 1:
