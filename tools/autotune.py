@@ -28,15 +28,22 @@ TILE_DIMS = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (64, 64)
              10: (32, 64), 11: (32, 32), 12: (32, 128), 13: (64, 64)}
 
 
-def time_desc(lib, d, st, copies=20):
-    """GPU-bound timing: a captured hipGraph of `copies` back-to-back launches of the op (launching from Python is
-    host-bound at ~7 us per call and cannot rank configurations of the small layers)."""
+def time_desc(lib, d, st, pool, junk, copies=20):
+    """GPU-bound timing with HBM-COLD weights, like in the real frame (1.5 GB of weights per frame never survive in the
+    256 MB Infinity Cache until the next frame): a captured hipGraph of back-to-back launches of the op, every launch reading
+    its own copy of the weights out of `pool`, and 512 MB of junk written before each timed replay.  (Launching from Python
+    is host-bound at ~7 us per call and cannot rank configurations of the small layers; timing with the same weights over
+    and over ranks them by their L2-hit behaviour, which is not what the frame sees.)"""
     if lib.vidc_conv2d_bn_act(C.byref(d), st) != 0:       # also sets the kernel's LDS attribute outside capture
         return None
+    wbytes = d.groups * d.Cout * d.KH * d.KW * d.Cin * 4
+    stride = (wbytes + 255) // 256 * 256
+    copies = int(max(2, min(copies, pool.numel() * 4 // stride)))
     ops = (L.Op * copies)()
-    for o in ops:
+    for i, o in enumerate(ops):
         o.kind = L.OP_CONV
         C.memmove(C.byref(o.u.conv), C.byref(d), C.sizeof(L.ConvDesc))
+        o.u.conv.w = pool.data_ptr() + i * stride
     h = C.c_void_p()
     if lib.vidc_program_create(ops, copies, C.byref(h)) != 0:
         return None
@@ -44,8 +51,10 @@ def time_desc(lib, d, st, copies=20):
     try:
         if lib.vidc_program_capture(h, st) == 0:
             ms = (C.c_float * 1)()
-            for _ in range(2):
-                if lib.vidc_program_time(h, st, 3, 1, ms, None) != 0:
+            for rep in range(2):
+                junk.fill_(rep)
+                torch.cuda.synchronize()
+                if lib.vidc_program_time(h, st, 1, 1, ms, None) != 0:
                     return None
                 us = ms[0] * 1e3 / copies
                 best = us if best is None else min(best, us)
@@ -96,6 +105,8 @@ def main():
     torch.cuda.set_stream(side)                 # graph capture needs a non-default stream
     st = side.cuda_stream
     ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)     # 256 MB split-K scratch
+    pool = (torch.randn(256 << 20, dtype=torch.float32, device=dev) * 0.05)     # 1 GB of weight copies (cold per launch)
+    junk = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
     for H in [int(v) for v in a.heights.split(",")]:
         for B in [int(v) for v in a.batches.split(",")]:
             cc = np.array([0.5 * 319.87654, 0.5 * 239.87603 * H / 240.0])
@@ -126,7 +137,7 @@ def main():
                                 if sk * d.groups * M * d.Cout > ws.numel():
                                     continue
                                 d.tile, d.splitk = t, sk
-                                us = time_desc(lib, d, st)
+                                us = time_desc(lib, d, st, pool, junk)
                                 if us is not None:
                                     cands.append((us, t, sk))
                         cands.sort()
