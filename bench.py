@@ -67,17 +67,33 @@ def _sig_flops(name):
     return 2.0 * M * N * K * G
 
 
+# vidc_conv_tile name -> template arguments <BM, BN, WM, WN, WK, NS> of conv_igemm_f32 (csrc/conv_mfma.hip kTiles): the kernel
+# name rocprofv3 reports for that tiling is conv_igemm_f32<BM, BN, WM, WN, WK, NS, PREC>
+TILE_TEMPLATE = {"128x128": (128, 128, 2, 2, 1, 2), "128x64": (128, 64, 2, 2, 1, 3), "64x128": (64, 128, 2, 2, 1, 3), "64x64": (64, 64, 2, 2, 1, 4),
+                 "64x64k2": (64, 64, 2, 2, 2, 3), "32x64k2": (32, 64, 1, 2, 2, 3), "32x32k4": (32, 32, 1, 1, 4, 3), "32x128": (32, 128, 1, 4, 1, 4),
+                 "32x32k8": (32, 32, 1, 1, 8, 2), "32x64k2d5": (32, 64, 1, 2, 2, 5), "32x32k4d4": (32, 32, 1, 1, 4, 4),
+                 "32x128d6": (32, 128, 1, 4, 1, 6), "64x64k2d4": (64, 64, 2, 2, 2, 4)}
+
+
 def conv_stack_times(prog, iters=5):
     """Per-op durations of one program execution: HIP events recorded between consecutive ops on the launch stream
-    (eager mode, averaged over `iters`).  Returns {mode: (ms, launches, algorithmic_flops)} for the fused-conv launches
-    of each arithmetic mode, the program total, and the (name, ms) table."""
+    (eager issue, averaged over `iters`), rescaled by (hipGraph replay time of the program / eager time of the program):
+    an event between every two launches costs ~1-2 us of GPU idle per op, which the production path (graph replay) does
+    not pay.  Returns {kernel: (ms, launches, flops)} for the fused-conv launches grouped by kernel (= tiling x arithmetic
+    mode = one template instantiation; a split-K launch includes its finalize kernel), the program's graph-replay time, and
+    the (name, ms) table."""
     total, per = prog.time(iters=iters, use_graph=False, per_op=True)
+    if prog.captured:
+        graph_ms = prog.time(iters=20, use_graph=True)
+        per = [t * graph_ms / total for t in per]
+        total = graph_ms
     out = {}
     for n, t in zip(prog.op_names, per):
         if n.startswith("conv:"):
-            mode = "bf16x3" if ":bf16x3 " in n else "fp32"
-            ms, cnt, fl = out.get(mode, (0.0, 0, 0.0))
-            out[mode] = (ms + t, cnt + 1, fl + _sig_flops(n))
+            _c, _key, tile, _sk, rest = n.split(":", 4)
+            kern = (tile, "bf16x3" if rest.startswith("bf16x3 ") else "fp32")
+            ms, cnt, fl = out.get(kern, (0.0, 0, 0.0))
+            out[kern] = (ms + t, cnt + 1, fl + _sig_flops(n))
     return out, total, list(zip(prog.op_names, per))
 
 
@@ -143,40 +159,50 @@ def main():
             sn_t, sn_total, sn_ops = conv_stack_times(sn_prog)
             dc_t, dc_total, dc_ops = conv_stack_times(dc_prog)
         flops = FLOPS_PER_FRAME.get((H, W), 293.88e9 * H * W / (240.0 * 320.0)) * B
-        modes = {}
+        kernels = {}
         for d in (sn_t, dc_t):
             for k, (ms, cnt, fl) in d.items():
-                a0, a1, a2 = modes.get(k, (0.0, 0, 0.0))
-                modes[k] = (a0 + ms, a1 + cnt, a2 + fl)
-        conv_ms = sum(v[0] for v in modes.values())
-        n_launch = sum(v[1] for v in modes.values())
+                a0, a1, a2 = kernels.get(k, (0.0, 0, 0.0))
+                kernels[k] = (a0 + ms, a1 + cnt, a2 + fl)
+        conv_ms = sum(v[0] for v in kernels.values())
+        conv_flops = sum(v[2] for v in kernels.values())
+        n_launch = sum(v[1] for v in kernels.values())
 
-        def roof(mode):
-            ms, cnt, fl = modes[mode]
+        def roof(kern):
+            """`achieved` = the kernel's own 2*M*N*K FLOPs per launch / its average launch duration (HIP events, this process).
+            bf16x3 executes 3 bf16 MFMA products per fp32-equivalent product: `frac` prices the fp32-equivalent FLOPs against
+            the dense bf16 peak, `frac_executed` the executed ones."""
+            tile, mode = kern
+            ms, cnt, fl = kernels[kern]
             ach = fl / (ms * 1e-3) / 1e12
-            if mode == "fp32":
-                return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                        "kernel": "conv_igemm_f32<...,PREC=0> (v_mfma_f32_32x32x2_f32) + conv_splitk_finalize",
-                        "launches_per_frame": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
-                        "algorithmic_gflop_per_frame": round(fl / 1e9, 2), "ms_per_frame": round(ms, 3)}
-            return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
-                    "kernel": "conv_igemm_f32<...,PREC=1> (bf16x3: 3 x v_mfma_f32_32x32x16_bf16 per product) + conv_splitk_finalize",
-                    "launches_per_frame": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
-                    "algorithmic_gflop_per_frame": round(fl / 1e9, 2), "ms_per_frame": round(ms, 3),
-                    "executed_tflops": round(3 * ach, 2), "frac_executed": round(3 * ach / PEAK_BF16_MFMA_TFLOPS, 4)}
+            prec = 1 if mode == "bf16x3" else 0
+            peak = PEAK_BF16_MFMA_TFLOPS if prec else PEAK_F32_MFMA_TFLOPS
+            r = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                 "kernel": "conv_igemm_f32<%s, %d>" % (", ".join(str(v) for v in TILE_TEMPLATE[tile]), prec),
+                 "arithmetic": ("bf16x3: 3 x v_mfma_f32_32x32x16_bf16 per fp32-equivalent product" if prec else "v_mfma_f32_32x32x2_f32"),
+                 "launches_per_frame": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2), "gflop_per_launch": round(fl / cnt / 1e9, 3),
+                 "ms_per_frame": round(ms, 3),
+                 "traffic_note": "PMC FETCH_SIZE/WRITE_SIZE of this kernel class: profiles/r1_pmc_summary.txt (rocprofv3 --pmc on the whole "
+                                 "bench process segfaults in rocprofv3 on this pool, so counters are collected on tools/conv_bench.py)"}
+            if prec:
+                r.update(executed_tflops=round(3 * ach, 2), frac_executed=round(3 * ach / peak, 4))
+            return r
 
-        dominant = max(modes, key=lambda k: modes[k][0])
+        dominant = max(kernels, key=lambda k: kernels[k][0])
         roofline = roof(dominant)
+        ranked = sorted(kernels, key=lambda k: -kernels[k][0])
         extra = {"program_ms": ({"frame_program_tick": round(sn_total, 3)} if args.mode == "interleaved" else
                                 {"surface_normal": round(sn_total, 3), "depth_completion": round(dc_total, 3)}),
                  "conv_ms_per_frame": round(conv_ms, 3), "conv_launches_per_frame": n_launch,
-                 "conv_stack_tflops_algorithmic": round(flops / (conv_ms * 1e-3) / 1e12, 2),
-                 "precision_mode": os.environ.get("VIDC_PRECISION", "mixed")}
-        for k in modes:
-            if k != dominant:
-                extra["roofline_" + k] = roof(k)
+                 "conv_stack": {"executed_gflop_per_frame": round(conv_flops / 1e9, 2),
+                                "tflops_fp32_equivalent": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
+                                "tflops_bf16_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / (conv_ms * 1e-3) / 1e12, 2)},
+                 "reference_formulation_gflop_per_frame": round(flops / 1e9, 2),
+                 "conv_stack_tflops_reference_formulation": round(flops / (conv_ms * 1e-3) / 1e12, 2),
+                 "precision_mode": os.environ.get("VIDC_PRECISION", "mixed"),
+                 "other_conv_kernels": [roof(k) for k in ranked[1:4]]}
+        for r in extra["other_conv_kernels"]:
+            r.pop("traffic_note", None)
         if args.per_op:
             with open(args.per_op, "w") as f:
                 for name, ops in ((("frame_program" if args.mode == "interleaved" else "surface_normal"), sn_ops), ("depth_completion", dc_ops)):

@@ -248,7 +248,7 @@ typedef struct vidc_program vidc_program;
 int vidc_program_create(const vidc_op* ops, int n_ops, vidc_program** out);
 int vidc_program_run(vidc_program* p, vidc_stream_t stream);          /* eager: one launch per op            */
 int vidc_program_capture(vidc_program* p, vidc_stream_t stream);      /* records a hipGraph of the program    */
-int vidc_program_launch(vidc_program* p, vidc_stream_t stream);       /* replays the captured graph           */
+int vidc_program_launch(vidc_program* p, vidc_stream_t stream);       /* replays the captured graph (all segments) */
 /* Segments: ops [begin, end) of one planned program as their own eager run / hipGraph (segment 0..VIDC_MAX_SEGMENTS-1), so the
  * host can place other launches between parts of a program -- the reference does the same thing implicitly: its plane block
  * and enrichment loop (main.py:277-294) sit between the two networks of one _call_cnn. */

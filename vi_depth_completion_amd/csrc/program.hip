@@ -151,7 +151,8 @@ extern "C" int vidc_program_capture(vidc_program* p, vidc_stream_t stream) {
 
 extern "C" int vidc_program_launch(vidc_program* p, vidc_stream_t stream) {
     VIDC_REQUIRE(p && p->exec[0], VIDC_ERR_STATE, "vidc_program_launch: program not captured");
-    VIDC_HIP(hipGraphLaunch(p->exec[0], vidc::as_stream(stream)));
+    for (int k = 0; k < VIDC_MAX_SEGMENTS && p->exec[k]; ++k)      // a program captured in segments replays all of them, in order
+        VIDC_HIP(hipGraphLaunch(p->exec[k], vidc::as_stream(stream)));
     return VIDC_OK;
 }
 
