@@ -72,7 +72,11 @@ def _sig_flops(name):
 TILE_TEMPLATE = {"128x128": (128, 128, 2, 2, 1, 2), "128x64": (128, 64, 2, 2, 1, 3), "64x128": (64, 128, 2, 2, 1, 3), "64x64": (64, 64, 2, 2, 1, 4),
                  "64x64k2": (64, 64, 2, 2, 2, 3), "32x64k2": (32, 64, 1, 2, 2, 3), "32x32k4": (32, 32, 1, 1, 4, 3), "32x128": (32, 128, 1, 4, 1, 4),
                  "32x32k8": (32, 32, 1, 1, 8, 2), "32x64k2d5": (32, 64, 1, 2, 2, 5), "32x32k4d4": (32, 32, 1, 1, 4, 4),
-                 "32x128d6": (32, 128, 1, 4, 1, 6), "64x64k2d4": (64, 64, 2, 2, 2, 4)}
+                 "32x128d6": (32, 128, 1, 4, 1, 6), "64x64k2d4": (64, 64, 2, 2, 2, 4),
+                 # loader-wave variants: conv_igemm_f32<..., PREC, 1>
+                 "32x64k2L": (32, 64, 1, 2, 2, 3), "32x64k2d5L": (32, 64, 1, 2, 2, 5), "32x32k4d4L": (32, 32, 1, 1, 4, 4), "64x64L": (64, 64, 2, 2, 1, 4),
+                 "64x64k2d4L": (64, 64, 2, 2, 2, 4), "64x128L": (64, 128, 2, 2, 1, 3), "128x64L": (128, 64, 2, 2, 1, 3),
+                 "64x32k2": (64, 32, 2, 1, 2, 3), "64x32k2d5": (64, 32, 2, 1, 2, 5), "64x32k2d5L": (64, 32, 2, 1, 2, 5)}
 
 
 def conv_stack_times(prog, iters=5):
@@ -178,7 +182,7 @@ def main():
             prec = 1 if mode == "bf16x3" else 0
             peak = PEAK_BF16_MFMA_TFLOPS if prec else PEAK_F32_MFMA_TFLOPS
             r = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                 "kernel": "conv_igemm_f32<%s, %d>" % (", ".join(str(v) for v in TILE_TEMPLATE[tile]), prec),
+                 "kernel": "conv_igemm_f32<%s, %d, %d>" % (", ".join(str(v) for v in TILE_TEMPLATE[tile]), prec, int(tile.endswith("L"))),
                  "arithmetic": ("bf16x3: 3 x v_mfma_f32_32x32x16_bf16 per fp32-equivalent product" if prec else "v_mfma_f32_32x32x2_f32"),
                  "launches_per_frame": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2), "gflop_per_launch": round(fl / cnt / 1e9, 3),
                  "ms_per_frame": round(ms, 3),

@@ -117,7 +117,11 @@ enum vidc_conv_tile { VIDC_TILE_AUTO = 0, VIDC_TILE_128x128 = 1, VIDC_TILE_128x6
                       VIDC_TILE_32x128 = 8, VIDC_TILE_32x32_K8 = 9,
                       /* same tilings with deeper LDS rings (_Dn = n stages) */
                       VIDC_TILE_32x64_K2_D5 = 10, VIDC_TILE_32x32_K4_D4 = 11, VIDC_TILE_32x128_D6 = 12, VIDC_TILE_64x64_K2_D4 = 13,
-                      VIDC_TILE_COUNT = 14 };
+                      /* _L: same tile with loader waves -- as many extra waves as compute waves issue all LDS-DMA */
+                      VIDC_TILE_32x64_K2_L = 14, VIDC_TILE_32x64_K2_D5_L = 15, VIDC_TILE_32x32_K4_D4_L = 16, VIDC_TILE_64x64_L = 17,
+                      VIDC_TILE_64x64_K2_D4_L = 18, VIDC_TILE_64x128_L = 19, VIDC_TILE_128x64_L = 20,
+                      VIDC_TILE_64x32_K2 = 21, VIDC_TILE_64x32_K2_D5 = 22, VIDC_TILE_64x32_K2_D5_L = 23,
+                      VIDC_TILE_COUNT = 24 };
 
 /* Arithmetic of the contraction.  FP32: v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32, the reference mode).
  * BF16X3: every operand is split as x = hi + lo (bf16 each, round-to-nearest-even) and each product is computed as

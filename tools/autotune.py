@@ -25,7 +25,8 @@ from vi_depth_completion_amd.networks.surface_normal import SurfaceNormalPredict
 
 OUT = os.path.join(ROOT, "vi_depth_completion_amd", "conv_tuning.json")
 TILE_DIMS = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (64, 64), 6: (32, 64), 7: (32, 32), 8: (32, 128), 9: (32, 32),
-             10: (32, 64), 11: (32, 32), 12: (32, 128), 13: (64, 64)}
+             10: (32, 64), 11: (32, 32), 12: (32, 128), 13: (64, 64), 14: (32, 64), 15: (32, 64), 16: (32, 32), 17: (64, 64), 18: (64, 64),
+             19: (64, 128), 20: (128, 64), 21: (64, 32), 22: (64, 32), 23: (64, 32)}
 
 
 def time_desc(lib, d, st, pool, junk, copies=20):
@@ -89,6 +90,7 @@ def main():
     ap.add_argument("--heights", default="240,256")
     ap.add_argument("--batches", default="1")
     ap.add_argument("--splitk", default="1,2,4,8,16")
+    ap.add_argument("--sigs", default="", help="comma-separated substrings: re-measure only signatures containing one of them (keeps the rest of the table)")
     ap.add_argument("--only-missing", action="store_true", help="keep the committed table and measure only signatures it lacks")
     ap.add_argument("--split-charge", type=float, default=0.25,
                     help="fraction of the standalone split-kernel time charged to a bf16x3 conv (most splits are fused into the\n"
@@ -99,8 +101,11 @@ def main():
     engine._TUNING = {}                      # measure against the cost-model plan, not an older table
     os.environ["VIDC_PRECISION"] = "fp32"      # record the programs with fp32 inputs (no split ops); both modes are timed below
     table, report = {}, []
-    if a.only_missing and os.path.exists(OUT):
+    if (a.only_missing or a.sigs) and os.path.exists(OUT):
         table = json.load(open(OUT))
+    if a.sigs:
+        pats = [v for v in a.sigs.split(",") if v]
+        table = {k: v for k, v in table.items() if not any(pt in k for pt in pats)}
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)                 # graph capture needs a non-default stream
     st = side.cuda_stream
@@ -118,7 +123,7 @@ def main():
                     if op.kind != L.OP_CONV:
                         continue
                     sig = name.split(" ")[1]
-                    if sig in table:
+                    if sig in table or (a.sigs and not any(pt in sig for pt in a.sigs.split(",") if pt)):
                         continue
                     d = L.ConvDesc.from_buffer_copy(op.u.conv)
                     d.workspace = ws.data_ptr()

@@ -11,12 +11,16 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vi_depth_completion_amd import _lib as L          # noqa: E402
-L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libvidc_timing.so")
+L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), os.environ.get("VIDC_TIMING_LIB", "libvidc_timing.so"))
 from vi_depth_completion_amd import synthetic as S     # noqa: E402
 
 SHAPES = {  # name: (H, W, cin, cout, k, G, tile, precision)
-    "l3_1x1_1024to256_G4": (16, 20, 1024, 256, 1, 4, 6, 1),
-    "l3_3x3_G4": (16, 20, 256, 256, 3, 4, 6, 1),
+    "l3_1x1_1024to256_G4": (16, 20, 1024, 256, 1, 4, 10, 1),
+    "l3_3x3_G4": (16, 20, 256, 256, 3, 4, 10, 1),
+    "l3_3x3_G4_L": (16, 20, 256, 256, 3, 4, 15, 1),
+    "l3_1x1_1024to256_G4_L": (16, 20, 1024, 256, 1, 4, 15, 1),
+    "l3_1x1_256to1024_G4_L": (16, 20, 256, 1024, 1, 4, 17, 1),
+    "f1_3x3_768_L": (64, 80, 768, 768, 3, 1, 19, 1),
     "l3_1x1_256to1024_G4": (16, 20, 256, 1024, 1, 4, 4, 1),
     "l3_1x1_256to1024_G1": (16, 20, 256, 1024, 1, 1, 6, 1),
     "f1_3x3_768": (64, 80, 768, 768, 3, 1, 3, 1),

@@ -129,8 +129,14 @@ __device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
 // (each 32-channel K unit is stored as [32 x hi | 32 x lo] = the same 128 bytes per row as fp32, so addressing, DMA and
 // swizzle are identical) and every K unit is 3 x 2 v_mfma_f32_32x32x16_bf16: lo*hi + hi*lo + hi*hi, fp32 accumulate.
 // Dropping lo*lo leaves ~2^-16 relative error per product: depth RMSE 1.4e-5 vs fp32 over the whole path (bar: 1e-3).
-template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC>
-__global__ void __launch_bounds__(64 * WMW * WNW * WKW)
+// SPEC 1 ("loader waves"): the workgroup has NW extra waves that do nothing but the LDS-DMA of the NW compute waves (loader l
+// issues exactly what compute wave l would) and the compute waves issue no DMA at all.  A wave can issue one 1 KiB DMA per ~64 clk
+// and stalls in-order behind it, so in the small-tile kernels (6 DMAs per wave per 192 clk of MFMA) the DMA issue used to sit on
+// the compute waves' critical path (in-kernel stamps, M=320 layer-3 shapes: 853 clk per stage, 521 clk without the refills,
+// 829 clk without the MFMAs).  One loader and one compute wave share each SIMD; the per-stage s_barrier is the only hand-off:
+// a loader passes it after ITS loads of stage s have landed (its own vmcnt), a compute wave after it has read stage s-1.
+template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC, int SPEC>
+__global__ void __launch_bounds__(64 * WMW * WNW * WKW * (SPEC ? 2 : 1))
 conv_igemm_f32(const ConvArgs a) {
     constexpr int NW = WMW * WNW * WKW, WPK = WMW * WNW;
     constexpr int TM = BM / (32 * WMW), TN = BN / (32 * WNW);
@@ -152,7 +158,10 @@ conv_igemm_f32(const ConvArgs a) {
 #endif
 
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool is_loader = SPEC && wave_all >= NW;              // wave-uniform
+    const bool loads = !SPEC || is_loader;                      // this wave issues DMA
+    const int wave = is_loader ? wave_all - NW : wave_all;      // role-local index: loader l feeds what compute wave l would load
     const int kq = wave / WPK, wq = wave - kq * WPK;
     const int wm = wq / WNW, wn = wq - wm * WNW;
     // XCD-aware workgroup mapping (guide T1).  Workgroup w runs on XCD w % 8 (observed, never relied on for
@@ -216,7 +225,7 @@ conv_igemm_f32(const ConvArgs a) {
 
     const int unit_end = min(units, st_end * WKW);      // past this workgroup's K range every DMA lane fetches zeros
     constexpr int PRO = NS - 1;                      // stages issued before the main loop
-    {
+    if (loads) {
         int ub = unit;
 #pragma unroll
         for (int s = 0; s < PRO; ++s) {
@@ -237,7 +246,10 @@ conv_igemm_f32(const ConvArgs a) {
     const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)a.Wo;
     const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;    // input pixel index == output pixel index
 #pragma unroll
+    for (int j = 0; j < A_J; ++j) { a_off[j] = 0; a_taps[j] = 0u; }
+#pragma unroll
     for (int j = 0; j < A_J; ++j) {
+        if (!loads) break;                               // compute waves of a SPEC kernel never issue DMA
         const int m = m0 + (j * WPK + wq) * 8 + lrow;
         const bool ok = m < a.M;
         const int mm = ok ? m : 0;
@@ -301,7 +313,10 @@ conv_igemm_f32(const ConvArgs a) {
     float* yg = a.y + g * a.y_gs;
     float e_s1[TN], e_b1[TN], e_s2[TN], e_b2[TN];
 #pragma unroll
+    for (int j = 0; j < TN; ++j) { e_s1[j] = 1.f; e_b1[j] = 0.f; e_s2[j] = 1.f; e_b2[j] = 0.f; }
+#pragma unroll
     for (int j = 0; j < TN; ++j) {
+        if (is_loader) break;
         const int n = n0 + wn * 32 * TN + j * 32 + li;
         const bool nok = n < a.Cout;
         const int ni = (int)(g * a.p_gs) + (nok ? n : 0);
@@ -311,7 +326,7 @@ conv_igemm_f32(const ConvArgs a) {
     }
     VIDC_STAMP(11);     // scale/shift loads issued
     float e_res[TM][TN][16];
-    if ((a.flags & VIDC_RESIDUAL) && a.splitk == 1) {    // uniform branch; indices clamped so every load is unconditional
+    if ((a.flags & VIDC_RESIDUAL) && a.splitk == 1 && !is_loader) {    // uniform branch; indices clamped so every load is unconditional
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -341,11 +356,29 @@ conv_igemm_f32(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Every iteration issues exactly one stage (zero-sourced beyond the K range), so the DMA issue code is branch-free
-    // and can be scheduled between MFMAs, and the vmcnt distance is the same in every iteration.
     VIDC_STAMP(0);      // setup done
+    const int n_main = nst > NS - 1 ? nst - (NS - 1) : 0;
+    if constexpr (SPEC) {
+        if (is_loader) {
+            // ---- loader wave: DMA only.  Same issue order as the unspecialised kernel (prologue B..., A..., then A, B per
+            //      iteration), so wait_stage()'s vmcnt arithmetic holds unchanged.  The last NS-1 iterations issue nothing and
+            //      wait for everything, so no DMA is outstanding when the wave ends.
 #pragma unroll
-    for (int s = 0; s < PRO; ++s) { issue_a(s); advance(); }     // the B halves of these stages are already in flight
+            for (int s = 0; s < PRO; ++s) { issue_a(s); advance(); }
+            int slot = 0;
+            for (int s = 0; s < nst; ++s) {
+                wait_stage<NS, A_J, LPS>(s, nst);
+                __builtin_amdgcn_s_barrier();     // stage s is in LDS (every loader waited for its pieces); stage s-1 has been read
+                int fill = slot + NS - 1; if (fill >= NS) fill -= NS;
+                if (s < n_main) { issue_a(fill); issue_b(fill); advance(); }
+                if (++slot == NS) slot = 0;
+            }
+            return;                               // terminated waves do not take part in the barriers of the epilogue
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < PRO; ++s) { issue_a(s); advance(); }     // the B halves of these stages are already in flight
+    }
     VIDC_STAMP(1);      // prologue DMAs issued
 
     // Fragment reads are inline asm: hipcc cannot prove that a ds_read does not alias an in-flight LDS-DMA and would
@@ -367,7 +400,7 @@ conv_igemm_f32(const ConvArgs a) {
         // DMA issue order: prologue B_0..B_{PRO-1}, A_0..A_{PRO-1}, then per iteration A, B.  Stage s < PRO has landed when
         // only the (PRO-1-s) younger prologue A groups and the s stages issued by the loop remain; from s = PRO on, when at
         // most NS-2 whole stages remain.
-        wait_stage<NS, A_J, LPS>(s, nst);
+        if constexpr (!SPEC) wait_stage<NS, A_J, LPS>(s, nst);      // SPEC: the loader waves wait for their DMA before this barrier
         __builtin_amdgcn_s_barrier();     // every wave's pieces of stage s are in LDS; everyone finished stage s-1
         if (s == 0) VIDC_STAMP(2);      // first stage landed
         int fill = slot + NS - 1; if (fill >= NS) fill -= NS;     // the slot read in iteration s-1: free since the barrier
@@ -395,16 +428,22 @@ conv_igemm_f32(const ConvArgs a) {
             for (int t = 0; t < 2; ++t) {
                 if (t == 0) wait_lgkmcnt<2 * (TM + TN)>(); else wait_lgkmcnt<0>();
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (decltype(issue_tag)::value) { if (t == 0) issue_a(fill); else { issue_b(fill); advance(); } }   // among the MFMAs
+#ifndef VIDC_DBG_SKIP_DMA
+                if constexpr (decltype(issue_tag)::value && !SPEC) { if (t == 0) issue_a(fill); else { issue_b(fill); advance(); } }   // among the MFMAs
+#endif
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[t][i]), xl = __builtin_bit_cast(bf16x8, al[t][i]);
                         const bf16x8 wh = __builtin_bit_cast(bf16x8, bh[t][j]), wl = __builtin_bit_cast(bf16x8, bl[t][j]);
+#ifdef VIDC_DBG_SKIP_MFMA
+                        acc[i][j][0] += __builtin_bit_cast(f32x4, xl).x + __builtin_bit_cast(f32x4, wh).x + __builtin_bit_cast(f32x4, xh).x + __builtin_bit_cast(f32x4, wl).x;
+#else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[i][j], 0, 0, 0);
+#endif
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -427,8 +466,10 @@ conv_igemm_f32(const ConvArgs a) {
                     wait_lgkmcnt<0>();
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (sub == 0) issue_a(fill);     // scheduled among the MFMAs below
-                if (sub == 1) { issue_b(fill); advance(); }
+                if constexpr (decltype(issue_tag)::value && !SPEC) {
+                    if (sub == 0) issue_a(fill);     // scheduled among the MFMAs below
+                    if (sub == 1) { issue_b(fill); advance(); }
+                }
     #pragma unroll
                 for (int i = 0; i < TM; ++i)
     #pragma unroll
@@ -443,7 +484,6 @@ conv_igemm_f32(const ConvArgs a) {
         }
         if (++slot == NS) slot = 0;
     };
-    const int n_main = nst > NS - 1 ? nst - (NS - 1) : 0;
     for (int s = 0; s < n_main; ++s) iteration(s, std::true_type{});
     for (int s = n_main; s < nst; ++s) iteration(s, std::false_type{});
 
@@ -630,7 +670,7 @@ __global__ void __launch_bounds__(256) pack_weight_bf16x3_kernel(const float* __
     base[32] = lo;
 }
 
-struct TileInfo { int bm, bn, wmw, wnw, wkw, ns; };
+struct TileInfo { int bm, bn, wmw, wnw, wkw, ns; };   // tiles >= kFirstLoaderTile run with loader waves
 constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {
     {0, 0, 0, 0, 0, 0},
     {128, 128, 2, 2, 1, 2},   // VIDC_TILE_128x128
@@ -646,28 +686,41 @@ constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {
     {32, 32, 1, 1, 4, 4},     // VIDC_TILE_32x32_K4_D4
     {32, 128, 1, 4, 1, 6},    // VIDC_TILE_32x128_D6
     {64, 64, 2, 2, 2, 4},     // VIDC_TILE_64x64_K2_D4
+    // ---- with loader waves (SPEC = 1): same tiles, DMA issued by NW extra waves ----
+    {32, 64, 1, 2, 2, 3},     // VIDC_TILE_32x64_K2_L
+    {32, 64, 1, 2, 2, 5},     // VIDC_TILE_32x64_K2_D5_L
+    {32, 32, 1, 1, 4, 4},     // VIDC_TILE_32x32_K4_D4_L
+    {64, 64, 2, 2, 1, 4},     // VIDC_TILE_64x64_L
+    {64, 64, 2, 2, 2, 4},     // VIDC_TILE_64x64_K2_D4_L   (16 waves)
+    {64, 128, 2, 2, 1, 3},    // VIDC_TILE_64x128_L
+    {128, 64, 2, 2, 1, 3},    // VIDC_TILE_128x64_L
+    // ---- more, narrower weight tiles in flight for the M = 320 layers (HBM-cold weights stream at ~25 B/clk per distinct tile) ----
+    {64, 32, 2, 1, 2, 3},     // VIDC_TILE_64x32_K2
+    {64, 32, 2, 1, 2, 5},     // VIDC_TILE_64x32_K2_D5
+    {64, 32, 2, 1, 2, 5},     // VIDC_TILE_64x32_K2_D5_L
 };
+constexpr int kFirstLoaderTile = VIDC_TILE_32x64_K2_L;
 
-template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC>
+template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC, int SPEC>
 int launch_tile_p(const ConvArgs& a, hipStream_t st) {
-    constexpr int NT = 64 * WMW * WNW * WKW;
+    constexpr int NT = 64 * WMW * WNW * WKW * (SPEC ? 2 : 1);
     constexpr size_t lds = (size_t)NS * (BM + BN) * BK * WKW * sizeof(float);
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
-        VIDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WMW, WNW, WKW, NS, PREC>),
+        VIDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WMW, WNW, WKW, NS, PREC, SPEC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n * a.splitk * a.groups, 1, 1);
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WMW, WNW, WKW, NS, PREC>), grid, dim3(NT), lds, st, a);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WMW, WNW, WKW, NS, PREC, SPEC>), grid, dim3(NT), lds, st, a);
     VIDC_CHECK_LAUNCH("conv_igemm_f32");
     return VIDC_OK;
 }
 
-template <int BM, int BN, int WMW, int WNW, int WKW, int NS>
+template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int SPEC = 0>
 int launch_tile(const ConvArgs& a, hipStream_t st, int precision) {
-    return precision == VIDC_PREC_BF16X3 ? launch_tile_p<BM, BN, WMW, WNW, WKW, NS, 1>(a, st)
-                                         : launch_tile_p<BM, BN, WMW, WNW, WKW, NS, 0>(a, st);
+    return precision == VIDC_PREC_BF16X3 ? launch_tile_p<BM, BN, WMW, WNW, WKW, NS, 1, SPEC>(a, st)
+                                         : launch_tile_p<BM, BN, WMW, WNW, WKW, NS, 0, SPEC>(a, st);
 }
 
 int validate(const vidc_conv_desc* d) {
@@ -709,7 +762,7 @@ extern "C" int vidc_conv2d_plan(vidc_conv_desc* d) {
     const int n_cu = 256;
     double best = 1e30;
     int best_tile = VIDC_TILE_64x64, best_sk = 1;
-    for (int t = 1; t < VIDC_TILE_COUNT; ++t) {
+    for (int t = 1; t < kFirstLoaderTile; ++t) {      // loader-wave variants are chosen by the measured table only
         const TileInfo ti = kTiles[t];
         if (ti.bn > d->Cout && ti.bn > 64) continue;
         const long long tm = (M + ti.bm - 1) / ti.bm, tn = (d->Cout + ti.bn - 1) / ti.bn;
@@ -781,6 +834,16 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         case VIDC_TILE_32x32_K4_D4: rc = launch_tile<32, 32, 1, 1, 4, 4>(a, st, dd.precision); break;
         case VIDC_TILE_32x128_D6:   rc = launch_tile<32, 128, 1, 4, 1, 6>(a, st, dd.precision); break;
         case VIDC_TILE_64x64_K2_D4: rc = launch_tile<64, 64, 2, 2, 2, 4>(a, st, dd.precision); break;
+        case VIDC_TILE_32x64_K2_L:     rc = launch_tile<32, 64, 1, 2, 2, 3, 1>(a, st, dd.precision); break;
+        case VIDC_TILE_32x64_K2_D5_L:  rc = launch_tile<32, 64, 1, 2, 2, 5, 1>(a, st, dd.precision); break;
+        case VIDC_TILE_32x32_K4_D4_L:  rc = launch_tile<32, 32, 1, 1, 4, 4, 1>(a, st, dd.precision); break;
+        case VIDC_TILE_64x64_L:        rc = launch_tile<64, 64, 2, 2, 1, 4, 1>(a, st, dd.precision); break;
+        case VIDC_TILE_64x64_K2_D4_L:  rc = launch_tile<64, 64, 2, 2, 2, 4, 1>(a, st, dd.precision); break;
+        case VIDC_TILE_64x128_L:       rc = launch_tile<64, 128, 2, 2, 1, 3, 1>(a, st, dd.precision); break;
+        case VIDC_TILE_128x64_L:       rc = launch_tile<128, 64, 2, 2, 1, 3, 1>(a, st, dd.precision); break;
+        case VIDC_TILE_64x32_K2:       rc = launch_tile<64, 32, 2, 1, 2, 3>(a, st, dd.precision); break;
+        case VIDC_TILE_64x32_K2_D5:    rc = launch_tile<64, 32, 2, 1, 2, 5>(a, st, dd.precision); break;
+        case VIDC_TILE_64x32_K2_D5_L:  rc = launch_tile<64, 32, 2, 1, 2, 5, 1>(a, st, dd.precision); break;
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
     if (rc != VIDC_OK) return rc;
