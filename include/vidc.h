@@ -222,6 +222,27 @@ int vidc_enrich_scatter(const float* plane_depth, const int32_t* sub, const int3
                         int B, int HW, float* enriched, vidc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * frame pre-processing on the device   (dataset.py:461-510)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* HOST function (no GPU): the coefficient tables of Pillow's Image.resize(..., Image.BILINEAR) for one axis (Resample.c
+ * precompute_coeffs + normalize_coeffs_8bpc): bounds[out][2] = (first input index, tap count), coeffs[out][*ksize_out] 22-bit
+ * fixed point.  Call with bounds = coeffs = NULL to query *ksize_out. */
+int vidc_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* coeffs, int coeffs_capacity, int* ksize_out);
+
+/* color_img.resize((Wo, Ho), resample=Image.BILINEAR) followed by transforms.ToTensor() (dataset.py:470-471), bit-identical on
+ * 8-bit images: src uint8 [B][H][W][C] (device) -> dst float [B][C][Ho][Wo] in [0,1].  Tables from vidc_resize_coeffs, on device. */
+int vidc_resize_bilinear_u8_to_chw(const uint8_t* src_hwc, float* dst_chw, int B, int H, int W, int C, int Ho, int Wo,
+                                   const int32_t* bounds_x, const int32_t* coeffs_x, int ksize_x, const int32_t* bounds_y,
+                                   const int32_t* coeffs_y, int ksize_y, vidc_stream_t stream);
+
+/* The sparse-depth map of dataset.py:495-510: tracks double [N][4] = (id, X, Y, Z) for all images (image b owns rows
+ * offsets[b] .. offsets[b+1]); col = int(fx*X/Z + cx), row = int(fy*Y/Z + cy) in float64, depth[row][col] = Z, a later track
+ * overwrites an earlier one.  depth float [B][H][W] is zero-filled by the call. */
+int vidc_rasterize_sparse_depth(const double* tracks, const int32_t* offsets, int B, double fx, double fy, double cx, double cy,
+                                float* depth, int H, int W, vidc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * programs: a whole network (or the whole frame) as one native call / one hipGraph
  * ---------------------------------------------------------------------------------------------- */
 

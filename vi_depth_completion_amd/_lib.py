@@ -85,6 +85,9 @@ SIGNATURES = {
     "vidc_plane_info_count": (C.c_int, [_i, _i]),
     "vidc_plane_finalize": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
     "vidc_enrich_scatter": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "vidc_resize_coeffs": (C.c_int, [_i, _i, _vp, _vp, _i, C.POINTER(C.c_int)]),
+    "vidc_resize_bilinear_u8_to_chw": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "vidc_rasterize_sparse_depth": (C.c_int, [_vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_double, _vp, _i, _i, _vp]),
     "vidc_program_create": (C.c_int, [C.POINTER(Op), _i, C.POINTER(_vp)]),
     "vidc_program_run": (C.c_int, [_vp, _vp]),
     "vidc_program_capture": (C.c_int, [_vp, _vp]),
