@@ -243,6 +243,20 @@ int vidc_rasterize_sparse_depth(const double* tracks, const int32_t* offsets, in
                                 float* depth, int H, int W, vidc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * evaluation statistics and output conversion on the device   (network_run.py:42-50, 72-82, 198-225, 387-403)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Sufficient statistics of the reference's DEPTH ERROR STATS over the pixels with gt > 0:
+ * stats[0] = n valid, [1] = sum |gt - pred|, [2] = sum (gt - pred)^2, [3..7] = #{max(gt/pred, pred/gt) < 1.05, 1.10, 1.25, 1.25^2,
+ * 1.25^3}; fp64, fixed summation order.  accumulate != 0: added to what stats holds (running totals over a test set).
+ * scratch: vidc_depth_metrics_scratch_bytes(n) bytes. */
+size_t vidc_depth_metrics_scratch_bytes(long long n);
+int vidc_depth_metrics(const float* pred, const float* gt, long long n, double* stats, int accumulate, void* scratch, vidc_stream_t stream);
+
+/* SaveDepthsToImage's pixel conversion: (depths * 1000).astype(np.uint32). */
+int vidc_depth_to_mm_u32(const float* depth, uint32_t* mm, long long n, vidc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * programs: a whole network (or the whole frame) as one native call / one hipGraph
  * ---------------------------------------------------------------------------------------------- */
 

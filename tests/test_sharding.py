@@ -37,8 +37,14 @@ def _worker(rank, world, port, q):
     rec = sharding.metric_record(len(mine), float(rank + 1), sum_sq_err=0.25 * (rank + 1), n_px=100.0)
     allrec = sharding.gather_records(rec)
     dist.barrier()
+    # frame-sharded evaluation: every rank holds the 8 running sums of its own frames; one all_reduce makes the job's totals
+    from vi_depth_completion_amd import evaluation
+    tot = torch.tensor([100.0 * (rank + 1), 10.0 * (rank + 1), 4.0 * (rank + 1), 50.0, 60.0, 70.0, 80.0, 90.0 + rank], dtype=torch.float64)
+    evaluation.all_reduce_totals(tot)
     if rank == 0:
-        q.put(sharding.combine(allrec))
+        res = sharding.combine(allrec)
+        res["eval"] = evaluation.stats_to_figures(tot.numpy())
+        q.put(res)
     dist.destroy_process_group()
 
 
@@ -59,6 +65,9 @@ def test_two_rank_gloo_gather():
     assert res["frames"] == 10.0 and res["seconds"] == 2.0            # max over ranks
     assert abs(res["frames_per_s"] - 5.0) < 1e-12
     assert abs(res["rmse"] - (0.75 / 200.0) ** 0.5) < 1e-12
+    ev = res["eval"]
+    assert ev["n"] == 300 and abs(ev["MAD"] - 30.0 / 300.0) < 1e-12 and abs(ev["RMSE"] - (12.0 / 300.0) ** 0.5) < 1e-12
+    assert abs(ev["1.05"] - 100.0 * 100.0 / 300.0) < 1e-9 and abs(ev["1.25^3"] - 100.0 * 181.0 / 300.0) < 1e-9
 
 
 def test_single_process_paths():

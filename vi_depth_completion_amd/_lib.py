@@ -88,6 +88,9 @@ SIGNATURES = {
     "vidc_resize_coeffs": (C.c_int, [_i, _i, _vp, _vp, _i, C.POINTER(C.c_int)]),
     "vidc_resize_bilinear_u8_to_chw": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "vidc_rasterize_sparse_depth": (C.c_int, [_vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_double, _vp, _i, _i, _vp]),
+    "vidc_depth_metrics_scratch_bytes": (C.c_size_t, [C.c_longlong]),
+    "vidc_depth_metrics": (C.c_int, [_vp, _vp, C.c_longlong, _vp, _i, _vp, _vp]),
+    "vidc_depth_to_mm_u32": (C.c_int, [_vp, _vp, C.c_longlong, _vp]),
     "vidc_program_create": (C.c_int, [C.POINTER(Op), _i, C.POINTER(_vp)]),
     "vidc_program_run": (C.c_int, [_vp, _vp]),
     "vidc_program_capture": (C.c_int, [_vp, _vp]),
