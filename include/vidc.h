@@ -257,6 +257,25 @@ int vidc_depth_metrics(const float* pred, const float* gt, long long n, double* 
 int vidc_depth_to_mm_u32(const float* depth, uint32_t* mm, long long n, vidc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * plane-mask head: the two native kernels it reaches   (plane_mask_detection/maskrcnn_benchmark/csrc)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Greedy non-maximum suppression (csrc/cuda/nms.cu:23-131 incl. its host loop; csrc/cpu/nms_cpu.cpp:5-67), entirely on the device.
+ * boxes_xyxy float [n][4] (16-byte aligned), "+1" area convention; order int32 [n] = box indices by descending score (the reference
+ * sorts with scores.sort(0, descending=True)); a box is suppressed by a kept, higher-scored one when IoU > threshold (inclusive = 0,
+ * nms.cu:57) or IoU >= threshold (inclusive = 1, nms_cpu.cpp:60).  keep int32 [n]: the surviving ORIGINAL indices in ascending
+ * order (like the reference's sorted result), *n_keep their count (device memory).  scratch: vidc_nms_scratch_bytes(n). */
+size_t vidc_nms_scratch_bytes(int n);
+int vidc_nms(const float* boxes_xyxy, const int32_t* order, int n, float threshold, int inclusive, int32_t* keep, int32_t* n_keep,
+             void* scratch, vidc_stream_t stream);
+
+/* ROIAlign forward (csrc/cuda/ROIAlign_cuda.cu:65-176, csrc/cpu/ROIAlign_cpu.cpp:17-218; Caffe2 semantics: no half-pixel shift,
+ * ROIs smaller than 1x1 forced to 1x1, sampling_ratio <= 0 -> ceil(roi / pooled) samples per bin and axis).
+ * x: NHWC [N][H][W][ldx] (C channels used); rois float [K][5] = (batch index, x1, y1, x2, y2); y: [K][pooled_h][pooled_w][C]. */
+int vidc_roi_align_forward(const float* x_nhwc, const float* rois, float* y, int K, int C, int H, int W, int ldx, int pooled_h,
+                           int pooled_w, float spatial_scale, int sampling_ratio, vidc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * programs: a whole network (or the whole frame) as one native call / one hipGraph
  * ---------------------------------------------------------------------------------------------- */
 
