@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--per-op", type=str, default="", help="write the per-op timing table to this file")
+    ap.add_argument("--source", default="", help="WxH of a raw camera stream (e.g. 640x480, 1280x720: BASELINE configs[2], [3]); every step "
+                                                  "then starts from uint8 frames resident in HBM and includes the device-side pre-processing "
+                                                  "(PIL-exact resize + ToTensor, sparse-point rasterisation) of SURVEY 8f-2")
     ap.add_argument("--mode", choices=("interleaved", "streams", "sequential"), default="interleaved",
                     help="interleaved: software pipeline over frames (pipeline.run_interleaved: tick t = surface-normal net of frame t "
                          "+ depth-completion net of frame t-1 as one 4-group program); streams: --in-flight frames on separate HIP "
@@ -118,20 +121,36 @@ def main():
 
     # frame f of the job is a function of (seed, f) only: rank r takes frames r, r+world, ... (round-robin shards)
     pool = []
+    pre = None
+    if args.source:
+        from vi_depth_completion_amd.preprocess import FramePreprocessor
+        sw_, sh_ = (int(v) for v in args.source.lower().split("x"))
+        pre = FramePreprocessor(dev, in_hw=(sh_, sw_), out_hw=(H, W), cc=(S.DEMO_CC[0], S.DEMO_CC[1] * H / 240.0))
     for j in range(args.pool):
-        b = S.synthetic_batch(B, H, W, 1234, frame0=(rank + j * world) * B)
-        pool.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()})
+        if pre is not None:
+            cam = S.synthetic_camera_batch(B, sh_, sw_, 1234, frame0=(rank + j * world) * B, out_hw=(H, W))
+            cam["image_u8"] = cam["image_u8"].to(dev)            # the frames are resident in HBM; tracks / gravity are host data like in the reference
+            pool.append(cam)
+        else:
+            b = S.synthetic_batch(B, H, W, 1234, frame0=(rank + j * world) * B)
+            pool.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()})
+
+    def frames(n):
+        """the n input batches of a run; with --source each one goes through the device-side pre-processing inside the timed region"""
+        for i in range(n):
+            item = pool[i % len(pool)]
+            yield pre(item["image_u8"], item["gravity_raw"], item["klt_tracks"]) if pre is not None else item
 
     def run(n):
         """n steps (= n frames of batch B through the whole hot path); all n outputs are complete on return."""
         if args.mode == "sequential" or (args.mode == "streams" and args.in_flight <= 1):
-            for i in range(n):
-                out = pipe._call_cnn(pool[i % len(pool)])
+            for b_ in frames(n):
+                out = pipe._call_cnn(b_)
         elif args.mode == "streams":
-            for out in pipe.run_stream((pool[i % len(pool)] for i in range(n)), in_flight=args.in_flight):
+            for out in pipe.run_stream(frames(n), in_flight=args.in_flight):
                 pass
         else:       # n frames = n + 1 pipeline ticks, all inside the timed region
-            for out in pipe.run_interleaved(pool[i % len(pool)] for i in range(n)):
+            for out in pipe.run_interleaved(frames(n)):
                 pass
         return out
 
@@ -227,7 +246,7 @@ def main():
         hb = S.synthetic_batch(B, H, W, 1234, frame0=rank * B)
         ref = O.call_cnn(cpu_sn, cpu_dc, hb, masks, intr, 200, rng=np.random.RandomState(77))   # also the warm-up
         pipe.rng = np.random.RandomState(77)
-        got = pipe._call_cnn(pool[0]).cpu()
+        got = pipe._call_cnn(next(frames(1)) if pre is None else {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in hb.items()}).cpu()
         sq_err, n_px = float((got - ref).double().pow(2).sum()), float(ref.numel())
         tc = time.perf_counter()
         for j in range(args.cpu_frames):
@@ -250,8 +269,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if os.environ.get("VIDC_PRECISION", "mixed") == "fp32" else "f32+bf16x3"), "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic %dx%d RGB + 200-pt sparse depth, batch %d per GPU, plane mask "
-                                   "fixed; warp + surface-normal net + plane block/enrichment + depth-completion net" % (W, H, B),
+            "config": {"workload": (("BASELINE configs[1]: synthetic %dx%d RGB + 200-pt sparse depth, batch %d per GPU, plane mask "
+                                    "fixed; warp + surface-normal net + plane block/enrichment + depth-completion net" % (W, H, B)) if not args.source else
+                                   ("%s uint8 camera stream + 200 VI-SLAM tracks per frame, batch %d per GPU, plane mask fixed; device-side "
+                                    "pre-processing (PIL-exact resize to %dx%d, rasterisation) + warp + surface-normal net + plane "
+                                    "block/enrichment + depth-completion net" % (args.source, B, W, H))),
                        "height": H, "width": W, "batch_per_gpu": B, "weights": "seeded random-init (seed 1234)",
                        "mode": args.mode, "frames_in_flight": (2 if args.mode == "interleaved" else args.in_flight if args.mode == "streams" else 1),
                        "sharding": "frames round-robin over %d rank(s), no data-path collective" % world},

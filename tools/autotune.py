@@ -139,13 +139,15 @@ def main():
                             for sk in [int(v) for v in a.splitk.split(",")]:
                                 if sk > 1 and (d.KH * d.KW * d.Cin // 32) // sk < 2:
                                     continue
-                                if sk * d.groups * M * d.Cout > ws.numel():
+                                if sk > 1 and sk * d.groups * M * d.Cout > ws.numel():
                                     continue
                                 d.tile, d.splitk = t, sk
                                 us = time_desc(lib, d, st, pool, junk)
                                 if us is not None:
                                     cands.append((us, t, sk))
                         cands.sort()
+                        if not cands:
+                            raise RuntimeError("no tiling ran for %s (precision %d): %s" % (sig, prec, lib.vidc_last_error().decode()))
                         best[prec] = cands[0]
                     # a bf16x3 conv needs its input split first (shared between consumers at best; charged in full here)
                     rows = d.B * d.H * d.W

@@ -46,10 +46,18 @@ __device__ inline T block_sum(T v, T* red) {
     return s;
 }
 
-__device__ inline int first_argmax(const int32_t* c, int n) {   // torch.argmax: first maximal index
-    int best = 0, bc = -1;
-    for (int h = 0; h < n; ++h) if (c[h] > bc) { bc = c[h]; best = h; }
-    return best;
+// torch.argmax (first maximal index) over n >= 0 non-negative counts, computed by ONE WHOLE WAVE (all 64 lanes must call it):
+// lane l scans l, l+64, ...; ties resolve to the smaller index in the lane scan and in the shuffle tree.  Same value in every lane.
+__device__ inline int first_argmax(const int32_t* c, int n) {
+    const int lane = threadIdx.x & 63;
+    int best = 0x7fffffff, bc = -1;
+    for (int h = lane; h < n; h += 64) { const int v = c[h]; if (v > bc) { bc = v; best = h; } }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int oc = __shfl_xor(bc, off, 64), ob = __shfl_xor(best, off, 64);
+        if (oc > bc || (oc == bc && ob < best)) { bc = oc; best = ob; }
+    }
+    return n > 0 ? best : 0;
 }
 
 // ---- stage 1a: inlier counts of every hypothesis.  threads = hypotheses, 256 pixels of one slot staged in LDS ---------
@@ -89,7 +97,10 @@ ransac_mask_kernel(const float* __restrict__ normals, const uint8_t* __restrict_
     __shared__ int s_best;
     const Slot s = slots[blockIdx.y];
     const float* nb = normals + (size_t)s.b * 3 * HW;
-    if (threadIdx.x == 0) s_best = first_argmax(counts + blockIdx.y * VIDC_MAX_HYP, s.n_hyp);
+    if (threadIdx.x < 64) {
+        const int bst = first_argmax(counts + blockIdx.y * VIDC_MAX_HYP, s.n_hyp);
+        if (threadIdx.x == 0) s_best = bst;
+    }
     __syncthreads();
     const int bp = s.n_hyp > 0 ? hyp_pix[s.hyp_off + s_best] : 0;
     const float hx = nb[bp], hy = nb[HW + bp], hz = nb[2 * HW + bp];
@@ -171,11 +182,14 @@ plane_offset_kernel(const float* __restrict__ homo, const float* __restrict__ de
     asum = block_sum(asum, redf);
     const float mean_angle = n_in > 0 ? asum / (float)n_in : 0.f;
     const bool accepted = n_in > 0 && !(mean_angle > ANGLE_THR);            // main.py:162
-    if (threadIdx.x == 0) {
-        rec[0] = mx; rec[1] = my; rec[2] = mz; rec[3] = 0.f; rec[4] = (float)n_in; rec[5] = mean_angle; rec[6] = accepted ? 1.f : 0.f;
-        for (int i = 7; i < VIDC_PLANE_RECORD; ++i) rec[i] = 0.f;
-        rec[12] = (float)first_argmax(counts + blockIdx.x * VIDC_MAX_HYP, s.n_hyp);
-        s_n = 0; s_dsum = 0.f;
+    if (threadIdx.x < 64) {
+        const int bst = first_argmax(counts + blockIdx.x * VIDC_MAX_HYP, s.n_hyp);
+        if (threadIdx.x == 0) {
+            rec[0] = mx; rec[1] = my; rec[2] = mz; rec[3] = 0.f; rec[4] = (float)n_in; rec[5] = mean_angle; rec[6] = accepted ? 1.f : 0.f;
+            for (int i = 7; i < VIDC_PLANE_RECORD; ++i) rec[i] = 0.f;
+            rec[12] = (float)bst;
+            s_n = 0; s_dsum = 0.f;
+        }
     }
     __syncthreads();
     if (!accepted) return;
@@ -233,7 +247,10 @@ plane_offset_kernel(const float* __restrict__ homo, const float* __restrict__ de
             hcnt[j] = c;
         }
         __syncthreads();
-        if (threadIdx.x == 0) s_best = first_argmax(hcnt, n_pts);
+        if (threadIdx.x < 64) {
+            const int bst = first_argmax(hcnt, n_pts);
+            if (threadIdx.x == 0) s_best = bst;
+        }
         __syncthreads();
         const float hyp = -dots[s_best];
         float sdot = 0.f; int c = 0;
@@ -251,29 +268,35 @@ plane_offset_kernel(const float* __restrict__ homo, const float* __restrict__ de
     }
 }
 
-// Row-major list of the pixels with depth > 0 of every image (one workgroup per image; each thread owns a contiguous run).
+// Row-major list of the pixels with depth > 0 of every image.  One workgroup per image walks the map 1024 pixels at a time with
+// coalesced loads; the ordered compaction of a step is a ballot + popcount per wave and a 16-entry scan across the waves.
 __global__ void __launch_bounds__(1024)
 sparse_list_kernel(const float* __restrict__ depth, int HW, int max_sparse, int32_t* __restrict__ sparse_idx,
                    int32_t* __restrict__ n_sparse) {
-    __shared__ int scan[1024];
-    const int b = blockIdx.x;
+    __shared__ int wcount[16];
+    __shared__ int base;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float* db = depth + (size_t)b * HW;
-    const int per = vidc::cdiv(HW, 1024);
-    const int p0 = threadIdx.x * per, p1 = min(HW, p0 + per);
-    int mine = 0;
-    for (int p = p0; p < p1; ++p) mine += db[p] > 0.f;
-    scan[threadIdx.x] = mine;
+    if (threadIdx.x == 0) base = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = (int)threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+    for (int p0 = 0; p0 < HW; p0 += 1024) {
+        const int p = p0 + threadIdx.x;
+        const bool f = p < HW && db[p] > 0.f;
+        const unsigned long long bal = __ballot(f);
+        if (lane == 0) wcount[wv] = __popcll(bal);
         __syncthreads();
-        scan[threadIdx.x] += v;
+        int k = base + __popcll(bal & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wv; ++w) k += wcount[w];
+        if (f && k < max_sparse) sparse_idx[(size_t)b * max_sparse + k] = p;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wcount[w];
+            base += t;
+        }
         __syncthreads();
     }
-    int k = scan[threadIdx.x] - mine;
-    for (int p = p0; p < p1 && mine; ++p)
-        if (db[p] > 0.f) { if (k < max_sparse) sparse_idx[(size_t)b * max_sparse + k] = p; ++k; }
-    if (threadIdx.x == 1023) n_sparse[b] = scan[1023];
+    if (threadIdx.x == 0) n_sparse[b] = base;
 }
 
 // ---- stage 3: depth = -d / (n . homo) on the plane: per-chunk validity statistics, then the masked write ---------------

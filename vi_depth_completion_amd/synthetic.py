@@ -187,3 +187,26 @@ def synthetic_batch(batch, height=240, width=320, seed=1234, n_sparse=200, frame
         "homogeneous_coordinates": homo.unsqueeze(0).repeat(batch, 1, 1, 1),
         "color_filename": ["color_%06d.png" % f for f in range(frame0, frame0 + batch)],
     }
+
+
+def synthetic_camera_batch(batch, src_height=480, src_width=640, seed=1234, n_sparse=200, frame0=0, out_hw=(240, 320)):
+    """Raw camera-side inputs of a stream (BASELINE configs[2], [3]: "640x480 stream", "1280x720"), i.e. what DemoDataset reads from
+    disk before its own pre-processing (dataset.py:461-510): uint8 RGB frames (B,H,W,3), the raw gravity file values (B,3) (the loader
+    negates y and z) and per frame a (n,4) float64 array of VI-SLAM tracks (id, X, Y, Z) whose projections fall inside the
+    out_hw image.  Frame f is a function of (seed, frame0+f) only."""
+    imgs, gravs, tracks = [], [], []
+    Ho, Wo = out_hw
+    for f in range(frame0, frame0 + batch):
+        tag = "cam%d" % f
+        imgs.append((uniform01(seed, tag + ".image", (src_height, src_width, 3)) * 256.0).clamp_(max=255.0).to(torch.uint8))
+        n = normal01(seed, tag + ".g", (2,))
+        g = torch.tensor([0.08 * float(n[0]), 1.0, 0.12 * float(n[1])], dtype=torch.float64)
+        g = (g / g.norm()).numpy()
+        gravs.append([g[0], -g[1], -g[2]])
+        u = uniform01(seed, tag + ".uv", (n_sparse, 2)).double().numpy()
+        z = (uniform01(seed, tag + ".z", (n_sparse,)).double() * 4.5 + 0.5).numpy()
+        col, row = u[:, 0] * (Wo - 1) + 0.5, u[:, 1] * (Ho - 1) + 0.5
+        x = (col - DEMO_CC[0]) / DEMO_FC[0] * z
+        y = (row - DEMO_CC[1] * Ho / 240.0) / DEMO_FC[1] * z
+        tracks.append(np.stack([np.arange(n_sparse, dtype=np.float64), x, y, z], axis=1))
+    return {"image_u8": torch.stack(imgs), "gravity_raw": np.asarray(gravs, dtype=np.float64), "klt_tracks": tracks}
