@@ -457,6 +457,94 @@ def test_plane_block_vs_golden(pipeline, golden_dir, name):
         assert np.abs(e[rc[:, 0], rc[:, 1]] - f["enriched_val"]).max() < 1e-3
 
 
+def _plane_scene(seed, H=240, W=320, n_sparse=200, noise=0.02):
+    """Synthetic room: unit normals that are piecewise constant (+ noise) over the id map's regions, depths consistent with planes
+    n.X + d = 0 so that the RANSAC stages accept them.  Returns (normals (1,3,H,W), sparse depth (1,1,H,W), homo (1,H,W,3))."""
+    g = torch.Generator().manual_seed(seed)
+    homo = S.homogeneous_grid(S.DEMO_FC, S.DEMO_CC, W, H)
+    ids = torch.from_numpy(S.plane_id_map(H, W).astype(np.int64))
+    nrm = torch.zeros(H, W, 3)
+    truth = {0: (torch.tensor([0.0, 0.0, -1.0]), 3.0), 1: (torch.tensor([0.0, -0.8, -0.6]), 1.5), 2: (torch.tensor([0.6, 0.0, -0.8]), 2.5)}
+    depth_full = torch.zeros(H, W)
+    for cls, (n, d) in truth.items():
+        m = ids == cls
+        nrm[m] = n
+        depth_full[m] = (-d / (homo[m] @ n)).clamp(0.3, 9.0)          # z such that n.(homo*z) + d = 0
+    nrm = torch.nn.functional.normalize(nrm + noise * torch.randn(H, W, 3, generator=g), dim=2)
+    sd = torch.zeros(H * W)
+    pos = torch.randperm(H * W, generator=g)[:n_sparse]
+    sd[pos] = depth_full.reshape(-1)[pos]
+    return nrm.permute(2, 0, 1)[None].contiguous(), sd.view(1, 1, H, W), homo[None]
+
+
+@pytest.mark.parametrize("case", ["two_planes", "background_only", "plane_without_points", "tiny_plane", "no_sparse_depth", "very_noisy_normals"])
+def test_plane_block_edge_cases_vs_oracle(pipeline, case):
+    """The plane block (main.py:130-190) on the shapes of input the reference's loop special-cases: only background (returns its
+    input, :135-137), a plane no sparse point falls on (offset RANSAC gets nothing, :176-178), a plane smaller than the 300
+    hypotheses, no sparse depth at all, and very noisy normals (few inliers per hypothesis).  HIP vs the CPU oracle with the same RNG
+    stream."""
+    normals, ds, homo = _plane_scene(7, noise=0.9 if case == "very_noisy_normals" else 0.02)
+    ids = S.plane_id_map(240, 320).copy()
+    if case == "background_only":
+        ids[:] = 0
+    elif case == "plane_without_points":
+        ds = ds.clone()
+        ds[0, 0][torch.from_numpy(ids == 2)] = 0.0
+    elif case == "tiny_plane":
+        ids[:] = 0
+        ids[100:108, 50:70] = 3                                            # 160 pixels < 300 hypotheses
+        ds = ds.clone()
+        ds[0, 0, 101, 55], ds[0, 0, 105, 66] = 2.0, 2.1
+    elif case == "no_sparse_depth":
+        ds = torch.zeros_like(ds)
+    want = O.extract_plane_depth(normals[0], torch.from_numpy(ids.astype(np.int64)), ds[0, 0], homo[0], rng=np.random.RandomState(3))
+    di, info = pipeline.planes.plane_depth(normals.to(DEV), [ids], ds.to(DEV), homo.to(DEV), rng=np.random.RandomState(3))
+    got = di[0, 0].cpu()
+    written_w, written_g = (want > 0) & (ds[0, 0] == 0), (got > 0) & (ds[0, 0] == 0)
+    # same planes written (allow a handful of threshold-borderline pixels), same values where both wrote
+    assert int((written_w != written_g).sum()) <= 5, (int(written_w.sum()), int(written_g.sum()))
+    both = written_w & written_g
+    if both.any():
+        assert ((got - want)[both].abs() / want[both].clamp(min=1.0)).max() < 2e-3
+    assert torch.equal(got[ds[0, 0] > 0], ds[0, 0][ds[0, 0] > 0])          # the original sparse depths always win (:186-187)
+    if case in ("background_only", "no_sparse_depth"):
+        assert int(written_g.sum()) == 0
+    if case == "two_planes":
+        assert int(written_g.sum()) > 10000
+    # enrichment on top: same candidate count -> same draws -> same pixels
+    nnz_w = int((want > 0).sum())
+    en = pipeline.planes.enrich(ds.to(DEV), di, info, 200, rng=np.random.RandomState(4))
+    if int(pipeline.planes.last_nnz[0]) == nnz_w:
+        want_en = O.enrich_sparse_depth(ds, want[None, None], 200, rng=np.random.RandomState(4))
+        assert torch.equal((en.cpu() > 0), (want_en > 0))
+
+
+def test_plane_with_more_than_300_points_is_refused(pipeline):
+    """plane_offset_ransac subsamples with a host permutation above 300 points (main.py:78); that branch is not on the device:
+    the path must say so instead of returning something else."""
+    normals, ds, homo = _plane_scene(9, n_sparse=3000)
+    ids = S.plane_id_map(240, 320)
+    di, info = pipeline.planes.plane_depth(normals.to(DEV), [ids], ds.to(DEV), homo.to(DEV), rng=np.random.RandomState(3))
+    with pytest.raises(NotImplementedError, match="300"):
+        pipeline.planes.enrich(ds.to(DEV), di, info, 200, rng=np.random.RandomState(4))
+
+
+def test_enriched_samples_zero_skips_the_plane_block(pipeline, seeded_weights):
+    """--enriched_samples 0 (main.py:273-275): the depth network gets the raw sparse depth; both modes."""
+    batch = S.synthetic_batch(1, 240, 320, 1234, frame0=11)
+    saved = pipeline.args.enriched_samples
+    try:
+        pipeline.args.enriched_samples = 0
+        a = pipeline._call_cnn(batch).cpu()
+        nrm = pipeline.surface_normal_cnn(batch["image"].to(DEV), batch["gravity"].to(DEV), batch["aligned_direction"].to(DEV))
+        b = pipeline.cnn(batch["image"].to(DEV), nrm, batch["sparse_depth"].to(DEV)).cpu()
+        assert torch.equal(a, b)
+        c = [o.cpu() for o in pipeline.run_interleaved(iter([{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}] * 2))]
+        assert float((c[0] - a).pow(2).mean().sqrt()) < 1e-3 and torch.equal(c[0], c[1])
+    finally:
+        pipeline.args.enriched_samples = saved
+
+
 @pytest.mark.parametrize("name", GOLDEN_FRAMES)
 def test_full_path_vs_golden(pipeline, golden_dir, name):
     """The whole _call_cnn (main.py:261-298): RMSE vs the reference's depth <= 1e-3 (north_star bar)."""
