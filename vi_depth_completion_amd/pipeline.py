@@ -172,7 +172,11 @@ class DepthCompletionPipeline:
                 rgb = batch["image"].to(dev, non_blocking=True)
                 ds = batch["sparse_depth"].to(dev, non_blocking=True)
                 B, _, H, W = rgb.shape
+                if prog is not None and (B, H, W) != shape0:
+                    raise ValueError("run_interleaved: all batches of a stream must have the same shape (got %s after %s); "
+                                     "start a new stream for the remainder" % ((B, H, W), shape0))
                 if prog is None:
+                    shape0 = (B, H, W)
                     prog = self.frame_program(B, H, W)
                     self.surface_normal_cnn._check(rgb)
                     self.cnn._check(rgb)
