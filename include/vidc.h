@@ -107,7 +107,7 @@ typedef struct vidc_conv_desc {
     int32_t precision;     /* vidc_conv_precision: with VIDC_PREC_BF16X3, x and w are the
                               hi|lo bf16 images made by vidc_split_bf16x3 /
                               vidc_pack_conv_weight_bf16x3 (same strides as fp32)     */
-    int32_t reserved0;
+    int32_t dilation;      /* tap spacing of the kernel (nn.Conv2d dilation); 0 or 1 = dense                  */
     void* y_split;         /* split-bf16 image of y (VIDC_SPLIT_OUT), or NULL         */
 } vidc_conv_desc;
 
@@ -155,6 +155,14 @@ int vidc_upsample_bilinear_ac(const float* x, float* y, int B, int h, int w, int
  * convs read (layout: vidc_split_bf16x3), with the same row stride ldy (a multiple of 32) -- saves the separate split
  * launch.  maxpool / stem: y may then be NULL (no fp32 copy); upsample: VIDC_UP_NO_F32_OUT.  stem: y_split is the image of
  * the whole [.., ldy] tensor and split_ch0 the first channel this launch writes (y itself points at that channel). */
+
+/* nn.AvgPool2d((kh,kw), stride=(sh,sw), padding=(ph,pw)), count_include_pad=True, on NHWC (FullImageEncoder.global_pooling,
+ * networks/surface_normal_dorn.py:10).  Ho = (H + 2ph - kh) / sh + 1, Wo likewise. */
+int vidc_avgpool2d(const float* x, float* y, int B, int H, int W, int C, int ldx, int kh, int kw, int sh, int sw, int ph, int pw, int ldy,
+                   vidc_stream_t stream);
+
+/* torch.nn.functional.normalize(x, dim=1) on NCHW [B][C][HW] (networks/surface_normal_dorn.py:154). */
+int vidc_normalize_nchw(const float* x, float* y, int B, int C, int HW, vidc_stream_t stream);
 
 /* Prediction head tail: 1x1 conv Cin -> Cout (Cout <= 4) with zero padding `pad` (the reference's
  * Conv2d(192,1,1,1,1), depth_completion.py:144, pads a 1x1 conv -> 62x82 map whose border equals the bias),
@@ -280,7 +288,8 @@ int vidc_roi_align_forward(const float* x_nhwc, const float* rois, float* y, int
  * ---------------------------------------------------------------------------------------------- */
 
 enum vidc_op_kind { VIDC_OP_CONV = 1, VIDC_OP_STEM = 2, VIDC_OP_MAXPOOL = 3, VIDC_OP_UPSAMPLE = 4, VIDC_OP_HEAD = 5,
-                    VIDC_OP_WARP_PARAMS = 6, VIDC_OP_WARP_FWD = 7, VIDC_OP_WARP_INV = 8, VIDC_OP_COPY = 9, VIDC_OP_SPLIT = 10 };
+                    VIDC_OP_WARP_PARAMS = 6, VIDC_OP_WARP_FWD = 7, VIDC_OP_WARP_INV = 8, VIDC_OP_COPY = 9, VIDC_OP_SPLIT = 10,
+                    VIDC_OP_AVGPOOL = 11, VIDC_OP_NORMALIZE = 12 };
 
 typedef struct vidc_generic_args {   /* arguments of the non-conv launchers, in declaration order */
     const void* p[6];

@@ -252,6 +252,41 @@ def depth_completion_forward(sd, image, normal, depth, taps=None):
 # ----------------------------------------------------------------------------------------------
 # Plane block (normal -> plane -> depth projection) and sparse-depth enrichment
 # ----------------------------------------------------------------------------------------------
+def dorn_forward(sd, x, taps=None):
+    """SurfaceNormalDORN.forward (networks/surface_normal_dorn.py:151-154): ResNet (:130-141, layer3/4 at stride 1, :119-125) ->
+    SceneUnderstandingModuleBN (:79-89) with FullImageEncoder (:18-30) -> F.normalize.  Eval mode: Dropout2d is the identity."""
+    p = "feature_extractor."
+    t = F.relu(_conv(x, sd, p + "conv1.conv1_1", 2, 1))
+    t = F.relu(_bn(_conv(t, sd, p + "conv1.conv1_2", 1, 1), sd, p + "conv1.bn_2"))
+    t = F.relu(_bn(_conv(t, sd, p + "conv1.conv1_3", 1, 1), sd, p + "conv1.bn1_3"))
+    t = F.relu(_bn(t, sd, p + "bn1"))
+    t = F.max_pool2d(t, 3, 2, 1)
+    for li, (n, stride) in enumerate(zip((3, 4, 23, 3), (1, 2, 1, 1)), start=1):
+        for bi in range(n):
+            t = _bottleneck(t, sd, "%slayer%d.%d." % (p, li, bi), stride if bi == 0 else 1)
+    if taps is not None:
+        taps["features"] = t
+    a = "aspp_module."
+    e = F.avg_pool2d(t, 8, stride=8, padding=(1, 0))
+    e = F.relu(F.linear(e.reshape(-1, 2048 * 4 * 5), sd[a + "encoder.global_fc.weight"], sd[a + "encoder.global_fc.bias"]))
+    e = F.conv2d(e.view(-1, 512, 1, 1), sd[a + "encoder.conv1.weight"], sd[a + "encoder.conv1.bias"])
+    x1 = F.interpolate(e, size=(t.shape[2], t.shape[3]), mode="bilinear", align_corners=True)
+    outs = [x1]
+    for name, dil in (("aspp1", 0), ("aspp2", 6), ("aspp3", 12), ("aspp4", 18)):
+        w, b = sd[a + name + ".0.weight"], sd[a + name + ".0.bias"]
+        u = F.conv2d(t, w, b) if dil == 0 else F.conv2d(t, w, b, padding=dil, dilation=dil)
+        u = F.relu(_bn(u, sd, a + name + ".1"))
+        u = F.relu(_bn(F.conv2d(u, sd[a + name + ".3.weight"], sd[a + name + ".3.bias"]), sd, a + name + ".4"))
+        outs.append(u)
+    c = torch.cat(outs, dim=1)
+    if taps is not None:
+        taps["concat"] = c
+    h = F.relu(F.conv2d(c, sd[a + "concat_process.1.weight"], sd[a + "concat_process.1.bias"]))
+    y = F.conv2d(h, sd[a + "concat_process.4.weight"], sd[a + "concat_process.4.bias"])
+    y = F.interpolate(y, size=(x.shape[2], x.shape[3]), mode="bilinear", align_corners=True)
+    return F.normalize(y, dim=1)
+
+
 def mean_normal(n):
     return F.normalize(n.mean(dim=0), dim=0)
 

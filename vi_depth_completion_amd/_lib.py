@@ -20,7 +20,7 @@ MAX_SEGMENTS = 4
 # vidc_conv_flags / vidc_up_flags / vidc_op_kind / vidc_conv_tile
 RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM, SPLIT_OUT, NO_F32_OUT = 1, 2, 4, 8, 16, 32, 64, 128
 UP_RELU, UP_ACCUM, UP_NO_F32_OUT = 1, 2, 4
-OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY, OP_SPLIT = range(1, 11)
+OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY, OP_SPLIT, OP_AVGPOOL, OP_NORMALIZE = range(1, 13)
 TILE_AUTO = 0
 TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "64x64k2", 6: "32x64k2", 7: "32x32k4", 8: "32x128",
               9: "32x32k8", 10: "32x64k2d5", 11: "32x32k4d4", 12: "32x128d6", 13: "64x64k2d4", 14: "32x64k2L", 15: "32x64k2d5L", 16: "32x32k4d4L", 17: "64x64L", 18: "64x64k2d4L",
@@ -41,7 +41,7 @@ class ConvDesc(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("flags", C.c_int32), ("groups", C.c_int32),
         ("x_gs", C.c_int64), ("w_gs", C.c_int64), ("y_gs", C.c_int64), ("r_gs", C.c_int64), ("p_gs", C.c_int64),
-        ("tile", C.c_int32), ("splitk", C.c_int32), ("precision", C.c_int32), ("reserved0", C.c_int32),
+        ("tile", C.c_int32), ("splitk", C.c_int32), ("precision", C.c_int32), ("dilation", C.c_int32),
         ("y_split", C.c_void_p),
     ]
 
@@ -77,6 +77,8 @@ SIGNATURES = {
     "vidc_stem_conv3x3s2": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "vidc_maxpool3x3s2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vidc_upsample_bilinear_ac": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "vidc_avgpool2d": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vidc_normalize_nchw": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "vidc_head_conv1x1_upsample": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_plane_scratch_bytes": (C.c_size_t, [_i, _i, _i]),
     "vidc_plane_ransac_normal": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -27,7 +27,7 @@ struct ConvArgs {
     const float* x; const float* w; float* y;
     const float* scale1; const float* shift1; const float* scale2; const float* shift2;
     const float* residual; float* ws; unsigned short* y_split;
-    int B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, ldr, KH, KW, stride, pad, flags, groups;
+    int B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, ldr, KH, KW, stride, pad, flags, groups, dil;
     long long x_gs, w_gs, y_gs, r_gs, p_gs;
     int M, K, ksteps, splitk, tiles_m, tiles_n;
     unsigned dv_tiles_m[3], dv_splitk[3], dv_tiles_n[3], dv_ntaps[3], dv_kw[3];   // {multiplier, shift, d == 1 mask} of fast_div()
@@ -267,9 +267,9 @@ conv_igemm_f32(const ConvArgs a) {
         const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
         unsigned colm = 0, taps = 0;                     // KH + KW steps instead of KH * KW; KH, KW <= 3 (validate())
 #pragma unroll
-        for (int tw = 0; tw < 3; ++tw) colm |= (tw < a.KW && (unsigned)(ix0 + tw) < (unsigned)a.W) ? 1u << tw : 0u;
+        for (int tw = 0; tw < 3; ++tw) colm |= (tw < a.KW && (unsigned)(ix0 + tw * a.dil) < (unsigned)a.W) ? 1u << tw : 0u;
 #pragma unroll
-        for (int th = 0; th < 3; ++th) taps |= (th < a.KH && (unsigned)(iy0 + th) < (unsigned)a.H) ? colm << (th * a.KW) : 0u;
+        for (int th = 0; th < 3; ++th) taps |= (th < a.KH && (unsigned)(iy0 + th * a.dil) < (unsigned)a.H) ? colm << (th * a.KW) : 0u;
         a_taps[j] = ok ? taps : 0u;
         a_off[j] = (((b * a.H + iy0) * a.W + ix0) * a.ldx + csw) * 4;
     }
@@ -280,7 +280,7 @@ conv_igemm_f32(const ConvArgs a) {
         float* sbase = smem + slot * STAGE;
         const unsigned tapbit = unit < unit_end ? 1u << tap : 0u;
         const int kh = (int)fast_div((unsigned)tap, a.dv_kw), kw = tap - kh * a.KW;
-        const int tap_off = (((kh * a.W + kw) * a.ldx) + cc * BK) * 4;
+        const int tap_off = ((((kh * a.W + kw) * a.dil) * a.ldx) + cc * BK) * 4;      // dilated taps (ASPP, surface_normal_dorn.py:46-62)
 #pragma unroll
         for (int j = 0; j < A_J; ++j) {
             const unsigned voff = (a_taps[j] & tapbit) ? (unsigned)(a_off[j] + tap_off) : OOB;
@@ -732,8 +732,12 @@ int validate(const vidc_conv_desc* d) {
     VIDC_REQUIRE(d->ldx >= d->Cin && d->ldy >= d->Cout && d->ldx % 4 == 0, VIDC_ERR_SHAPE, "conv: bad channel strides");
     VIDC_REQUIRE(d->KH >= 1 && d->KW >= 1 && d->KH <= 3 && d->KW <= 3 && d->stride >= 1 && d->pad >= 0, VIDC_ERR_SHAPE,
                  "conv: bad kernel geometry (kernels up to 3x3)");
-    VIDC_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
-                 VIDC_ERR_SHAPE, "conv: Ho/Wo inconsistent with H/W, kernel, stride, pad");
+    {
+        const int dil = d->dilation > 1 ? d->dilation : 1;
+        VIDC_REQUIRE(d->dilation >= 0 && d->Ho == (d->H + 2 * d->pad - dil * (d->KH - 1) - 1) / d->stride + 1 &&
+                         d->Wo == (d->W + 2 * d->pad - dil * (d->KW - 1) - 1) / d->stride + 1,
+                     VIDC_ERR_SHAPE, "conv: Ho/Wo inconsistent with H/W, kernel, stride, pad, dilation");
+    }
     VIDC_REQUIRE(d->groups >= 1 && d->splitk >= 1, VIDC_ERR_SHAPE, "conv: groups/splitk must be >= 1");
     VIDC_REQUIRE(!(d->flags & VIDC_AFFINE2) || (d->scale2 && d->shift2), VIDC_ERR_NULL, "conv: AFFINE2 without scale2/shift2");
     VIDC_REQUIRE(!(d->flags & VIDC_RESIDUAL) || (d->residual && d->ldr >= d->Cout), VIDC_ERR_NULL, "conv: RESIDUAL without tensor");
@@ -803,7 +807,7 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
     a.residual = dd.residual; a.ws = dd.workspace; a.y_split = reinterpret_cast<unsigned short*>(dd.y_split);
     a.B = dd.B; a.H = dd.H; a.W = dd.W; a.Cin = dd.Cin; a.ldx = dd.ldx; a.Ho = dd.Ho; a.Wo = dd.Wo; a.Cout = dd.Cout;
     a.ldy = dd.ldy; a.ldr = dd.ldr; a.KH = dd.KH; a.KW = dd.KW; a.stride = dd.stride; a.pad = dd.pad; a.flags = dd.flags;
-    a.groups = dd.groups; a.x_gs = dd.x_gs; a.w_gs = dd.w_gs; a.y_gs = dd.y_gs; a.r_gs = dd.r_gs; a.p_gs = dd.p_gs;
+    a.groups = dd.groups; a.dil = dd.dilation > 1 ? dd.dilation : 1; a.x_gs = dd.x_gs; a.w_gs = dd.w_gs; a.y_gs = dd.y_gs; a.r_gs = dd.r_gs; a.p_gs = dd.p_gs;
     a.M = dd.B * dd.Ho * dd.Wo; a.K = dd.KH * dd.KW * dd.Cin; a.ksteps = a.K / BK;
     a.splitk = dd.splitk;
     const TileInfo ti = kTiles[dd.tile];

@@ -175,7 +175,70 @@ head_upsample_kernel(const float* __restrict__ low, float* __restrict__ y, int B
     y[idx] = v;
 }
 
+// ---- nn.AvgPool2d(k, stride, padding) with count_include_pad=True (FullImageEncoder, surface_normal_dorn.py:10), NHWC -------------
+__global__ void __launch_bounds__(256)
+avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int ldx, int kh, int kw, int sh, int sw, int ph,
+               int pw, int Ho, int Wo, int ldy) {
+    const int q = C / 4;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * Ho * Wo * q) return;
+    const int c = (int)(idx % q) * 4;
+    long long t = idx / q;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < kh; ++r) {
+        const int iy = oy * sh - ph + r;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        for (int u = 0; u < kw; ++u) {
+            const int ix = ox * sw - pw + u;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(&x[((size_t)(b * H + iy) * W + ix) * ldx + c]);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    const float d = (float)(kh * kw);                       // padding counts
+    *reinterpret_cast<float4*>(&y[((size_t)(b * Ho + oy) * Wo + ox) * ldy + c]) = make_float4(s.x / d, s.y / d, s.z / d, s.w / d);
+}
+
+// ---- F.normalize(x, dim=1) on NCHW (surface_normal_dorn.py:154): x / max(||x||_2, 1e-12) per pixel --------------------------------
+__global__ void __launch_bounds__(256) normalize_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * HW) return;
+    const int b = (int)(idx / HW), p = (int)(idx - (long long)b * HW);
+    const float* xb = x + (size_t)b * C * HW + p;
+    float ss = 0.f;
+    for (int c = 0; c < C; ++c) { const float v = xb[(size_t)c * HW]; ss += v * v; }
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    float* yb = y + (size_t)b * C * HW + p;
+    for (int c = 0; c < C; ++c) yb[(size_t)c * HW] = xb[(size_t)c * HW] * inv;
+}
+
 }  // namespace
+
+extern "C" int vidc_avgpool2d(const float* x, float* y, int B, int H, int W, int C, int ldx, int kh, int kw, int sh, int sw, int ph, int pw,
+                              int ldy, vidc_stream_t stream) {
+    VIDC_REQUIRE(x && y, VIDC_ERR_NULL, "vidc_avgpool2d: null pointer");
+    VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 &&
+                     pw >= 0 && H + 2 * ph >= kh && W + 2 * pw >= kw,
+                 VIDC_ERR_SHAPE, "vidc_avgpool2d: bad shape");
+    const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+    const long long total = (long long)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(avgpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vidc::as_stream(stream), x, y, B, H, W, C, ldx, kh, kw, sh,
+                       sw, ph, pw, Ho, Wo, ldy);
+    VIDC_CHECK_LAUNCH("avgpool_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_normalize_nchw(const float* x, float* y, int B, int C, int HW, vidc_stream_t stream) {
+    VIDC_REQUIRE(x && y, VIDC_ERR_NULL, "vidc_normalize_nchw: null pointer");
+    VIDC_REQUIRE(B > 0 && C > 0 && HW > 0, VIDC_ERR_SHAPE, "vidc_normalize_nchw: bad shape");
+    const long long total = (long long)B * HW;
+    hipLaunchKernelGGL(normalize_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vidc::as_stream(stream), x, y, B, C, HW);
+    VIDC_CHECK_LAUNCH("normalize_nchw_kernel");
+    return VIDC_OK;
+}
 
 extern "C" int vidc_stem_conv3x3s2(const float* x, const float* w_oihw, float* y, int B, int Cin, int H, int W, int Cout, int ldy,
                                    int relu, void* y_split, int split_ch0, vidc_stream_t stream) {

@@ -50,6 +50,11 @@ int launch_op(const vidc_op& op, hipStream_t st) {
             long long rows = (long long)(uint32_t)g.i[0] | ((long long)(uint32_t)g.i[1] << 32);
             return vidc_split_bf16x3((const float*)g.p[0], const_cast<void*>(g.p[1]), rows, g.i[2], g.i[3], s);
         }
+        case VIDC_OP_AVGPOOL:   // i = B, H, W, C, ldx, kh, kw, sh, sw, ph, pw, ldy
+            return vidc_avgpool2d((const float*)g.p[0], (float*)g.p[1], g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.i[5], g.i[6], g.i[7], g.i[8],
+                                  g.i[9], g.i[10], g.i[11], s);
+        case VIDC_OP_NORMALIZE:   // i = B, C, HW
+            return vidc_normalize_nchw((const float*)g.p[0], (float*)g.p[1], g.i[0], g.i[1], g.i[2], s);
         case VIDC_OP_COPY: {   // p[0] -> p[1], i[0..1] = byte count (lo, hi)
             size_t bytes = (size_t)(uint32_t)g.i[0] | ((size_t)(uint32_t)g.i[1] << 32);
             VIDC_HIP(hipMemcpyAsync(const_cast<void*>(g.p[1]), g.p[0], bytes, hipMemcpyDeviceToDevice, st));

@@ -52,6 +52,12 @@ class WeightStore:
         self.module = module
         self._cache = {}
         self._sd = None
+        self._virtual = {}       # name -> fn(state_dict) : derived entries (e.g. a Linear weight re-laid-out for NHWC activations)
+
+    def add_virtual(self, name, fn):
+        if name not in self._virtual:
+            self._virtual[name] = fn
+            self._sd = None
 
     def invalidate(self):
         self._cache.clear()
@@ -60,6 +66,8 @@ class WeightStore:
     def sd(self):
         if self._sd is None:
             self._sd = {k: v.detach() for k, v in self.module.state_dict().items()}
+            for name, fn in self._virtual.items():
+                self._sd[name] = fn(self._sd)
         return self._sd
 
     def raw(self, key):
@@ -119,6 +127,8 @@ class JointWeightStore(WeightStore):
     def sd(self):
         if self._sd is None:
             self._sd = {"%s/%s" % (name, k): v.detach() for name, m in self.modules.items() for k, v in m.state_dict().items()}
+            for name, fn in self._virtual.items():
+                self._sd[name] = fn(self._sd)
         return self._sd
 
 
@@ -210,15 +220,15 @@ class Program:
 
     # ---- ops ---------------------------------------------------------------------------------------------
     def conv(self, x, key, bn=None, relu=False, stride=1, padding=0, bn2=None, relu2=False, residual=None,
-             relu_after_residual=False, out=None, accumulate=False, ref_flops_scale=1.0):
+             relu_after_residual=False, out=None, accumulate=False, ref_flops_scale=1.0, dilation=1):
         keys = _keys(key)
         G = len(keys)
         assert x.G == G and not x.nchw
         w0 = self.ws.raw(keys[0] + ".weight")
         co, ci, kh, kw = w0.shape
         assert ci == x.C, "conv %s expects Cin=%d, got %d" % (keys[0], ci, x.C)
-        Ho = (x.H + 2 * padding - kh) // stride + 1
-        Wo = (x.W + 2 * padding - kw) // stride + 1
+        Ho = (x.H + 2 * padding - dilation * (kh - 1) - 1) // stride + 1
+        Wo = (x.W + 2 * padding - dilation * (kw - 1) - 1) // stride + 1
         y = out if out is not None else self.nhwc(Ho, Wo, co, G)
         assert (y.H, y.W, y.C, y.G) == (Ho, Wo, co, G)
         self._split_cache = {k: v for k, v in self._split_cache.items() if k[0] != y.buf}     # y is (re)written
@@ -240,7 +250,7 @@ class Program:
         xin = self.split(x) if prec == L.PREC_BF16X3 else x
         self._emit("conv", [xin, residual, y if accumulate else None], [y], x=xin, y=y, keys=keys, precision=prec,
                    bn=_keys(bn) if bn is not None else None, bn2=_keys(bn2) if bn2 is not None else None,
-                   residual=residual, flags=flags, stride=stride, pad=padding, geom=(co, ci, kh, kw, Ho, Wo))
+                   residual=residual, flags=flags, stride=stride, pad=padding, geom=(co, ci, kh, kw, Ho, Wo), dilation=dilation)
         return y
 
     def split(self, x):
@@ -259,6 +269,37 @@ class Program:
         # same storage, the caller's view of it (grouped and channel-concatenated views share one split image)
         sbuf, ld0 = self._split_cache[ck]
         return T(sbuf, x.B, x.H, x.W, x.C, x.G, ld=ld0)
+
+    def linear(self, x, key, relu=False):
+        """nn.Linear on `x.view(B, -1)` of the reference's NCHW tensor (surface_normal_dorn.py:23-24), as a 1x1 conv over the
+        NHWC buffer viewed as one pixel with H*W*C channels; the weight columns are re-ordered (c,h,w) -> (h,w,c) once."""
+        assert x.G == 1 and x.ld == x.C and x.ch_off == 0 and not x.nchw
+        Cc, Hh, Ww = x.C, x.H, x.W
+        vkey = "%s@hwc%dx%dx%d" % (key, Hh, Ww, Cc)
+
+        def relayout(sd, key=key):
+            w = sd[key + ".weight"]
+            return w.view(w.shape[0], Cc, Hh, Ww).permute(0, 2, 3, 1).reshape(w.shape[0], Hh * Ww * Cc, 1, 1).contiguous()
+
+        self.ws.add_virtual(vkey + ".weight", relayout)
+        self.ws.add_virtual(vkey + ".bias", lambda sd, key=key: sd[key + ".bias"])
+        flat = T(x.buf, x.B, 1, 1, Hh * Ww * Cc)
+        return self.conv(flat, vkey, relu=relu)
+
+    def avgpool(self, x, kernel, stride, padding):
+        kh, kw = kernel
+        sh, sw = stride
+        ph, pw = padding
+        Ho, Wo = (x.H + 2 * ph - kh) // sh + 1, (x.W + 2 * pw - kw) // sw + 1
+        y = self.nhwc(Ho, Wo, x.C, x.G)
+        self._emit("avgpool", [x], [y], x=x, y=y, geom=(kh, kw, sh, sw, ph, pw))
+        return y
+
+    def normalize_nchw(self, x):
+        assert x.nchw
+        y = T(self._new_buf(x.B * x.C * x.H * x.W), x.B, x.H, x.W, x.C, nchw=True)
+        self._emit("normalize", [x], [y], x=x, y=y)
+        return y
 
     def stem_conv(self, xs, key, relu=True, x_is_nchw=True):
         """xs: one NCHW tensor or a list (one per group, Cin may differ: 3,3,1)."""
@@ -280,11 +321,13 @@ class Program:
         self._emit("maxpool", [x], [y], x=x, y=y)
         return y
 
-    def upsample(self, x, size, relu=False, into=None):
-        """UpsamplingBilinear2d(size).  `into`: accumulate (+=) into an existing tensor instead of a new one."""
-        y = into if into is not None else self.nhwc(size[0], size[1], x.C, x.G)
+    def upsample(self, x, size, relu=False, into=None, out=None):
+        """UpsamplingBilinear2d(size).  `into`: accumulate (+=) into an existing tensor; `out`: write (=) into an existing tensor
+        (e.g. a channel slice of a concat buffer) instead of a new one."""
+        y = into if into is not None else (out if out is not None else self.nhwc(size[0], size[1], x.C, x.G))
         assert (y.H, y.W, y.C * y.G) == (size[0], size[1], x.C * x.G)
         flags = (L.UP_RELU if relu else 0) | (L.UP_ACCUM if into is not None else 0)
+        self._split_cache = {k: v for k, v in self._split_cache.items() if k[0] != y.buf}
         self._emit("upsample", [x, into], [y], x=x, y=y, flags=flags)
         return y
 
@@ -447,6 +490,7 @@ class Program:
                 d.B, d.H, d.W, d.Cin, d.ldx = x.B, x.H, x.W, ci, x.ld
                 d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, co, y.ld
                 d.KH, d.KW, d.stride, d.pad = kh, kwid, kw["stride"], kw["pad"]
+                d.dilation = kw.get("dilation", 1)
                 d.flags, d.groups = kw["flags"], len(keys)
                 if kw.get("split_out") is not None:
                     d.y_split = addr(kw["split_out"])
@@ -535,6 +579,19 @@ class Program:
                 g.p[0], g.p[1] = addr(x), addr(y)
                 g.i[0], g.i[1], g.i[2], g.i[3] = rows & 0xFFFFFFFF, rows >> 32, x.C * x.G, x.ld
                 self.op_names.append("split:%dx%d" % (rows, x.C * x.G))
+            elif kind == "avgpool":
+                x, y = kw["x"], kw["y"]
+                op.kind = L.OP_AVGPOOL
+                g.p[0], g.p[1] = addr(x), addr(y)
+                for j, v in enumerate((x.B, x.H, x.W, x.C * x.G, x.ld) + tuple(kw["geom"]) + (y.ld,)):
+                    g.i[j] = v
+                self.op_names.append("avgpool")
+            elif kind == "normalize":
+                x, y = kw["x"], kw["y"]
+                op.kind = L.OP_NORMALIZE
+                g.p[0], g.p[1] = addr(x), addr(y)
+                g.i[0], g.i[1], g.i[2] = x.B, x.C, x.H * x.W
+                self.op_names.append("normalize")
             elif kind == "copy":
                 src, dst = kw["src"], kw["dst"]
                 nbytes = min(self.buf_elems[src.buf], self.buf_elems[dst.buf]) * 4

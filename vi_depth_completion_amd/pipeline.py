@@ -74,17 +74,21 @@ def build_frame_program(sn, dc, B, H, W, device, dry_run=False):
 
 class DepthCompletionPipeline:
     def __init__(self, enriched_samples=200, fc_img=(202.0, 202.0), cc_img=(0.5 * 319.87654, 0.5 * 239.87603),
-                 align_corners=False, device="cuda", network_class_creator=ModifiedFPN, rng=np.random):
+                 align_corners=False, device="cuda", network_class_creator=ModifiedFPN, rng=np.random, use_gravity=True):
         if not torch.cuda.is_available():
             raise RuntimeError("DepthCompletionPipeline needs a GPU: the HIP path has no CPU fallback")
         self.args = argparse.Namespace(enriched_samples=enriched_samples)
         self.device = torch.device(device)
         self.cnn = network_class_creator().to(self.device)                                   # network_run.py:422-424
-        self.surface_normal_cnn = SurfaceNormalPrediction(fc_img=np.asarray(fc_img, dtype=np.float64),
-                                                          cc_img=np.asarray(cc_img, dtype=np.float64),
-                                                          align_corners=align_corners).to(self.device)   # main.py:243
+        self.use_gravity = bool(use_gravity)
+        if self.use_gravity:
+            self.surface_normal_cnn = SurfaceNormalPrediction(fc_img=np.asarray(fc_img, dtype=np.float64),
+                                                              cc_img=np.asarray(cc_img, dtype=np.float64),
+                                                              align_corners=align_corners).to(self.device)   # main.py:243
+        else:
+            from .networks.surface_normal_dorn import SurfaceNormalDORN
+            self.surface_normal_cnn = SurfaceNormalDORN().to(self.device)                                    # main.py:245
         self.plane_masks_extraction = None
-        self.use_gravity = True
         self.planes = PlaneBlock()
         self.rng = rng
         self.eval_mode()
@@ -117,7 +121,10 @@ class DepthCompletionPipeline:
         planes = planes or self.planes
         ds = input_batch["sparse_depth"].to(dev, non_blocking=True)
         rgb = input_batch["image"].to(dev, non_blocking=True)
-        normals = self.surface_normal_cnn.enqueue(rgb, input_batch["gravity"].to(dev), input_batch["aligned_direction"].to(dev), slot)
+        if self.use_gravity:
+            normals = self.surface_normal_cnn.enqueue(rgb, input_batch["gravity"].to(dev), input_batch["aligned_direction"].to(dev), slot)
+        else:
+            normals = self.surface_normal_cnn(rgb)                                                           # main.py:270-271
         rng = rng if rng is not None else self.rng
         st = {"ds": ds, "rgb": rgb, "normals": normals, "di": None, "nnz": None, "rng": rng}
         if self.args.enriched_samples != 0:
@@ -163,6 +170,8 @@ class DepthCompletionPipeline:
         RANSAC / enrichment draws come off `self.rng` in the same order as back-to-back `_call_cnn` calls."""
         import itertools
         import os
+        if not self.use_gravity:
+            raise NotImplementedError("run_interleaved pipelines the gravity-aligned surface-normal network; use _call_cnn with use_gravity=False")
         dev = self.device
         prog = None
         prev = None            # frame waiting for its depth network: dict(rgb, enriched)

@@ -115,6 +115,8 @@ def seeded_state_dict(reference_state, seed=1234, device="cpu"):
             fan_in = shape[1] * shape[2] * shape[3]
             gain = 0.25 if (name.endswith("feature_concat.2.weight") and shape[0] == 1) else 1.0
             out[name] = normal01(seed, name, shape, device, scale=gain * float(np.sqrt(2.0 / fan_in)), dtype=torch.float32)
+        elif len(shape) == 2 and leaf == "weight":  # nn.Linear weight: kaiming-normal like a conv
+            out[name] = normal01(seed, name, shape, device, scale=float(np.sqrt(2.0 / shape[1])), dtype=torch.float32)
         elif leaf == "running_var":
             out[name] = uniform01(seed, name, shape, device) + 0.5
         elif leaf == "running_mean":
