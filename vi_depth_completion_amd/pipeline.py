@@ -26,7 +26,7 @@ class FixedPlaneMask:
         return self.id_map
 
 
-def build_frame_program(sn, dc, B, H, W, device, dry_run=False):
+def build_frame_program(sn, dc, B, H, W, device, dry_run=False, weights=None):
     """ONE planned program for a pipeline tick: the surface-normal network of frame i+1 and the depth-completion
     network of frame i.  Their four ResNet-101 pyramids have identical layer shapes, so each pyramid layer is one
     grouped launch over (sn, dc.rgb, dc.normal, dc.depth) instead of a 1-group and a 3-group launch -- at batch 1
@@ -38,7 +38,7 @@ def build_frame_program(sn, dc, B, H, W, device, dry_run=False):
     from .networks.fpn_decoder import emit_decoder
     wp = sn.warp_2dof_alignment
     assert (wp.H, wp.W) == (H, W), "frame size %dx%d does not match the warp intrinsics (%dx%d)" % (W, H, wp.W, wp.H)
-    ws = engine.JointWeightStore({"sn": sn, "dc": dc})
+    ws = weights if weights is not None else engine.JointWeightStore({"sn": sn, "dc": dc})     # `weights`: reuse packed weights (tools)
     prog = engine.Program(ws, device, B)
     x = prog.input_nchw("sn_image", 3, H, W)
     g = prog.input_raw("gravity", B * 3)
