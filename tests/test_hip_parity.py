@@ -619,6 +619,21 @@ def test_run_interleaved_matches_sequential(pipeline):
         assert rmse < 1e-3, rmse
     # frames must not leak into each other: different inputs give different outputs
     assert not torch.equal(outs[0], outs[1])
+    # the caller may recycle its input tensors as soon as the generator hands control back: feed every frame through ONE set of
+    # device buffers that is overwritten for the next frame
+    reuse = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in frames[0].items()}
+
+    def recycled():
+        for fr in frames:
+            for k, v in fr.items():
+                if torch.is_tensor(v):
+                    reuse[k].copy_(v)
+            yield reuse
+    pipeline.rng = np.random.RandomState(321)
+    rec = [o.cpu() for o in pipeline.run_interleaved(recycled())]
+    pipeline.rng = saved
+    for a, b in zip(outs, rec):
+        assert torch.equal(a, b)
     # running the same stream again gives the same answer (no state left over from the drain tick)
     pipeline.rng = np.random.RandomState(321)
     again = [o.cpu() for o in pipeline.run_interleaved(iter(frames))]

@@ -209,7 +209,10 @@ class DepthCompletionPipeline:
                 prog.storage[prog.inputs["aligned"].buf][: B * 3].copy_(batch["aligned_direction"].to(dev).reshape(-1), non_blocking=True)
                 prog.launch_segment(0) if graph else prog.run_segment(0)
                 normals = prog.tensor(prog.outputs["normals"])
-                cur = {"rgb": rgb, "depth_in": ds}
+                # the depth network of this frame runs in the NEXT tick: keep private copies of what it will read then, in case the
+                # caller recycles its input tensors (a host->device transfer above already made one)
+                own = lambda t, src: t if t.data_ptr() != src.data_ptr() else t.clone()
+                cur = {"rgb": own(rgb, batch["image"]), "depth_in": own(ds, batch["sparse_depth"])}
                 pending = None
                 if self.args.enriched_samples != 0:
                     homo = batch["homogeneous_coordinates"].to(dev, non_blocking=True)
