@@ -571,6 +571,31 @@ def test_full_path_vs_oracle_batch2(pipeline, seeded_weights):
     assert rmse < 1e-3, rmse
 
 
+@pytest.mark.parametrize("align_corners", [False, True])
+def test_full_path_320x256_batch2_both_modes(seeded_weights, align_corners):
+    """The bench shape (320x256, SURVEY §0: the reference itself is hard-wired to 320x240, so the resolution-generic oracle is the
+    reference here), batch 2, both grid_sample conventions, sequential _call_cnn and the software-pipelined mode: RMSE <= 1e-3."""
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    H, W = 256, 320
+    cc = (0.5 * 319.87654, 0.5 * 239.87603 * H / 240.0)
+    pipe = DepthCompletionPipeline(enriched_samples=200, cc_img=cc, align_corners=align_corners)
+    pipe.load_state_dicts(seeded_weights["sn"], seeded_weights["dc"])
+    pipe.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(H, W))
+    batches = [S.synthetic_batch(2, H, W, 1234, frame0=60 + 2 * i) for i in range(2)]
+    intr = O.Intrinsics(202.0, 202.0, cc[0], cc[1])
+    masks = [S.plane_id_map(H, W)] * 2
+    rng = np.random.RandomState(17)
+    want = [O.call_cnn(seeded_weights["sn"], seeded_weights["dc"], b, masks, intr, 200, align_corners=align_corners, rng=rng) for b in batches]
+    pipe.rng = np.random.RandomState(17)
+    seq = [pipe._call_cnn(b).cpu() for b in batches]
+    pipe.rng = np.random.RandomState(17)
+    dev_batches = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
+    il = [o.cpu() for o in pipe.run_interleaved(iter(dev_batches))]
+    for w_, a, b in zip(want, seq, il):
+        assert a.shape == (2, 1, H, W)
+        assert float((a - w_).pow(2).mean().sqrt()) < 1e-3 and float((b - w_).pow(2).mean().sqrt()) < 1e-3
+
+
 def test_graph_and_eager_agree(pipeline, monkeypatch):
     batch = S.synthetic_batch(1, 240, 320, 1234, frame0=9)
     x = (batch["image"].to(DEV), batch["gravity"].to(DEV), batch["aligned_direction"].to(DEV))
