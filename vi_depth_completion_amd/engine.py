@@ -387,12 +387,38 @@ class Program:
                     self.ops[t][2].append(kw["y"].buf)
                 drop.add(i)
                 continue
-            if y.ch_off != 0 or y.C * y.G != xs.C * xs.G or y.ld != y.C * y.G or y.ld % 32 or pk.get("split_out") is not None:
+            # general case: the tensor is written by one producer, or slice by slice by several (a concat buffer filled by a conv and
+            # an upsample, say); every producer writes its slice of the split image.  The slices must tile the split's channel range.
+            last = {}                                        # channel slice -> its LAST writer (earlier ones are superseded)
+            foreign = False
+            for t in range(i):
+                if xs.buf in self.ops[t][2]:
+                    if self.ops[t][0] not in ("conv", "maxpool", "upsample"):
+                        foreign = True
+                        continue
+                    yt = self.ops[t][3]["y"]
+                    if yt.buf == xs.buf:
+                        last[(yt.ch_off, yt.C * yt.G)] = t
+            writers = sorted(last.values())
+            lo, hi = xs.ch_off, xs.ch_off + xs.C * xs.G
+            ok = bool(writers) and not foreign and xs.ld % 32 == 0 and lo % 32 == 0
+            cover = []
+            for t in writers:
+                yt = self.ops[t][3]["y"]
+                ok = ok and yt.ld == xs.ld and yt.ch_off % 32 == 0 and (yt.C * yt.G) % 32 == 0 and lo <= yt.ch_off and \
+                    yt.ch_off + yt.C * yt.G <= hi and self.ops[t][3].get("split_out") is None
+                cover.append((yt.ch_off, yt.ch_off + yt.C * yt.G))
+            cover.sort()
+            ok = ok and cover[0][0] == lo and cover[-1][1] == hi and all(cover[k][1] == cover[k + 1][0] for k in range(len(cover) - 1))
+            if not ok:
                 continue
-            pk["split_out"] = kw["y"]
-            if pkind == "conv":
-                pk["flags"] |= L.SPLIT_OUT
-            self.ops[j][2].append(kw["y"].buf)
+            simg = kw["y"]                                   # the split image: compact, ld = xs.C * xs.G
+            for t in writers:
+                yt = self.ops[t][3]["y"]
+                self.ops[t][3]["split_out"] = T(simg.buf, yt.B, yt.H, yt.W, yt.C, yt.G, ld=simg.C * simg.G, ch_off=yt.ch_off - lo)
+                if self.ops[t][0] == "conv":
+                    self.ops[t][3]["flags"] |= L.SPLIT_OUT
+                self.ops[t][2].append(simg.buf)
             drop.add(i)
         for j, (kind, _r, _w, kw) in enumerate(self.ops):
             if kind in ("conv", "maxpool", "upsample", "stem") and kw.get("split_out") is not None and kw["y"].buf not in self.pinned:
