@@ -147,7 +147,9 @@ int vidc_stem_conv3x3s2(const float* x, const float* w_oihw, float* y, int B, in
 /* nn.MaxPool2d(3, 2, 1) on NHWC (surface_normal.py:44). */
 int vidc_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, void* y_split, vidc_stream_t stream);
 
-enum vidc_up_flags { VIDC_UP_RELU = 1, VIDC_UP_ACCUM = 2, VIDC_UP_NO_F32_OUT = 4 };
+enum vidc_up_flags { VIDC_UP_RELU = 1, VIDC_UP_ACCUM = 2, VIDC_UP_NO_F32_OUT = 4,
+                     VIDC_UP_SUM_GROUPS_SHIFT = 8 /* bits 8..15 = G > 1: x holds G groups of C channels (group g at channel g*C); their
+                                                      upsampled (and ReLU'd) values are summed into the C output channels, g = 0 first */ };
 /* nn.UpsamplingBilinear2d(size) == bilinear, align_corners=True, on NHWC (surface_normal.py:88 ...). */
 int vidc_upsample_bilinear_ac(const float* x, float* y, int B, int h, int w, int C, int ldx, int H, int W, int ldy,
                               int flags, void* y_split, vidc_stream_t stream);

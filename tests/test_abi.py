@@ -121,7 +121,7 @@ def test_frame_program_structure(recorded_frame_program, recorded_programs):
     sn, dc = recorded_programs
     kinds = [k for k, _, _, _ in fp.ops]
     assert kinds.count("stem") == 4 and kinds.count("head") == 2 and kinds.count("maxpool") == 1
-    assert kinds.count("warp_fwd") == 1 and kinds.count("warp_inv") == 1 and kinds.count("upsample") == 10
+    assert kinds.count("warp_fwd") == 1 and kinds.count("warp_inv") == 1 and kinds.count("upsample") == 6
     # 105 grouped pyramid launches + 12 surface-normal decoder/head launches (18 convs) + 12 depth-completion ones
     assert kinds.count("conv") == 105 + 12 + 12
     pyr = [kw for k, _, _, kw in fp.ops if k == "conv" and len(kw["keys"]) == 4]
@@ -156,7 +156,7 @@ def test_program_recording_matches_reference_op_counts(recorded_programs):
     # 3x3 as conv ops, + 1 head 1x1 kernel = 125 convs
     nconv = lambda p: sum(len(kw["keys"]) for k, _, _, kw in p.ops if k == "conv")
     assert kinds(sn).count("stem") == 1 and kinds(sn).count("conv") == 105 + 11 + 1 and nconv(sn) == 123 and kinds(sn).count("head") == 1
-    assert kinds(sn).count("upsample") == 5 and kinds(sn).count("maxpool") == 1
+    assert kinds(sn).count("upsample") == 3 and kinds(sn).count("maxpool") == 1
     # DC: the 3 pyramids run grouped: 3 stems + 105 grouped launches (= 315 convs) + 17 + 1 + head = 337 convs
     assert kinds(dc).count("stem") == 3 and kinds(dc).count("conv") == 105 + 11 + 1 and nconv(dc) == 315 + 18 and kinds(dc).count("head") == 1
     stem = lambda cin: 2 * 120 * 160 * 64 * cin * 9

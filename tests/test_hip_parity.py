@@ -292,6 +292,14 @@ def test_upsample(sizes):
     acc = nhwc(base).to(DEV)
     ops.upsample_bilinear_ac(nhwc(x).to(DEV), (H, W), relu=True, accumulate_into=acc)
     assert (nchw(acc).cpu() - (base + F.relu(ref))).abs().max() < 2e-5
+    # three groups summed into one accumulator in a single launch == three accumulating launches, bit for bit
+    x3 = S.normal01(6, "up.x3", (2, 3 * 64, h, w)).float()
+    one = nhwc(base).to(DEV)
+    ops.upsample_bilinear_ac(nhwc(x3).to(DEV), (H, W), relu=True, accumulate_into=one, sum_groups=3)
+    three = nhwc(base).to(DEV)
+    for g in range(3):
+        ops.upsample_bilinear_ac(nhwc(x3[:, g * 64:(g + 1) * 64]).to(DEV), (H, W), relu=True, accumulate_into=three)
+    assert torch.equal(one, three)
 
 
 def test_glue_kernels_write_split_images():

@@ -112,20 +112,25 @@ upsample_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int h
     src_index(oy, h, H, y0, y1, ly);
     src_index(ox, w, W, x0, x1, lx);
     const float hy = 1.f - ly, hx = 1.f - lx;
-    const float* xb = x + (size_t)b * h * w * ldx + c;
-    float4 v00 = *reinterpret_cast<const float4*>(xb + ((size_t)y0 * w + x0) * ldx);
-    float4 v01 = *reinterpret_cast<const float4*>(xb + ((size_t)y0 * w + x1) * ldx);
-    float4 v10 = *reinterpret_cast<const float4*>(xb + ((size_t)y1 * w + x0) * ldx);
-    float4 v11 = *reinterpret_cast<const float4*>(xb + ((size_t)y1 * w + x1) * ldx);
-    float4 o;
-    o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
-    o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
-    o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
-    o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
-    if (flags & VIDC_UP_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     const size_t row = (size_t)(b * H + oy) * W + ox;
     float4* dst = reinterpret_cast<float4*>(&y[row * ldy + c]);
-    if (flags & VIDC_UP_ACCUM) { float4 p = *dst; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    const int G = (flags >> 8) & 0xFF;                 // > 1: x holds G groups of C channels whose upsampled values are summed, in order
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (flags & VIDC_UP_ACCUM) o = *dst;
+    for (int g = 0; g < (G > 1 ? G : 1); ++g) {
+        const float* xb = x + (size_t)b * h * w * ldx + g * C + c;
+        const float4 v00 = *reinterpret_cast<const float4*>(xb + ((size_t)y0 * w + x0) * ldx);
+        const float4 v01 = *reinterpret_cast<const float4*>(xb + ((size_t)y0 * w + x1) * ldx);
+        const float4 v10 = *reinterpret_cast<const float4*>(xb + ((size_t)y1 * w + x0) * ldx);
+        const float4 v11 = *reinterpret_cast<const float4*>(xb + ((size_t)y1 * w + x1) * ldx);
+        float4 u;
+        u.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+        u.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+        u.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+        u.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+        if (flags & VIDC_UP_RELU) { u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f); }
+        o.x = u.x + o.x; o.y = u.y + o.y; o.z = u.z + o.z; o.w = u.w + o.w;       // value + running sum, like one launch per group would
+    }
     if (!(flags & VIDC_UP_NO_F32_OUT)) *dst = o;
     if (ysp) vidc::store_split4(ysp, row, ldy, c, o);
 }
@@ -276,6 +281,7 @@ extern "C" int vidc_upsample_bilinear_ac(const float* x, float* y, int B, int h,
     VIDC_REQUIRE(x && y, VIDC_ERR_NULL, "vidc_upsample_bilinear_ac: null pointer");
     VIDC_REQUIRE(!y_split || ldy % 32 == 0, VIDC_ERR_SHAPE, "vidc_upsample_bilinear_ac: split output needs ldy % 32 == 0");
     VIDC_REQUIRE(!(flags & VIDC_UP_NO_F32_OUT) || y_split, VIDC_ERR_SHAPE, "vidc_upsample_bilinear_ac: NO_F32_OUT without y_split writes nothing");
+    VIDC_REQUIRE(ldx >= C * (((flags >> 8) & 0xFF) > 1 ? ((flags >> 8) & 0xFF) : 1) && ldy >= C, VIDC_ERR_SHAPE, "vidc_upsample_bilinear_ac: bad channel strides");
     VIDC_REQUIRE(B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, VIDC_ERR_SHAPE,
                  "vidc_upsample_bilinear_ac: bad shape");
     long long total = (long long)B * H * W * (C / 4);

@@ -321,9 +321,15 @@ class Program:
         self._emit("maxpool", [x], [y], x=x, y=y)
         return y
 
-    def upsample(self, x, size, relu=False, into=None, out=None):
+    def upsample(self, x, size, relu=False, into=None, out=None, sum_groups=False):
         """UpsamplingBilinear2d(size).  `into`: accumulate (+=) into an existing tensor; `out`: write (=) into an existing tensor
-        (e.g. a channel slice of a concat buffer) instead of a new one."""
+        (e.g. a channel slice of a concat buffer) instead of a new one.  sum_groups: x is a grouped tensor whose G upsampled (ReLU'd)
+        groups are added up, group 0 first -- z2 + z3 + z4 of the decoders in one launch."""
+        if sum_groups:
+            assert into is not None and x.G > 1 and (into.H, into.W, into.C * into.G) == (size[0], size[1], x.C)
+            self._split_cache = {k: v for k, v in self._split_cache.items() if k[0] != into.buf}
+            self._emit("upsample", [x, into], [into], x=x, y=into, flags=(L.UP_RELU if relu else 0) | L.UP_ACCUM | (x.G << 8), sum_groups=x.G)
+            return into
         y = into if into is not None else (out if out is not None else self.nhwc(size[0], size[1], x.C, x.G))
         assert (y.H, y.W, y.C * y.G) == (size[0], size[1], x.C * x.G)
         flags = (L.UP_RELU if relu else 0) | (L.UP_ACCUM if into is not None else 0)
@@ -560,7 +566,7 @@ class Program:
                 x, y = kw["x"], kw["y"]
                 op.kind = L.OP_UPSAMPLE
                 g.p[0], g.p[1] = addr(x), addr(y)
-                for j, v in enumerate((x.B, x.H, x.W, x.C * x.G, x.ld, y.H, y.W, y.ld, kw["flags"])):
+                for j, v in enumerate((x.B, x.H, x.W, (x.C if kw.get("sum_groups") else x.C * x.G), x.ld, y.H, y.W, y.ld, kw["flags"])):
                     g.i[j] = v
                 if kw.get("split_out") is not None:
                     g.p[2] = addr(kw["split_out"])

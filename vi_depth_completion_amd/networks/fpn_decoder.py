@@ -89,7 +89,7 @@ def emit_decoder_grouped(prog, module, levels, key_prefix=""):
     shape at the same pyramid level run as ONE grouped launch on channel slices of a shared buffer --
       level 3: 3x3 (f3.3, f4.10) and the low-resolution 1x1 (f3.7, f4.14) as 2 groups,
       level 2: 3x3 (f2.3, f3.10, f4.17) and the low-resolution 1x1 (f2.7, f3.14, f4.21) as 3 groups --
-    17 -> 11 conv launches and 6 -> 5 upsample launches per decoder, same arithmetic per output element (grouping only changes
+    17 -> 11 conv launches and 6 -> 3 upsample launches per decoder, same arithmetic per output element (grouping only changes
     which launch computes it; z1+z2+z3+z4 is still accumulated in that order).  Needs the upsample/1x1 commute (emit_branch)."""
     from ..engine import K, T
     flat = [T(t.buf, t.B, t.H, t.W, t.C * t.G, 1, t.ld, t.ch_off) for t in levels]
@@ -129,8 +129,7 @@ def emit_decoder_grouped(prog, module, levels, key_prefix=""):
     g2 = grouped(g2, ((2, 7), (3, 14), (4, 21)), relu=False, ref_flops_scale=up_scale(2, 1))
     # level 1: z1, then += z2, z3, z4 in the reference's order
     zsum = cbr(cbr(x1, 1, 0), 1, 3)
-    for g in range(3):
-        prog.upsample(sl(g2, g), size[1], relu=True, into=zsum)
+    prog.upsample(g2, size[1], relu=True, into=zsum, sum_groups=True)        # (((z1 + z2) + z3) + z4), one launch
     return zsum
 
 

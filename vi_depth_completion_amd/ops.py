@@ -124,10 +124,19 @@ def maxpool3x3s2(x, split_out=None):
     return y
 
 
-def upsample_bilinear_ac(x, size, relu=False, accumulate_into=None, split_out=None, store_f32=True):
+def upsample_bilinear_ac(x, size, relu=False, accumulate_into=None, split_out=None, store_f32=True, sum_groups=1):
+    """sum_groups = G > 1: x holds G groups of C/G channels; their upsampled (ReLU'd) values are added into accumulate_into (C/G ch)."""
     _dev(x)
     x = x.contiguous()
     B, h, w, Cc = x.shape
+    if sum_groups > 1:
+        assert accumulate_into is not None and Cc % sum_groups == 0
+        y = accumulate_into
+        co = Cc // sum_groups
+        flags = (L.UP_RELU if relu else 0) | L.UP_ACCUM | (sum_groups << 8)
+        L.check(L.lib().vidc_upsample_bilinear_ac(L.ptr(x), L.ptr(y), B, h, w, co, Cc, size[0], size[1], co, flags, L.ptr(split_out),
+                                                  L.current_stream()), "upsample")
+        return y
     y = accumulate_into if accumulate_into is not None else torch.empty((B, size[0], size[1], Cc), dtype=torch.float32, device=x.device)
     flags = (L.UP_RELU if relu else 0) | (L.UP_ACCUM if accumulate_into is not None else 0) | (0 if store_f32 else L.UP_NO_F32_OUT)
     L.check(L.lib().vidc_upsample_bilinear_ac(L.ptr(x), L.ptr(y), B, h, w, Cc, Cc, size[0], size[1], Cc, flags, L.ptr(split_out),
