@@ -249,11 +249,11 @@ def main():
         got = pipe._call_cnn(next(frames(1)) if pre is None else {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in hb.items()}).cpu()
         sq_err, n_px = float((got - ref).double().pow(2).sum()), float(ref.numel())
         tc = time.perf_counter()
-        for j in range(args.cpu_frames):
+        for j in range(args.cpu_frames if world == 1 else 0):     # the CPU baseline is timed at N=1 only (the other ranks would idle in the gather)
             hbj = S.synthetic_batch(B, H, W, 1234, frame0=(j + 1) * B)
             O.call_cnn(cpu_sn, cpu_dc, hbj, masks, intr, 200, rng=np.random.RandomState(j))
         cpu_s = time.perf_counter() - tc
-        cpu_baseline = {"value": round(args.cpu_frames * B / cpu_s, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
+        cpu_baseline = None if world > 1 else {"value": round(args.cpu_frames * B / cpu_s, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
                         "kind": "port",
                         "sample": "%d frames of the same %dx%d batch-%d workload through oracle/vidc_oracle.call_cnn "
                                   "(torch CPU fp32, %d threads of %d host CPUs)" % (args.cpu_frames, W, H, B,
