@@ -95,7 +95,9 @@ typedef struct vidc_conv_desc {
     const float* scale2;   /* [Cout] or NULL                                          */
     const float* shift2;
     const float* residual; /* NHWC, channel stride ldr, or NULL                       */
-    float* workspace;      /* split-K partials: splitk*groups*M*Cout floats, or NULL  */
+    float* workspace;      /* split-K scratch, or NULL: VIDC_SPLITK_COUNTERS ticket counters (uint32, MUST be zero before the first
+                              launch that uses the buffer; every launch leaves them zero) followed by splitk*groups*M*Cout floats
+                              of partials.  Launches that share a workspace must be ordered (same stream).             */
     int32_t B, H, W, Cin, ldx;
     int32_t Ho, Wo, Cout, ldy, ldr;
     int32_t KH, KW, stride, pad;
@@ -135,6 +137,7 @@ int vidc_split_bf16x3(const float* x, void* y, long long rows, int C, int ldx, v
 int vidc_pack_conv_weight_bf16x3(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW, vidc_stream_t stream);
 
 int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream);
+#define VIDC_SPLITK_COUNTERS 16384   /* ticket counters at the head of a split-K workspace (one per output tile) */
 size_t vidc_conv2d_workspace_bytes(const vidc_conv_desc* d);
 /* Fills d->tile / d->splitk with the heuristic choice for this shape on the current device. */
 int vidc_conv2d_plan(vidc_conv_desc* d);

@@ -59,7 +59,7 @@ def test_conv_plan_is_sane(lib, M, N, K):
     wgs = -(-M // bm) * -(-N // bn) * d.splitk
     assert wgs >= min(64, (M // 32) * (N // 64))        # the planner must not leave most of the 256 CUs idle
     if d.splitk > 1:
-        assert lib.vidc_conv2d_workspace_bytes(C.byref(d)) == d.splitk * M * N * 4
+        assert lib.vidc_conv2d_workspace_bytes(C.byref(d)) == (L.SPLITK_COUNTERS + d.splitk * M * N) * 4
 
 
 def test_rng_draws_follow_reference_order():

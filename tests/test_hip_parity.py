@@ -247,6 +247,36 @@ def test_conv_is_deterministic():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("tile", [4, 5, 13, 17, 18, 21, 23])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_conv_splitk_shared_workspace_repeatable(tile, prec):
+    """The fused split-K reduction (last-arriving k-slice workgroup sums the partials in slice order) on ONE workspace reused by
+    different convs back to back, like in a program: every repetition gives the same bits, the result matches torch-CPU, and the
+    ticket counters at the head of the workspace are zero again after every launch."""
+    from vi_depth_completion_amd import ops
+    from vi_depth_completion_amd import _lib as L
+    ws = torch.zeros(L.SPLITK_COUNTERS + 8 * 2 * 330 * 256, dtype=torch.float32, device=DEV)
+    cases = []
+    for seed, (H, W, cin, cout, k, groups, sk) in enumerate([(15, 22, 256, 256, 3, 2, 4), (9, 10, 512, 128, 1, 1, 8), (15, 22, 128, 96, 3, 1, 3)]):
+        x, w, s1, b1 = _conv_case(40 + seed, 1, H, W, cin, cout, k, 1, groups)
+        res = S.normal01(40 + seed, "res", (1, groups * cout, H, W)).float()
+        ref = F.relu(F.relu(_ref_conv(x, w, s1, b1, k, 1, k // 2, groups)) + res)
+        pack = ops.pack_conv_weight_bf16x3 if prec else ops.pack_conv_weight
+        wp = torch.stack([pack(wg.to(DEV)) for wg in w])
+        cases.append((nhwc(x).to(DEV), wp, s1.to(DEV), b1.to(DEV), k, k // 2, nhwc(res).to(DEV), groups, sk, ref))
+    first = {}
+    for rep in range(6):
+        for ci, (xd, wp, s1, b1, k, pad, res, groups, sk, ref) in enumerate(cases):
+            y = ops.conv2d_bn_act(xd, wp, s1, b1, k, k, 1, pad, relu1=True, residual=res, relu3=True, tile=tile, splitk=sk, groups=groups,
+                                  precision=prec, workspace=ws)
+            if rep == 0:
+                first[ci] = y
+                assert (nchw(y).cpu() - ref).abs().max().item() < 3e-4
+            else:
+                assert torch.equal(y, first[ci])
+            assert int(ws[:L.SPLITK_COUNTERS].view(torch.int32).abs().sum()) == 0
+
+
 def test_conv_rejects_bad_shapes():
     from vi_depth_completion_amd import ops
     x = torch.zeros(1, 8, 8, 48, device=DEV)      # Cin=48 is not a multiple of 32

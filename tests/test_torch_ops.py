@@ -1,0 +1,94 @@
+"""`torch.ops.vidc.*` (vi_depth_completion_amd/torch_ops.py): registration and shape functions on CPU, numerics on the GPU
+against torch-CPU fp32 / the oracle (same tolerances as tests/test_hip_parity.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vidc_oracle as O
+from vi_depth_completion_amd import synthetic as S
+from vi_depth_completion_amd import torch_ops as T
+
+torch.set_grad_enabled(False)
+FX, FY, CX, CY = 202.0, 202.0, 159.93827, 119.938015
+
+
+def test_ops_are_registered():
+    for name in T.OPS:
+        assert hasattr(torch.ops.vidc, name), name
+
+
+def test_no_cpu_kernel():
+    """The operators exist for the GPU dispatch key only: a CPU call must fail loudly, never compute."""
+    x = torch.zeros(1, 3, 240, 320)
+    g = torch.tensor([[0.0, 1.0, 0.0]])
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.vidc.warp2dof_fwd(x, g, g, FX, FY, CX, CY, False)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.vidc.maxpool3x3s2(torch.zeros(1, 8, 8, 32))
+
+
+def test_shape_functions():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        x = torch.empty(2, 60, 80, 64)
+        w = torch.empty(128, 64, 3, 3)
+        s = torch.empty(128)
+        assert torch.ops.vidc.conv2d_bn_act(x, w, s, s, 2, 1, True, 1).shape == (2, 30, 40, 128)
+        assert torch.ops.vidc.maxpool3x3s2(x).shape == (2, 30, 40, 64)
+        assert torch.ops.vidc.upsample_bilinear_ac(x, 120, 160, False).shape == (2, 120, 160, 64)
+        assert torch.ops.vidc.stem_conv3x3s2(torch.empty(2, 3, 240, 320), torch.empty(64, 3, 3, 3), True).shape == (2, 120, 160, 64)
+        assert torch.ops.vidc.head_conv1x1_upsample(x, torch.empty(1, 64, 1, 1), torch.empty(1), 1, 240, 320, True).shape == (2, 1, 240, 320)
+        h, y = torch.ops.vidc.warp2dof_fwd(torch.empty(2, 3, 240, 320), torch.empty(2, 3), torch.empty(2, 3), FX, FY, CX, CY, False)
+        assert h.shape == (2, 3, 3) and y.shape == (2, 3, 240, 320)
+
+
+@pytest.mark.gpu
+def test_warp_ops_match_oracle():
+    b = S.synthetic_batch(2, 240, 320, 1234)
+    img, g, a = b["image"], b["gravity"], b["aligned_direction"]
+    intr = O.Intrinsics(FX, FY, CX, CY)
+    H_or, y_or = O.warp_forward(img, g, a, intr, False)
+    H, y = torch.ops.vidc.warp2dof_fwd(img.cuda(), g.cuda(), a.cuda(), FX, FY, CX, CY, False)
+    assert (H.cpu() - H_or).abs().max() <= 2e-5 * H_or.abs().max()
+    d = (y.cpu() - y_or).abs()
+    assert d.max() < 1e-3 and d.mean() < 2e-5
+    nmap = S.normal01(1234, "ops.normalmap", (2, 3, 240, 320)).float()
+    _, z_or = O.warp_inverse_normals(nmap, g, a, intr, False)
+    z_or = F.normalize(z_or, dim=1)
+    _, z = torch.ops.vidc.warp2dof_inv_rot_norm(nmap.cuda(), g.cuda(), a.cuda(), FX, FY, CX, CY, False, True)
+    dz = (z.cpu() - z_or).abs()
+    assert dz.mean() < 6e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [(0, 2e-4), (1, 2e-4)])
+def test_conv_op_matches_torch(precision, tol):
+    x = S.normal01(7, "ops.x", (2, 64, 30, 40)).float()
+    w = S.normal01(7, "ops.w", (96, 64, 3, 3)).float() * (2.0 / (64 * 9)) ** 0.5
+    scale = 0.5 + S.uniform01(7, "ops.s", (96,)).float()
+    shift = 0.1 * S.normal01(7, "ops.b", (96,)).float()
+    ref = F.relu(F.conv2d(x, w, stride=2, padding=1) * scale[None, :, None, None] + shift[None, :, None, None])
+    y = torch.ops.vidc.conv2d_bn_act(x.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda(), scale.cuda(), shift.cuda(), 2, 1, True, precision)
+    assert y.shape == (2, 15, 20, 96)
+    assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max() < tol
+
+
+@pytest.mark.gpu
+def test_glue_ops_match_torch():
+    x = S.normal01(9, "ops.g", (2, 64, 31, 41)).float()
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    mp = torch.ops.vidc.maxpool3x3s2(xh).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(mp, F.max_pool2d(x, 3, 2, 1))
+    up = torch.ops.vidc.upsample_bilinear_ac(xh, 62, 82, True).cpu().permute(0, 3, 1, 2)
+    ref = F.relu(F.interpolate(x, size=(62, 82), mode="bilinear", align_corners=True))
+    assert (up - ref).abs().max() < 1e-5
+    img = S.uniform01(9, "ops.img", (2, 3, 240, 320))
+    w = S.normal01(9, "ops.sw", (64, 3, 3, 3)).float() * 0.2
+    st = torch.ops.vidc.stem_conv3x3s2(img.cuda(), w.cuda(), True).cpu().permute(0, 3, 1, 2)
+    assert (st - F.relu(F.conv2d(img, w, stride=2, padding=1))).abs().max() < 1e-5
+    hw = S.normal01(9, "ops.hw", (1, 64, 1, 1)).float() * 0.1
+    hb = torch.tensor([0.3])
+    hd = torch.ops.vidc.head_conv1x1_upsample(xh, hw.cuda(), hb.cuda(), 1, 120, 160, True).cpu()
+    ref = F.relu(F.interpolate(F.conv2d(x, hw, hb, padding=1), size=(120, 160), mode="bilinear", align_corners=True))
+    assert (hd - ref).abs().max() < 2e-5

@@ -109,7 +109,8 @@ def main():
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)                 # graph capture needs a non-default stream
     st = side.cuda_stream
-    ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)     # 256 MB split-K scratch
+    ws = torch.zeros(64 << 20, dtype=torch.float32, device=dev)     # 256 MB split-K scratch (zeroed: ticket counters at its head)
+    split_dst = torch.empty(64 << 20, dtype=torch.float32, device=dev)
     pool = (torch.randn(256 << 20, dtype=torch.float32, device=dev) * 0.05)     # 1 GB of weight copies (cold per launch)
     junk = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
     for H in [int(v) for v in a.heights.split(",")]:
@@ -139,7 +140,7 @@ def main():
                             for sk in [int(v) for v in a.splitk.split(",")]:
                                 if sk > 1 and (d.KH * d.KW * d.Cin // 32) // sk < 2:
                                     continue
-                                if sk > 1 and sk * d.groups * M * d.Cout > ws.numel():
+                                if sk > 1 and L.SPLITK_COUNTERS + sk * d.groups * M * d.Cout > ws.numel():
                                     continue
                                 d.tile, d.splitk = t, sk
                                 us = time_desc(lib, d, st, pool, junk)
@@ -151,7 +152,7 @@ def main():
                         best[prec] = cands[0]
                     # a bf16x3 conv needs its input split first (shared between consumers at best; charged in full here)
                     rows = d.B * d.H * d.W
-                    t_split = time_split(lib, d.x, ws.data_ptr(), rows, d.Cin * d.groups, d.ldx, st)
+                    t_split = time_split(lib, d.x, split_dst.data_ptr(), rows, d.Cin * d.groups, d.ldx, st)
                     us32, t32, sk32 = best[0]
                     us16, t16, sk16 = best[1]
                     prec = 1 if us16 + a.split_charge * t_split < 0.95 * us32 else 0

@@ -57,7 +57,7 @@ def run(shape, tile, splitk, iters=20, check=False, precision=0):
     lib = L.lib()
     if tile == 0:
         L.check(lib.vidc_conv2d_plan(C.byref(d)), "plan")
-    ws = torch.empty(max(4, lib.vidc_conv2d_workspace_bytes(C.byref(d)) // 4), device=dev)
+    ws = torch.zeros(max(4, lib.vidc_conv2d_workspace_bytes(C.byref(d)) // 4), device=dev)
     d.workspace = ws.data_ptr()
     st = torch.cuda.current_stream().cuda_stream
     rc = lib.vidc_conv2d_bn_act(C.byref(d), st)

@@ -27,6 +27,7 @@ TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: 
               19: "64x128L", 20: "128x64L", 21: "64x32k2", 22: "64x32k2d5", 23: "64x32k2d5L"}
 TILE_COUNT = 24
 PREC_FP32, PREC_BF16X3 = 0, 1
+SPLITK_COUNTERS = 16384            # VIDC_SPLITK_COUNTERS: ticket counters at the head of a split-K workspace
 
 _f32p = C.POINTER(C.c_float)
 

@@ -11,8 +11,8 @@
 //   LDS -> ds_read_b128 fragments.  Each lane's b128 holds 4 consecutive k of its row; MFMA t of a group consumes
 //   element t of the A and of the B fragment, i.e. the k-order inside an 8-wide chunk is permuted identically for both.
 //   Epilogue in registers: acc*scale1+shift1, relu, [*scale2+shift2, relu], [+residual, relu], [+= y], store NHWC
-//   at a channel offset (concat-free skip connections).  Split-K writes fp32 partials and a finalize kernel applies
-//   the same epilogue.  `groups` (blockIdx.z) runs the three ModifiedFPN pyramids in one launch.
+//   at a channel offset (concat-free skip connections).  Split-K: every k-slice workgroup writes its fp32 partial tile and
+//   the last one to arrive (ticket counter per tile) sums them in slice order and runs the same epilogue -- no second launch.  `groups` (blockIdx.z) runs the three ModifiedFPN pyramids in one launch.
 #include "common.h"
 #include <type_traits>
 
@@ -48,22 +48,6 @@ __host__ inline void fast_div_init(unsigned d, unsigned out[3]) {
 }
 __device__ __forceinline__ unsigned fast_div(unsigned n, const unsigned dv[3]) {
     return (__umulhi(n, dv[0]) >> dv[1]) + (n & dv[2]);
-}
-
-__device__ inline float epilogue(float v, int n, size_t off_r, size_t off_y, const ConvArgs& a, const float* s1, const float* b1,
-                                 const float* s2, const float* b2, const float* res, const float* y) {
-    v = v * s1[n] + b1[n];
-    if (a.flags & VIDC_RELU1) v = fmaxf(v, 0.f);
-    if (a.flags & VIDC_AFFINE2) {
-        v = v * s2[n] + b2[n];
-        if (a.flags & VIDC_RELU2) v = fmaxf(v, 0.f);
-    }
-    if (a.flags & VIDC_RESIDUAL) {
-        v += res[off_r];
-        if (a.flags & VIDC_RELU3) v = fmaxf(v, 0.f);
-    }
-    if (a.flags & VIDC_ACCUM) v += y[off_y];
-    return v;
 }
 
 using vidc::bf16_rne;
@@ -521,6 +505,72 @@ conv_igemm_f32(const ConvArgs a) {
     const bool aff2 = a.flags & VIDC_AFFINE2, has_res = a.flags & VIDC_RESIDUAL, accum = a.flags & VIDC_ACCUM;
     const bool st_f32 = !(a.flags & VIDC_NO_F32_OUT), st_split = a.flags & VIDC_SPLIT_OUT;
     unsigned short* ysp = st_split ? a.y_split + (size_t)g * a.y_gs * 2 : nullptr;
+#ifndef VIDC_CONV_TIMING
+    // ---- split-K without a second launch: every k-slice workgroup stores its fp32 partial tile, takes a ticket on the tile's
+    //      counter (head of the workspace; device-scope atomic), and the LAST one to arrive sums the splitk partials in slice
+    //      order 0..splitk-1 (its own included, re-read from the workspace) and runs the normal epilogue below.  The sum does not
+    //      depend on the arrival order, so the result is bit-reproducible; the counter is left at zero for the next launch.
+    if (a.splitk > 1) {
+        float* part = a.ws + VIDC_SPLITK_COUNTERS;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nb = n0 + wn * 32 * TN + j * 32;
+                if (nb >= a.Cout) continue;
+                const int mrow = m0 + wm * 32 * TM + i * 32 + 4 * lh;
+                float* wsp = part + ((size_t)(kz * a.groups + g) * a.M) * a.Cout + nb + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mrow + (r & 3) + 8 * (r >> 2);
+                    if (m < a.M) __hip_atomic_store(wsp + (size_t)m * a.Cout, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        // The partials travel as relaxed agent-scope atomics (sc1 write-through stores here, sc1 loads below), so they are coherent
+        // across the XCDs' L2s without a release/acquire fence pair: an agent-scope fence writes back / invalidates the WHOLE L2 of
+        // the XCD (buffer_wbl2 / buffer_inv), which cost ~50 us per launch with HBM-cold weight tiles in flight.  Ordering is by
+        // completion instead: every store has been acknowledged (vmcnt 0) before the barrier that precedes the ticket.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                    // (only the WPK epilogue waves are still alive; the ring is free from here on)
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            unsigned* cnt = reinterpret_cast<unsigned*>(a.ws) + ((size_t)g * a.tiles_n + tile_n) * a.tiles_m + tile_m;
+            const unsigned ticket = atomicAdd(cnt, 1u);
+            const bool last = ticket == (unsigned)(a.splitk - 1);
+            if (last) atomicExch(cnt, 0u);
+            *flag = last ? 1 : 0;
+        }
+        __syncthreads();
+        if (*reinterpret_cast<volatile int*>(flag) == 0) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nb = n0 + wn * 32 * TN + j * 32;
+                if (nb >= a.Cout) continue;
+                const int mrow = m0 + wm * 32 * TM + i * 32 + 4 * lh;
+                const int n = nb + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int z = 0; z < a.splitk; ++z) {
+                    const float* wsp = part + ((size_t)(z * a.groups + g) * a.M) * a.Cout + n;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = min(mrow + (r & 3) + 8 * (r >> 2), a.M - 1);
+                        acc[i][j][r] += __hip_atomic_load(wsp + (size_t)m * a.Cout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (has_res) {
+                    const int nc = min(n, a.Cout - 1);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = min(mrow + (r & 3) + 8 * (r >> 2), a.M - 1);
+                        e_res[i][j][r] = res[(size_t)m * a.ldr + nc];
+                    }
+                }
+            }
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -531,17 +581,6 @@ conv_igemm_f32(const ConvArgs a) {
             const int mb = m0 + wm * 32 * TM + i * 32;             // first row of this tile (wave-uniform)
             const int mrow = mb + 4 * lh;
             const bool full = mb + 32 <= a.M;
-#ifndef VIDC_CONV_TIMING
-            if (a.splitk > 1) {
-                float* wsp = a.ws + ((size_t)(kz * a.groups + g) * a.M) * a.Cout + n;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mrow + (r & 3) + 8 * (r >> 2);
-                    if (full || m < a.M) wsp[(size_t)m * a.Cout] = acc[i][j][r];
-                }
-                continue;
-            }
-#endif
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[i][j][r] * e_s1[j] + e_b1[j], lo1);
@@ -588,34 +627,6 @@ conv_igemm_f32(const ConvArgs a) {
 #ifdef VIDC_CONV_TIMING
     if (threadIdx.x == 0) dbg[7] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-}
-
-// Sums the split-K partials and applies the fused epilogue; one thread per 4 output channels.
-__global__ void __launch_bounds__(256) conv_splitk_finalize(const ConvArgs a) {
-    const int g = blockIdx.z;
-    const int q = a.Cout / 4;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)a.M * q) return;
-    const int m = (int)(idx / q), n = (int)(idx - (long long)m * q) * 4;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < a.splitk; ++z) {
-        float4 v = *reinterpret_cast<const float4*>(&a.ws[((size_t)(z * a.groups + g) * a.M + m) * a.Cout + n]);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    const float* s1 = a.scale1 + g * a.p_gs;
-    const float* b1 = a.shift1 + g * a.p_gs;
-    const float* s2 = a.scale2 ? a.scale2 + g * a.p_gs : nullptr;
-    const float* b2 = a.shift2 ? a.shift2 + g * a.p_gs : nullptr;
-    const float* res = a.residual ? a.residual + g * a.r_gs : nullptr;
-    float* yg = a.y + g * a.y_gs;
-    float v[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        size_t oy = (size_t)m * a.ldy + n + t;
-        const float o = epilogue(v[t], n + t, (size_t)m * a.ldr + n + t, oy, a, s1, b1, s2, b2, res, yg);
-        if (!(a.flags & VIDC_NO_F32_OUT)) yg[oy] = o;
-        if (a.flags & VIDC_SPLIT_OUT) store_split(a.y_split + (size_t)g * a.y_gs * 2, (size_t)m, a.ldy, n + t, o);
-    }
 }
 
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
@@ -790,7 +801,7 @@ extern "C" int vidc_conv2d_plan(vidc_conv_desc* d) {
 
 extern "C" size_t vidc_conv2d_workspace_bytes(const vidc_conv_desc* d) {
     if (!d || d->splitk <= 1) return 0;
-    return (size_t)d->splitk * d->groups * d->B * d->Ho * d->Wo * d->Cout * sizeof(float);
+    return ((size_t)VIDC_SPLITK_COUNTERS + (size_t)d->splitk * d->groups * d->B * d->Ho * d->Wo * d->Cout) * sizeof(float);
 }
 
 extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream) {
@@ -816,6 +827,7 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
     {
         const int stages = (a.ksteps + ti.wkw - 1) / ti.wkw;
         if (a.splitk > stages) a.splitk = stages;
+        if ((long long)a.tiles_m * a.tiles_n * a.groups > VIDC_SPLITK_COUNTERS) a.splitk = 1;    // one ticket counter per output tile
     }
     fast_div_init((unsigned)a.tiles_m, a.dv_tiles_m);
     fast_div_init((unsigned)a.splitk, a.dv_splitk);
@@ -850,14 +862,7 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         case VIDC_TILE_64x32_K2_D5_L:  rc = launch_tile<64, 32, 2, 1, 2, 5, 1>(a, st, dd.precision); break;
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
-    if (rc != VIDC_OK) return rc;
-    if (a.splitk > 1) {
-        long long n4 = (long long)a.M * (a.Cout / 4);
-        dim3 grid((unsigned)((n4 + 255) / 256), 1, a.groups);
-        hipLaunchKernelGGL(conv_splitk_finalize, grid, dim3(256), 0, st, a);
-        VIDC_CHECK_LAUNCH("conv_splitk_finalize");
-    }
-    return VIDC_OK;
+    return rc;
 }
 
 extern "C" int vidc_split_bf16x3(const float* x, void* y, long long rows, int C, int ldx, vidc_stream_t stream) {

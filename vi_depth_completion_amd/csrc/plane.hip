@@ -60,31 +60,50 @@ __device__ inline int first_argmax(const int32_t* c, int n) {
     return n > 0 ? best : 0;
 }
 
-// ---- stage 1a: inlier counts of every hypothesis.  threads = hypotheses, 256 pixels of one slot staged in LDS ---------
+// ---- stage 1a: inlier counts of every hypothesis.  threads = hypotheses; 256 pixels of one slot are compacted into LDS (ballot
+//      ranks, one float4 per pixel, zero-padded to a multiple of 4), the inner loop takes 4 points per step with the four broadcast
+//      ds_read_b128 issued up front and the rare borderline acosf kept out of the straight-line code -----------------------------
 __global__ void __launch_bounds__(320)
 ransac_count_kernel(const float* __restrict__ normals, const uint8_t* __restrict__ ids, const Slot* __restrict__ slots,
                     const int32_t* __restrict__ hyp_pix, int HW, int32_t* __restrict__ counts) {
-    __shared__ float px[CH], py[CH], pz[CH];
-    __shared__ int n_mine;
+    __shared__ float4 pts[CH + 4];
+    __shared__ int wcnt[CH / 64];
     const Slot s = slots[blockIdx.y];
     const float* nb = normals + (size_t)s.b * 3 * HW;
     const uint8_t* idb = ids + (size_t)s.b * HW;
-    if (threadIdx.x == 0) n_mine = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x * CH + threadIdx.x;
+    const bool mine = threadIdx.x < CH && p < HW && idb[p] == (uint8_t)s.cls;
+    const unsigned long long bal = __ballot(mine);
+    if (lane == 0 && wave < CH / 64) wcnt[wave] = __popcll(bal);
     __syncthreads();
-    if (threadIdx.x < CH) {          // compact this chunk's pixels of the class into LDS (order is irrelevant for a count)
-        const int p = blockIdx.x * CH + threadIdx.x;
-        if (p < HW && idb[p] == (uint8_t)s.cls) {
-            int k = atomicAdd(&n_mine, 1);
-            px[k] = nb[p]; py[k] = nb[HW + p]; pz[k] = nb[2 * HW + p];
-        }
-    }
+    int n = 0, k = __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < CH / 64; ++w) { n += wcnt[w]; if (w < wave) k += wcnt[w]; }
+    if (n == 0) return;
+    if (mine) pts[k] = make_float4(nb[p], nb[HW + p], nb[2 * HW + p], 0.f);
+    if (threadIdx.x < 4) pts[n + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);     // dot = 0: neither close nor borderline
     __syncthreads();
-    const int n = n_mine;
-    if (n == 0 || (int)threadIdx.x >= s.n_hyp) return;
+    if ((int)threadIdx.x >= s.n_hyp) return;
     const int hp = hyp_pix[s.hyp_off + threadIdx.x];
     const float hx = nb[hp], hy = nb[HW + hp], hz = nb[2 * HW + hp];
     int c = 0;
-    for (int k = 0; k < n; ++k) c += close_angle(dot3(hx, hy, hz, px[k], py[k], pz[k])) ? 1 : 0;
+    for (int i = 0; i < n; i += 4) {
+        const float4 q0 = pts[i], q1 = pts[i + 1], q2 = pts[i + 2], q3 = pts[i + 3];
+        float t[4] = {dot3(hx, hy, hz, q0.x, q0.y, q0.z), dot3(hx, hy, hz, q1.x, q1.y, q1.z), dot3(hx, hy, hz, q2.x, q2.y, q2.z),
+                      dot3(hx, hy, hz, q3.x, q3.y, q3.z)};
+        bool edge = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {               // same decision as close_angle(): clamp, cosine far from the threshold, acosf near it
+            t[j] = fminf(fmaxf(t[j], -1.0f), 1.0f);
+            c += t[j] > COS_THR + 1e-4f ? 1 : 0;
+            edge |= fabsf(t[j] - COS_THR) <= 1e-4f;
+        }
+        if (__builtin_expect(edge, 0)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (fabsf(t[j] - COS_THR) <= 1e-4f) c += acosf(t[j]) * RAD2DEG < ANGLE_THR ? 1 : 0;
+        }
+    }
     if (c) atomicAdd(&counts[blockIdx.y * VIDC_MAX_HYP + threadIdx.x], c);     // integer: order-independent
 }
 
@@ -268,35 +287,80 @@ plane_offset_kernel(const float* __restrict__ homo, const float* __restrict__ de
     }
 }
 
-// Row-major list of the pixels with depth > 0 of every image.  One workgroup per image walks the map 1024 pixels at a time with
-// coalesced loads; the ordered compaction of a step is a ballot + popcount per wave and a 16-entry scan across the waves.
+// Row-major list of the pixels with depth > 0 of every image.  One workgroup (16 waves) per image; wave w owns the w-th contiguous
+// sixteenth of the map (a multiple of 256 pixels).  Pass 1 counts the wave's candidates (independent float4 loads, no barrier),
+// one barrier publishes the 16 totals, pass 2 re-reads the segment (cache hits) and emits the indices in row-major order: inside a
+// 256-pixel step the order is lane-major / component-minor, so a pixel's rank is four masked popcounts plus its lane-local prefix.
 __global__ void __launch_bounds__(1024)
 sparse_list_kernel(const float* __restrict__ depth, int HW, int max_sparse, int32_t* __restrict__ sparse_idx,
                    int32_t* __restrict__ n_sparse) {
     __shared__ int wcount[16];
-    __shared__ int base;
     const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float* db = depth + (size_t)b * HW;
-    if (threadIdx.x == 0) base = 0;
-    __syncthreads();
-    for (int p0 = 0; p0 < HW; p0 += 1024) {
-        const int p = p0 + threadIdx.x;
-        const bool f = p < HW && db[p] > 0.f;
-        const unsigned long long bal = __ballot(f);
-        if (lane == 0) wcount[wv] = __popcll(bal);
-        __syncthreads();
-        int k = base + __popcll(bal & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wv; ++w) k += wcount[w];
-        if (f && k < max_sparse) sparse_idx[(size_t)b * max_sparse + k] = p;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int t = 0;
-            for (int w = 0; w < 16; ++w) t += wcount[w];
-            base += t;
+    const int seg = ((HW + 16 * 256 - 1) / (16 * 256)) * 256;
+    const int lo = wv * seg, hi = min(lo + seg, HW);
+    const bool vec = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(db) & 15) == 0;
+    auto load4 = [&](int p, bool (&f)[4]) {
+        if (vec && p + 3 < hi) {
+            const float4 v = *reinterpret_cast<const float4*>(db + p);
+            f[0] = v.x > 0.f; f[1] = v.y > 0.f; f[2] = v.z > 0.f; f[3] = v.w > 0.f;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) f[c] = p + c < hi && db[p + c] > 0.f;
         }
-        __syncthreads();
+    };
+    int cnt = 0;
+    int p0 = lo;
+    if (vec) {                                         // straight-line body: 4 independent 16-byte loads in flight per lane
+        for (; p0 + 1024 <= hi; p0 += 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(db + p0 + u * 256 + lane * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cnt += (int)(v[u].x > 0.f) + (int)(v[u].y > 0.f) + (int)(v[u].z > 0.f) + (int)(v[u].w > 0.f);
+        }
     }
-    if (threadIdx.x == 0) n_sparse[b] = base;
+    for (; p0 < hi; p0 += 256) {
+        bool f[4];
+        load4(p0 + lane * 4, f);
+        cnt += (int)f[0] + (int)f[1] + (int)f[2] + (int)f[3];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) wcount[wv] = cnt;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < 16; ++w) { const int c = wcount[w]; total += c; if (w < wv) base += c; }
+    if (threadIdx.x == 0) n_sparse[b] = total;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int32_t* out = sparse_idx + (size_t)b * max_sparse;
+    auto emit = [&](int p, const bool (&f)[4]) {       // 256 pixels: p = this lane's first one
+        const unsigned long long b0 = __ballot(f[0]), b1 = __ballot(f[1]), b2 = __ballot(f[2]), b3 = __ballot(f[3]);
+        if ((b0 | b1 | b2 | b3) == 0ull) return;
+        int k = base + __popcll(b0 & below) + __popcll(b1 & below) + __popcll(b2 & below) + __popcll(b3 & below);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (f[c]) { if (k < max_sparse) out[k] = p + c; ++k; }
+        base += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+    };
+    p0 = lo;
+    if (vec) {
+        for (; p0 + 1024 <= hi; p0 += 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(db + p0 + u * 256 + lane * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool f[4] = {v[u].x > 0.f, v[u].y > 0.f, v[u].z > 0.f, v[u].w > 0.f};
+                emit(p0 + u * 256 + lane * 4, f);
+            }
+        }
+    }
+    for (; p0 < hi; p0 += 256) {
+        bool f[4];
+        load4(p0 + lane * 4, f);
+        emit(p0 + lane * 4, f);
+    }
 }
 
 // ---- stage 3: depth = -d / (n . homo) on the plane: per-chunk validity statistics, then the masked write ---------------
@@ -332,17 +396,16 @@ plane_stats_kernel(const float* __restrict__ homo, const Slot* __restrict__ slot
 __global__ void __launch_bounds__(CH)
 plane_write_kernel(const float* __restrict__ homo, const Slot* __restrict__ slots, const uint8_t* __restrict__ inlier_mask, int HW,
                    float* __restrict__ records, const int32_t* __restrict__ stats, float* __restrict__ plane_depth) {
-    __shared__ int tot[4];
+    __shared__ int redi[CH / 64];
     const Slot s = slots[blockIdx.y];
     float* rec = records + (size_t)blockIdx.y * VIDC_PLANE_RECORD;
     if (rec[6] == 0.f || rec[9] == 0.f) return;
-    if (threadIdx.x < 4) {
-        int t = 0;
-        for (int c = 0; c < (int)gridDim.x; ++c) t += stats[((size_t)blockIdx.y * gridDim.x + c) * 4 + threadIdx.x];
-        tot[threadIdx.x] = t;
+    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;              // integer sums: any order gives the same totals
+    for (int c = threadIdx.x; c < (int)gridDim.x; c += CH) {
+        const int32_t* q = stats + ((size_t)blockIdx.y * gridDim.x + c) * 4;
+        t0 += q[0]; t1 += q[1]; t2 += q[2]; t3 += q[3];
     }
-    __syncthreads();
-    const int n = tot[0], n_big = tot[1], n_over = tot[2], n_neg = tot[3];
+    const int n = block_sum(t0, redi), n_big = block_sum(t1, redi), n_over = block_sum(t2, redi), n_neg = block_sum(t3, redi);
     bool valid = true;                                 // main.py:120-125 (true division)
     if (n > 0) {
         if ((float)n_big / (float)n > 0.05f || n_over > 0) valid = false;

@@ -633,8 +633,9 @@ class Program:
                 self.op_names.append("copy")
             else:
                 raise ValueError(kind)
-        # split-K workspaces (one per stream id so concurrent convs never share partials)
-        self.workspaces = {sid: torch.empty(nb // 4 + 4, dtype=torch.float32, device=self.device) for sid, nb in ws_need.items()}
+        # split-K workspaces (one per stream id so concurrent convs never share partials); zeroed once: their heads hold the
+        # per-tile ticket counters of the fused split-K reduction, which every launch leaves at zero (include/vidc.h)
+        self.workspaces = {sid: torch.zeros(nb // 4 + 4, dtype=torch.float32, device=self.device) for sid, nb in ws_need.items()}
         for op in conv_ops:
             if op.u.conv.splitk > 1:
                 op.u.conv.workspace = self.workspaces[op.stream_id].data_ptr()
