@@ -212,3 +212,25 @@ def synthetic_camera_batch(batch, src_height=480, src_width=640, seed=1234, n_sp
         y = (row - DEMO_CC[1] * Ho / 240.0) / DEMO_FC[1] * z
         tracks.append(np.stack([np.arange(n_sparse, dtype=np.float64), x, y, z], axis=1))
     return {"image_u8": torch.stack(imgs), "gravity_raw": np.asarray(gravs, dtype=np.float64), "klt_tracks": tracks}
+
+
+def seeded_detector_state_dict(reference_state, seed, device="cpu"):
+    """Seeded parameters for the plane-mask detector (networks/plane_mask_rcnn.py; the reference's GeneralizedRCNN state_dict layout,
+    SURVEY.md §8f-1): `seeded_state_dict` for every learnable / FrozenBatchNorm entry, the anchor buffers kept as they are, and four
+    calibrations so that random weights give a non-degenerate detector: the stem's BN gain divides the 0..255-scale input down to O(1)
+    activations (otherwise every sigmoid saturates and top-k / NMS decisions are ties), the class head is biased towards the plane
+    class and the mask head towards "inside", so that a few detections pass the 0.9 confidence threshold with large masks."""
+    learn = {k: v for k, v in reference_state.items() if "anchor_generator" not in k}
+    out = seeded_state_dict(learn, seed, device)
+    for k, v in reference_state.items():
+        if "anchor_generator" in k:
+            out[k] = v.detach().clone().to(device)
+    out["backbone.body.stem.bn1.weight"] = out["backbone.body.stem.bn1.weight"] / 70.0
+    for k in list(out):          # the residual stages still grow the activations ~20x: the FPN laterals bring the pyramid back to O(1)
+        if ".fpn.fpn_inner" in k:
+            out[k] = out[k] * 0.05
+    if "roi_heads.box.predictor.cls_score.bias" in out:
+        out["roi_heads.box.predictor.cls_score.bias"] = torch.tensor([-1.0, 1.0], dtype=torch.float32, device=device)
+    if "roi_heads.mask.predictor.mask_fcn_logits.bias" in out:
+        out["roi_heads.mask.predictor.mask_fcn_logits.bias"] = torch.tensor([0.0, 0.75], dtype=torch.float32, device=device)
+    return out
