@@ -289,12 +289,59 @@ int vidc_roi_align_forward(const float* x_nhwc, const float* rois, float* y, int
                            int pooled_w, float spatial_scale, int sampling_ratio, vidc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * plane-mask detector: everything of COCODemo.run_on_tensor that is not a convolution   (plane_mask_detection/demo/predictor.py:143-150;
+ * SURVEY §8f-1).  Static shapes: R proposal / detection slots per image with the live counts in device memory; no host synchronisation.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* demo/predictor.py:101-118,143-144 (uint8 cast of 255*image, BGR, x255, - PIXEL_MEAN) + to_image_list's zero padding to Hp x Wp, written
+ * as the im2col matrix of the 7x7 / stride 2 / pad 3 stem: cols [B][Hp/2][Wp/2][160], column (kh*7+kw)*3 + c (c = B,G,R), 147..159 = 0. */
+int vidc_det_stem_im2col(const float* image01_nchw, float* cols, int B, int H, int W, int Hp, int Wp, float mean_b, float mean_g,
+                         float mean_r, vidc_stream_t stream);
+/* F.interpolate(x, scale_factor=2, mode="nearest") of the FPN top-down path (modeling/backbone/fpn.py:66-72), NHWC. */
+int vidc_upsample_nearest2x(const float* x, float* y, int B, int h, int w, int C, int ldx, int ldy, vidc_stream_t stream);
+/* RPNPostProcessor.forward_for_single_feature_map up to NMS (modeling/rpn/inference.py:74-100): rpn_map [B][h][w][ld] holds A objectness
+ * logits then 4A box deltas per pixel; sigmoid, the k = min(pre_nms_top_n, A*h*w) best in descending order (ties: lower (h,w,a) index
+ * first), anchors (cell_anchors_host [A][4], host memory, + the pixel's stride offset), BoxCoder(1,1,1,1).decode, clip to the image.
+ * boxes [B][out_stride][4] / scores [B][out_stride]: the first k entries of every image are written. */
+int vidc_rpn_topk_decode(const float* rpn_map, int B, int h, int w, int ld, int A, int stride, const float* cell_anchors_host,
+                         int pre_nms_top_n, int img_h, int img_w, float* boxes, float* scores, long long out_stride, vidc_stream_t stream);
+/* The first per_level NMS survivors of every level (keep / n_keep as written by vidc_nms per level: keep [B][slots] at the level's
+ * offset, indices relative to it; n_keep [B][n_levels]), then the `total` best over all levels (modeling/rpn/inference.py:103-108,
+ * 148-190).  level_offsets_host [n_levels + 1] (host memory).  proposals [B][total][4] (zero-filled beyond n_proposals[b]). */
+int vidc_rpn_select(const float* boxes, const float* scores, const int32_t* keep, const int32_t* n_keep, int B, int n_levels,
+                    const int32_t* level_offsets_host, int per_level, int total, float* proposals, float* proposal_scores,
+                    int32_t* n_proposals, vidc_stream_t stream);
+/* Pooler.forward (modeling/poolers.py:11-122): LevelMapper + ROIAlign from the mapped level of P2..P5.  feats_host: 4 device pointers to
+ * NHWC [B][h][w][C] maps (host array), hw_host [4][2]; boxes [B][R][4] (image index = slot / R); y [B*R][pooled][pooled][C]. */
+int vidc_roi_align_fpn(const float* const* feats_host, const int32_t* hw_host, int n_levels, int C, const float* boxes, int B, int R,
+                       int pooled, int sampling_ratio, float* y, vidc_stream_t stream);
+/* PostProcessor.forward / filter_results for the two-class head (modeling/roi_heads/box_head/inference.py:47-146), in two steps around
+ * vidc_nms.  head_out [B*R][ld]: 2 class logits, 8 box deltas.  Candidates = plane-class probability > score_thresh, decoded with
+ * BoxCoder(10,10,5,5) and clipped, in descending score order (cand_src = proposal slot); unused slots hold far-away unit boxes. */
+int vidc_det_candidates(const float* head_out, int ld, const float* proposals, const int32_t* n_proposals, int B, int R, int img_h, int img_w,
+                        float score_thresh, float* cand_boxes, float* cand_scores, int32_t* cand_src, int32_t* n_cand, vidc_stream_t stream);
+/* NMS survivors (keep / n_keep [B][R] / [B] from vidc_nms over the R candidate slots) in ascending proposal order, like the reference. */
+int vidc_det_select(const float* cand_boxes, const float* cand_scores, const int32_t* cand_src, const int32_t* n_cand, const int32_t* keep,
+                    const int32_t* n_keep, int B, int R, float* det_boxes, float* det_scores, int32_t* n_det, vidc_stream_t stream);
+/* MaskPostProcessor + Masker(threshold, padding 1) (modeling/roi_heads/mask_head/inference.py:27-49, 86-150): sigmoid of the detection's
+ * class channel `cls`, zero border, box expansion, bilinear resize (align_corners=False) to the integer box, threshold, paste.
+ * mask_logits [B*R][M/2][M/2*4][ld]: the 2x2 transposed conv as a 1x1 conv to 4 sub-pixel channel blocks; pasted [B][R][H][W] uint8. */
+int vidc_mask_paste(const float* mask_logits, int ld, int cls, int M, const float* det_boxes, const int32_t* n_det, int B, int R, int H, int W,
+                    float thresh, uint8_t* pasted, vidc_stream_t stream);
+/* select_top_predictions + overlay_mask (demo/predictor.py:201-220, 253-323): detections with score > confidence in descending score
+ * order, the biggest 4-connected component of each mask, those of at least min_fraction * H * W pixels numbered 1.. by descending size
+ * and painted in that order.  inst [B][H][W] uint8. */
+size_t vidc_instance_map_scratch_bytes(int B, int R, int H, int W);
+int vidc_instance_map(const uint8_t* pasted, const float* det_scores, const int32_t* n_det, int B, int R, int H, int W, float confidence,
+                      float min_fraction, uint8_t* inst, void* scratch, vidc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * programs: a whole network (or the whole frame) as one native call / one hipGraph
  * ---------------------------------------------------------------------------------------------- */
 
 enum vidc_op_kind { VIDC_OP_CONV = 1, VIDC_OP_STEM = 2, VIDC_OP_MAXPOOL = 3, VIDC_OP_UPSAMPLE = 4, VIDC_OP_HEAD = 5,
                     VIDC_OP_WARP_PARAMS = 6, VIDC_OP_WARP_FWD = 7, VIDC_OP_WARP_INV = 8, VIDC_OP_COPY = 9, VIDC_OP_SPLIT = 10,
-                    VIDC_OP_AVGPOOL = 11, VIDC_OP_NORMALIZE = 12 };
+                    VIDC_OP_AVGPOOL = 11, VIDC_OP_NORMALIZE = 12, VIDC_OP_DET_IM2COL = 13, VIDC_OP_NEAREST2X = 14 };
 
 typedef struct vidc_generic_args {   /* arguments of the non-conv launchers, in declaration order */
     const void* p[6];

@@ -79,3 +79,134 @@ def test_fast_nms_equals_pinned_nms():
         scores = rng.uniform(0, 1, n).astype(np.float32)
         for thr in (0.3, 0.5, 0.7):
             assert np.array_equal(PM.nms(torch.from_numpy(boxes), torch.from_numpy(scores), thr).numpy(), DO.nms(boxes, scores, thr))
+
+
+def test_detector_state_dict_layout(golden_dir):
+    """The module exposes the reference GeneralizedRCNN's 648 state_dict entries, same names, order and shapes (strict load_state_dict)."""
+    from vi_depth_completion_amd.networks.plane_mask_rcnn import GeneralizedRCNN
+    man = np.load(os.path.join(golden_dir, "plane_mask_manifest.npz"))
+    sd = GeneralizedRCNN().state_dict()
+    assert list(sd.keys()) == [str(k) for k in man["keys"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in man["shapes"]]
+    anchors = torch.cat([v for k, v in sd.items() if "anchor_generator" in k]).numpy()
+    assert np.array_equal(anchors, man["anchors"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# GPU: HIP path vs the oracle
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.fixture(scope="module")
+def detector(detector_weights):
+    from vi_depth_completion_amd.plane_mask import PlaneMaskDetector
+    det = PlaneMaskDetector(device="cuda")
+    det.load_state_dict({k: v.cuda() for k, v in detector_weights.items()})
+    return det
+
+
+def _rpn_maps(taps, dev="cuda"):
+    """the oracle's per-level (logits (1,3,h,w), deltas (1,12,h,w)) as the engine's (1,h,w,32) maps"""
+    out = []
+    for lg, dl in zip(taps["rpn_logits"], taps["rpn_deltas"]):
+        m = torch.zeros(lg.shape[0], lg.shape[2], lg.shape[3], 32)
+        m[..., 0:3] = lg.permute(0, 2, 3, 1)
+        m[..., 3:15] = dl.permute(0, 2, 3, 1)
+        out.append(m.to(dev))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["demo", "synthetic"])
+def test_dense_program_matches_oracle(detector, oracle_runs, name):
+    """Backbone + FPN + RPN head.  Tolerance: activations are O(1) (max ~3); bf16x3 / fp32-MFMA summation-order noise through ~110
+    convs: max |diff| 5e-3, mean 2e-4 (observed ~1e-3 / 3e-5)."""
+    g, t, _ = oracle_runs[name]
+    img = torch.from_numpy(g["image"])[None].cuda()
+    dense = detector.dense(img)
+    for l in range(4):
+        got = dense.tensor(dense.outputs["P%d" % (l + 2)]).cpu()
+        d = (got - _nhwc(t["feats"][l])).abs()
+        assert d.max() < 5e-3 and d.mean() < 2e-4, (l, float(d.max()), float(d.mean()))
+    for l in range(5):
+        got = dense.tensor(dense.outputs["rpn%d" % l]).cpu()
+        d1 = (got[..., 0:3] - _nhwc(t["rpn_logits"][l])).abs()
+        d2 = (got[..., 3:15] - _nhwc(t["rpn_deltas"][l])).abs()
+        assert d1.max() < 5e-3 and d2.max() < 5e-3, (l, float(d1.max()), float(d2.max()))
+        assert float(got[..., 15:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["demo", "synthetic"])
+def test_proposals_from_oracle_rpn_maps(detector, oracle_runs, name):
+    """Top-k, decode, clip, NMS, selection over levels on the ORACLE's RPN maps: same proposals in the same order (boxes 1e-3 px: expf)."""
+    g, t, _ = oracle_runs[name]
+    props, sc, n = detector.proposals(_rpn_maps(t), 1, 240, 320)
+    assert int(n[0]) == t["proposals"].shape[0]
+    k = int(n[0])
+    assert (sc[0, :k].cpu() - t["objectness"]).abs().max() < 1e-6
+    assert (props[0, :k].cpu() - t["proposals"]).abs().max() < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["demo", "synthetic"])
+def test_box_head_and_detections_from_oracle_inputs(detector, oracle_runs, name):
+    g, t, _ = oracle_runs[name]
+    feats = [_nhwc(f).cuda() for f in t["feats"][:4]]
+    k = t["proposals"].shape[0]
+    props = torch.zeros(1, 50, 4)
+    props[0, :k] = t["proposals"]
+    head = detector.box_head(feats, props.cuda(), 1, 240, 320).cpu()
+    assert (head[:k, 0:2] - t["class_logits"]).abs().max() < 3e-3 and (head[:k, 2:10] - t["box_regression"]).abs().max() < 3e-3
+    # detections on the oracle's head outputs
+    h = torch.zeros(50, 32)
+    h[:k, 0:2], h[:k, 2:10] = t["class_logits"], t["box_regression"]
+    n_props = torch.tensor([k], dtype=torch.int32)
+    db, ds, nd = detector.detections(h.cuda(), props.cuda(), n_props.cuda(), 1, 240, 320)
+    m = t["det_boxes"].shape[0]
+    assert int(nd[0]) == m
+    assert (db[0, :m].cpu() - t["det_boxes"]).abs().max() < 1e-3 and (ds[0, :m].cpu() - t["det_scores"]).abs().max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["demo", "synthetic"])
+def test_mask_head_paste_and_instance_map_from_oracle_inputs(detector, oracle_runs, name):
+    g, t, inst = oracle_runs[name]
+    feats = [_nhwc(f).cuda() for f in t["feats"][:4]]
+    m = t["det_boxes"].shape[0]
+    det = torch.zeros(1, 50, 4)
+    det[0, :m] = t["det_boxes"]
+    logits = detector.mask_logits(feats, det.cuda(), 1, 240, 320)                       # (50, 14, 56, 32)
+    lg = logits[:m, :, :, 1].cpu().view(m, 14, 14, 2, 2).permute(0, 1, 3, 2, 4).reshape(m, 28, 28)       # [h][w][(i,j)] -> [2h+i][2w+j]
+    assert (lg.sigmoid() - t["mask_prob"][:, 0]).abs().max() < 3e-3
+    # paste + instance map on the oracle's probabilities
+    p = t["mask_prob"][:, 0].clamp(1e-7, 1 - 1e-7)
+    ol = torch.log(p / (1 - p)).view(m, 14, 2, 14, 2).permute(0, 1, 3, 2, 4).reshape(m, 14, 56)
+    full = torch.zeros(50, 14, 56, 32)
+    full[:m, :, :, 1] = ol
+    n_det = torch.tensor([m], dtype=torch.int32).cuda()
+    pasted = detector.paste(full.cuda(), det.cuda(), n_det, 1, 240, 320)
+    diff = (pasted[0, :m].cpu() != t["pasted"]).float().mean()
+    assert diff < 2e-4, float(diff)                  # pixels whose interpolated probability sits within rounding of 0.5
+    sc = torch.zeros(1, 50)
+    sc[0, :m] = t["det_scores"]
+    full_p = torch.zeros(1, 50, 240, 320, dtype=torch.uint8)
+    full_p[0, :m] = t["pasted"]
+    got = detector.instance_map(full_p.cuda(), sc.cuda(), n_det, 1, 240, 320)[0].cpu().numpy()
+    assert np.array_equal(got, inst)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["demo", "synthetic"])
+def test_run_on_tensor_end_to_end(detector, oracle_runs, name):
+    """Image -> instance-id map, nothing teacher-forced.  Discrete decisions (top-k order, NMS, the 0.9 / 0.5 / 5 % thresholds) sit on
+    floats that differ by ~1e-3 between the HIP convs and torch-CPU, so single detections may flip; bar: >= 97 % of the pixels carry the
+    reference's id."""
+    g, _t, inst = oracle_runs[name]
+    got = detector.run_on_tensor(torch.from_numpy(g["image"]))
+    assert got.shape == inst.shape and got.dtype == np.uint8
+    agree = float((got == inst).mean())
+    print("instance map agreement %s: %.4f, planes %d vs %d" % (name, agree, got.max(), inst.max()))
+    assert agree >= 0.97

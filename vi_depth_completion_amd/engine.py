@@ -53,6 +53,7 @@ class WeightStore:
         self._cache = {}
         self._sd = None
         self._virtual = {}       # name -> fn(state_dict) : derived entries (e.g. a Linear weight re-laid-out for NHWC activations)
+        self.bn_eps = 1e-5       # nn.BatchNorm2d's default; 0 for the detector's FrozenBatchNorm2d (layers/batch_norm.py: no eps)
 
     def add_virtual(self, name, fn):
         if name not in self._virtual:
@@ -104,7 +105,7 @@ class WeightStore:
                 bias = bias.double() if bias is not None else torch.zeros(co, dtype=torch.float64, device=dev)
                 if bn_keys is not None:
                     bn = bn_keys[g]
-                    s = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + 1e-5)
+                    s = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + self.bn_eps)
                     t = sd[bn + ".bias"].double() - sd[bn + ".running_mean"].double() * s + bias * s
                 else:
                     s, t = torch.ones(co, dtype=torch.float64, device=dev), bias
@@ -313,6 +314,19 @@ class Program:
         y = self.nhwc(Ho, Wo, co, G)
         for g in range(G):
             self._emit("stem", [xs[g]], [y], x=xs[g], y=y, key=keys[g], g=g, relu=relu)
+        return y
+
+    def det_im2col(self, image, Hp, Wp, mean_bgr):
+        """The detector's input transform fused with the im2col of its 7x7/s2 stem (vidc_det_stem_im2col): image NCHW in [0,1] ->
+        NHWC (B, Hp/2, Wp/2, 160)."""
+        assert image.nchw and image.C == 3
+        y = self.nhwc(Hp // 2, Wp // 2, 160)
+        self._emit("det_im2col", [image], [y], x=image, y=y, geom=(image.H, image.W, Hp, Wp), mean=tuple(float(v) for v in mean_bgr))
+        return y
+
+    def nearest2x(self, x):
+        y = self.nhwc(2 * x.H, 2 * x.W, x.C, x.G)
+        self._emit("nearest2x", [x], [y], x=x, y=y)
         return y
 
     def maxpool(self, x):
@@ -624,6 +638,21 @@ class Program:
                 g.p[0], g.p[1] = addr(x), addr(y)
                 g.i[0], g.i[1], g.i[2] = x.B, x.C, x.H * x.W
                 self.op_names.append("normalize")
+            elif kind == "det_im2col":
+                x, y = kw["x"], kw["y"]
+                op.kind = L.OP_DET_IM2COL
+                g.p[0], g.p[1] = addr(x), addr(y)
+                for j, v in enumerate((x.B,) + tuple(kw["geom"])):
+                    g.i[j] = v
+                g.f[0], g.f[1], g.f[2] = kw["mean"]
+                self.op_names.append("det_im2col")
+            elif kind == "nearest2x":
+                x, y = kw["x"], kw["y"]
+                op.kind = L.OP_NEAREST2X
+                g.p[0], g.p[1] = addr(x), addr(y)
+                for j, v in enumerate((x.B, x.H, x.W, x.C * x.G, x.ld, y.ld)):
+                    g.i[j] = v
+                self.op_names.append("nearest2x")
             elif kind == "copy":
                 src, dst = kw["src"], kw["dst"]
                 nbytes = min(self.buf_elems[src.buf], self.buf_elems[dst.buf]) * 4
