@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--source", default="", help="WxH of a raw camera stream (e.g. 640x480, 1280x720: BASELINE configs[2], [3]); every step "
                                                   "then starts from uint8 frames resident in HBM and includes the device-side pre-processing "
                                                   "(PIL-exact resize + ToTensor, sparse-point rasterisation) of SURVEY 8f-2")
+    ap.add_argument("--plane-head", action="store_true",
+                    help="BASELINE configs[2] 'full pipeline incl. plane_mask_detection head': the plane-instance maps come from the "
+                         "R-101-FPN Mask R-CNN detector (plane_mask.PlaneMaskDetector, seeded weights) every frame instead of a fixed map")
     ap.add_argument("--mode", choices=("interleaved", "streams", "sequential"), default="interleaved",
                     help="interleaved: software pipeline over frames (pipeline.run_interleaved: tick t = surface-normal net of frame t "
                          "+ depth-completion net of frame t-1 as one 4-group program); streams: --in-flight frames on separate HIP "
@@ -53,7 +56,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_pipeline(H, W, dev):
+def build_pipeline(H, W, dev, plane_head=False):
     from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
     cc = (0.5 * 319.87654 * W / 320.0, 0.5 * 239.87603 * H / 240.0)
     pipe = DepthCompletionPipeline(enriched_samples=200, cc_img=cc, device=dev, rng=np.random.RandomState(1234))
@@ -61,7 +64,14 @@ def build_pipeline(H, W, dev):
     dc_sd = S.seeded_state_dict(pipe.cnn.state_dict(), 1234, device=dev)
     pipe.load_state_dicts(sn_sd, dc_sd)
     pipe.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(H, W))
-    return pipe, sn_sd, dc_sd, cc
+    det_sd = None
+    if plane_head:
+        from vi_depth_completion_amd.plane_mask import PlaneMaskDetector
+        det = PlaneMaskDetector(device=dev)
+        det_sd = S.seeded_detector_state_dict(det.state_dict(), 1234, device=dev)
+        det.load_state_dict(det_sd)
+        pipe.plane_masks_extraction = det
+    return pipe, sn_sd, dc_sd, cc, det_sd
 
 
 def _sig_flops(name):
@@ -117,7 +127,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
 
     H, W, B = args.height, args.width, args.batch
-    pipe, sn_sd, dc_sd, cc = build_pipeline(H, W, dev)
+    pipe, sn_sd, dc_sd, cc, det_sd = build_pipeline(H, W, dev, args.plane_head)
 
     # frame f of the job is a function of (seed, f) only: rank r takes frames r, r+world, ... (round-robin shards)
     pool = []
@@ -242,8 +252,14 @@ def main():
         intr = O.Intrinsics(202.0, 202.0, cc[0], cc[1])
         cpu_sn = {k: v.cpu() for k, v in sn_sd.items()}
         cpu_dc = {k: v.cpu() for k, v in dc_sd.items()}
-        masks = [S.plane_id_map(H, W)] * B
         hb = S.synthetic_batch(B, H, W, 1234, frame0=rank * B)
+        if args.plane_head:      # the oracle's own detector (CPU) on the same frames
+            from oracle import plane_mask_oracle as PM
+            cpu_det = {k: v.cpu() for k, v in det_sd.items()}
+            plane_masks = lambda batch: [PM.run_on_tensor(cpu_det, batch["image"][i]) for i in range(B)]
+        else:
+            plane_masks = lambda batch: [S.plane_id_map(H, W)] * B
+        masks = plane_masks(hb)
         ref = O.call_cnn(cpu_sn, cpu_dc, hb, masks, intr, 200, rng=np.random.RandomState(77))   # also the warm-up
         pipe.rng = np.random.RandomState(77)
         got = pipe._call_cnn(next(frames(1)) if pre is None else {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in hb.items()}).cpu()
@@ -251,7 +267,7 @@ def main():
         tc = time.perf_counter()
         for j in range(args.cpu_frames if world == 1 else 0):     # the CPU baseline is timed at N=1 only (the other ranks would idle in the gather)
             hbj = S.synthetic_batch(B, H, W, 1234, frame0=(j + 1) * B)
-            O.call_cnn(cpu_sn, cpu_dc, hbj, masks, intr, 200, rng=np.random.RandomState(j))
+            O.call_cnn(cpu_sn, cpu_dc, hbj, plane_masks(hbj), intr, 200, rng=np.random.RandomState(j))
         cpu_s = time.perf_counter() - tc
         cpu_baseline = None if world > 1 else {"value": round(args.cpu_frames * B / cpu_s, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
                         "kind": "port",
@@ -270,10 +286,11 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if os.environ.get("VIDC_PRECISION", "mixed") == "fp32" else "f32+bf16x3"), "data": "synthetic",
             "config": {"workload": (("BASELINE configs[1]: synthetic %dx%d RGB + 200-pt sparse depth, batch %d per GPU, plane mask "
-                                    "fixed; warp + surface-normal net + plane block/enrichment + depth-completion net" % (W, H, B)) if not args.source else
-                                   ("%s uint8 camera stream + 200 VI-SLAM tracks per frame, batch %d per GPU, plane mask fixed; device-side "
+                                    "%s; warp + surface-normal net + plane block/enrichment + depth-completion net" % (
+                                        W, H, B, "from the Mask R-CNN plane head every frame" if args.plane_head else "fixed")) if not args.source else
+                                   ("%s uint8 camera stream + 200 VI-SLAM tracks per frame, batch %d per GPU, plane mask %s; device-side "
                                     "pre-processing (PIL-exact resize to %dx%d, rasterisation) + warp + surface-normal net + plane "
-                                    "block/enrichment + depth-completion net" % (args.source, B, W, H))),
+                                    "block/enrichment + depth-completion net" % (args.source, B, "from the Mask R-CNN plane head every frame" if args.plane_head else "fixed", W, H))),
                        "height": H, "width": W, "batch_per_gpu": B, "weights": "seeded random-init (seed 1234)",
                        "mode": args.mode, "frames_in_flight": (2 if args.mode == "interleaved" else args.in_flight if args.mode == "streams" else 1),
                        "sharding": "frames round-robin over %d rank(s), no data-path collective" % world},

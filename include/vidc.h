@@ -282,6 +282,14 @@ size_t vidc_nms_scratch_bytes(int n);
 int vidc_nms(const float* boxes_xyxy, const int32_t* order, int n, float threshold, int inclusive, int32_t* keep, int32_t* n_keep,
              void* scratch, vidc_stream_t stream);
 
+/* The same NMS over n_segments independent box lists in one launch set (one list per image and pyramid level, say).  Segment s is
+ * boxes[seg_offsets[s] .. + seg_counts[s]) (device int32 arrays; counts <= max_n <= 4096), ALREADY in descending score order.
+ * keep[seg_offsets[s] + i] = index inside the segment of its i-th survivor (ascending = score order), n_keep[s] their count.
+ * max_keep > 0: only the first max_keep survivors of every segment are wanted (boxlist_nms's max_proposals): the walk stops there. */
+size_t vidc_nms_segmented_scratch_bytes(int n_segments, int max_n);
+int vidc_nms_segmented(const float* boxes_xyxy, const int32_t* seg_offsets, const int32_t* seg_counts, int n_segments, int max_n,
+                       float threshold, int inclusive, int max_keep, int32_t* keep, int32_t* n_keep, void* scratch, vidc_stream_t stream);
+
 /* ROIAlign forward (csrc/cuda/ROIAlign_cuda.cu:65-176, csrc/cpu/ROIAlign_cpu.cpp:17-218; Caffe2 semantics: no half-pixel shift,
  * ROIs smaller than 1x1 forced to 1x1, sampling_ratio <= 0 -> ceil(roi / pooled) samples per bin and axis).
  * x: NHWC [N][H][W][ldx] (C channels used); rois float [K][5] = (batch index, x1, y1, x2, y2); y: [K][pooled_h][pooled_w][C]. */

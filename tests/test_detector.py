@@ -93,3 +93,39 @@ def test_hip_roi_align_vs_oracle(cfg):
     got = detector.roi_align(torch.from_numpy(x).cuda(), torch.from_numpy(rois).cuda(), (PH, PW), scale, sr).cpu().numpy()
     assert got.shape == want.shape
     assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.gpu
+def test_segmented_nms_matches_oracle():
+    """vidc_nms_segmented: several score-ordered lists of different lengths in one launch set, each against the oracle's greedy NMS."""
+    import torch
+    from oracle import detector_oracle as DO
+    from vi_depth_completion_amd import _lib as L
+    rng = np.random.RandomState(11)
+    counts = [1000, 333, 64, 65, 1, 50]
+    offs = np.concatenate(([0], np.cumsum(counts)))[:-1] + np.arange(len(counts)) * 4      # gaps between the lists
+    total = int(offs[-1] + counts[-1])
+    boxes = np.zeros((total, 4), np.float32)
+    expect = []
+    for o, n in zip(offs, counts):
+        xy = rng.uniform(0, 300, (n, 2)).astype(np.float32)
+        wh = rng.uniform(4, 150, (n, 2)).astype(np.float32)
+        boxes[o:o + n] = np.concatenate([xy, xy + wh], 1)
+        expect.append(DO.nms(boxes[o:o + n], -np.arange(n, dtype=np.float32), 0.6))          # already in score order
+    bd = torch.from_numpy(boxes).cuda()
+    so, sn = torch.tensor(offs, dtype=torch.int32).cuda(), torch.tensor(counts, dtype=torch.int32).cuda()
+    keep = torch.full((total,), -1, dtype=torch.int32).cuda()
+    nk = torch.zeros(len(counts), dtype=torch.int32).cuda()
+    scratch = torch.empty(L.lib().vidc_nms_segmented_scratch_bytes(len(counts), 1000), dtype=torch.uint8).cuda()
+    L.check(L.lib().vidc_nms_segmented(L.ptr(bd), L.ptr(so), L.ptr(sn), len(counts), 1000, 0.6, 1, 0, L.ptr(keep), L.ptr(nk), L.ptr(scratch),
+                                       L.current_stream()), "nms_segmented")
+    keep_h, nk_h = keep.cpu().numpy(), nk.cpu().numpy()
+    for s, (o, n) in enumerate(zip(offs, counts)):
+        assert nk_h[s] == len(expect[s]) and np.array_equal(keep_h[o:o + nk_h[s]], expect[s])
+    # max_keep: the first 50 survivors of every list (boxlist_nms(max_proposals=50))
+    L.check(L.lib().vidc_nms_segmented(L.ptr(bd), L.ptr(so), L.ptr(sn), len(counts), 1000, 0.6, 1, 50, L.ptr(keep), L.ptr(nk), L.ptr(scratch),
+                                       L.current_stream()), "nms_segmented")
+    keep_h, nk_h = keep.cpu().numpy(), nk.cpu().numpy()
+    for s, (o, n) in enumerate(zip(offs, counts)):
+        m = min(50, len(expect[s]))
+        assert nk_h[s] == m and np.array_equal(keep_h[o:o + m], expect[s][:m])

@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--batches", default="1")
     ap.add_argument("--splitk", default="1,2,4,8,16")
     ap.add_argument("--sigs", default="", help="comma-separated substrings: re-measure only signatures containing one of them (keeps the rest of the table)")
+    ap.add_argument("--detector", action="store_true", help="measure the signatures of the plane-mask detector's three programs "
+                                                             "(networks/plane_mask_rcnn.py) instead of the depth-completion path's")
     ap.add_argument("--only-missing", action="store_true", help="keep the committed table and measure only signatures it lacks")
     ap.add_argument("--split-charge", type=float, default=0.25,
                     help="fraction of the standalone split-kernel time charged to a bf16x3 conv (most splits are fused into the\n"
@@ -119,7 +121,13 @@ def main():
             sn = SurfaceNormalPrediction(fc_img=np.array([202.0, 202.0]), cc_img=cc).to(dev).eval()
             dc = ModifiedFPN().to(dev).eval()
             from vi_depth_completion_amd.pipeline import build_frame_program
-            for prog in (sn.program(B, dev), dc.program(B, H, 320, dev), build_frame_program(sn, dc, B, H, 320, dev)):
+            if a.detector:
+                from vi_depth_completion_amd.networks.plane_mask_rcnn import GeneralizedRCNN
+                det = GeneralizedRCNN().to(dev).eval()
+                progs = det.programs(B, H, 320, dev)
+            else:
+                progs = (sn.program(B, dev), dc.program(B, H, 320, dev), build_frame_program(sn, dc, B, H, 320, dev))
+            for prog in progs:
                 for op, name in zip(prog.c_ops, prog.op_names):
                     if op.kind != L.OP_CONV:
                         continue
@@ -152,6 +160,8 @@ def main():
                         best[prec] = cands[0]
                     # a bf16x3 conv needs its input split first (shared between consumers at best; charged in full here)
                     rows = d.B * d.H * d.W
+                    if rows * d.Cin * d.groups > split_dst.numel():          # (the detector's mask head at batch 8: 80 M floats)
+                        split_dst = torch.empty(rows * d.Cin * d.groups, dtype=torch.float32, device=dev)
                     t_split = time_split(lib, d.x, split_dst.data_ptr(), rows, d.Cin * d.groups, d.ldx, st)
                     us32, t32, sk32 = best[0]
                     us16, t16, sk16 = best[1]

@@ -96,6 +96,8 @@ SIGNATURES = {
     "vidc_depth_to_mm_u32": (C.c_int, [_vp, _vp, C.c_longlong, _vp]),
     "vidc_nms_scratch_bytes": (C.c_size_t, [_i]),
     "vidc_nms": (C.c_int, [_vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "vidc_nms_segmented_scratch_bytes": (C.c_size_t, [_i, _i]),
+    "vidc_nms_segmented": (C.c_int, [_vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp]),
     "vidc_roi_align_forward": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "vidc_det_stem_im2col": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
     "vidc_upsample_nearest2x": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

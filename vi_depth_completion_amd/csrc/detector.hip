@@ -116,6 +116,68 @@ nms_compact_kernel(const uint8_t* __restrict__ keep_flag, int n, int32_t* __rest
     if (threadIdx.x == 0) *n_keep = base;
 }
 
+// ---- segmented NMS: S independent box lists (one per (image, pyramid level), say), each already in descending score order, in one
+//      launch set.  Segment s = boxes[off[s] .. off[s] + n[s]); keep[off[s] + i] = i-th survivor (index inside the segment, ascending =
+//      score order), n_keep[s] their count.  mask scratch: [S][max_n][cb_max] words. -----------------------------------------------------
+__global__ void __launch_bounds__(64)
+nms_seg_mask_kernel(const float4* __restrict__ boxes, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_n, float thresh, int ge,
+                    unsigned long long* __restrict__ mask, int max_n, int cb_max) {
+    const int s = blockIdx.z, n = seg_n[s], rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
+    const float4* bx = boxes + seg_off[s];
+    __shared__ float4 cbox[64];
+    const int cj = cb * 64 + threadIdx.x;
+    if (cj < n) cbox[threadIdx.x] = bx[cj];
+    __syncthreads();
+    const int ri = rb * 64 + threadIdx.x;
+    if (ri >= n) return;
+    const float4 me = bx[ri];
+    const int cols = min(64, n - cb * 64);
+    unsigned long long t = 0;
+    for (int j = (rb == cb ? threadIdx.x + 1 : 0); j < cols; ++j) {
+        const float v = box_iou(me, cbox[j]);
+        if (ge ? (v >= thresh) : (v > thresh)) t |= 1ull << j;
+    }
+    mask[((size_t)s * max_n + ri) * cb_max + cb] = t;
+}
+
+// one wave per segment (n <= 4096): the greedy walk of nms_reduce_kernel<1>, survivors written straight to keep[] in order
+__global__ void __launch_bounds__(64)
+nms_seg_reduce_kernel(const unsigned long long* __restrict__ mask, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_n,
+                      int max_n, int cb_max, int max_keep, int32_t* __restrict__ keep, int32_t* __restrict__ n_keep) {
+    const int s = blockIdx.x, n = seg_n[s], lane = threadIdx.x;
+    const int col_blocks = (n + 63) / 64;
+    const unsigned long long* m = mask + (size_t)s * max_n * cb_max;
+    int32_t* kp = keep + seg_off[s];
+    unsigned long long removed = 0;                       // lane l: the removed word of column tile l
+    int count = 0;
+    for (int blk = 0; blk < col_blocks && count < max_keep; ++blk) {     // later boxes never change earlier decisions: stop when full
+        const int rows = min(64, n - blk * 64);
+        unsigned long long rem = __shfl(removed, blk, 64);
+        const unsigned long long diag = lane < rows ? m[(size_t)(blk * 64 + lane) * cb_max + blk] : 0ull;
+        unsigned long long kept = 0;
+        for (int r = 0; r < rows; ++r) {
+            const unsigned long long row = __shfl(diag, r, 64);
+            if (!((rem >> r) & 1ull)) { kept |= 1ull << r; rem |= row; }
+        }
+        if (count + __popcll(kept) > max_keep) {          // keep only the first max_keep - count survivors of this tile
+            int room = max_keep - count;
+            unsigned long long t = kept, first = 0;
+            while (room-- > 0) { const unsigned long long low = t & (~t + 1ull); first |= low; t ^= low; }
+            kept = first;
+        }
+        if (lane < rows && ((kept >> lane) & 1ull)) kp[count + __popcll(kept & ((1ull << lane) - 1ull))] = blk * 64 + lane;
+        count += __popcll(kept);
+        if (lane > blk && lane < col_blocks) {
+            const unsigned long long* mcol = m + (size_t)(blk * 64) * cb_max + lane;
+            unsigned long long acc = 0;
+            for (int r = 0; r < rows; ++r) acc |= ((kept >> r) & 1ull) ? mcol[(size_t)r * cb_max] : 0ull;
+            removed |= acc;
+        }
+    }
+    if (lane == 0) n_keep[s] = count;
+}
+
 // ---- ROIAlign forward, NHWC --------------------------------------------------------------------------------------------
 // grid (pooled_w * pooled_h, K); block = 64 * CW threads: lanes along channels
 __global__ void __launch_bounds__(256)
@@ -187,6 +249,27 @@ extern "C" int vidc_nms(const float* boxes_xyxy, const int32_t* order, int n, fl
     VIDC_CHECK_LAUNCH("nms_reduce_kernel");
     hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(256), 0, st, flag, n, keep, n_keep);
     VIDC_CHECK_LAUNCH("nms_compact_kernel");
+    return VIDC_OK;
+}
+
+extern "C" size_t vidc_nms_segmented_scratch_bytes(int n_segments, int max_n) {
+    return (size_t)n_segments * max_n * ((max_n + 63) / 64) * sizeof(unsigned long long) + 64;
+}
+
+extern "C" int vidc_nms_segmented(const float* boxes_xyxy, const int32_t* seg_offsets, const int32_t* seg_counts, int n_segments, int max_n,
+                                  float threshold, int inclusive, int max_keep, int32_t* keep, int32_t* n_keep, void* scratch,
+                                  vidc_stream_t stream) {
+    VIDC_REQUIRE(boxes_xyxy && seg_offsets && seg_counts && keep && n_keep && scratch, VIDC_ERR_NULL, "vidc_nms_segmented: null pointer");
+    VIDC_REQUIRE(n_segments > 0 && max_n > 0 && max_n <= 4096, VIDC_ERR_SHAPE, "vidc_nms_segmented: max_n = %d out of range (1..4096)", max_n);
+    VIDC_REQUIRE(((size_t)boxes_xyxy & 15) == 0, VIDC_ERR_SHAPE, "vidc_nms_segmented: boxes must be 16-byte aligned");
+    hipStream_t st = vidc::as_stream(stream);
+    const int cb = (max_n + 63) / 64;
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(scratch);
+    hipLaunchKernelGGL(nms_seg_mask_kernel, dim3(cb, cb, n_segments), dim3(64), 0, st, reinterpret_cast<const float4*>(boxes_xyxy), seg_offsets,
+                       seg_counts, threshold, inclusive, mask, max_n, cb);
+    VIDC_CHECK_LAUNCH("nms_seg_mask_kernel");
+    hipLaunchKernelGGL(nms_seg_reduce_kernel, dim3(n_segments), dim3(64), 0, st, mask, seg_offsets, seg_counts, max_n, cb, max_keep > 0 ? max_keep : max_n, keep, n_keep);
+    VIDC_CHECK_LAUNCH("nms_seg_reduce_kernel");
     return VIDC_OK;
 }
 

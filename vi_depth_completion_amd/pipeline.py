@@ -114,6 +114,28 @@ class DepthCompletionPipeline:
             state.update(sd)
             m.load_state_dict(state)
 
+    # ---- plane masks ---------------------------------------------------------------------------------------------------
+    def _masks_begin(self, rgb):
+        """Starts the plane-instance maps of a batch.  A device-side extractor (plane_mask.PlaneMaskDetector: `run_on_batch`) is
+        enqueued on the current stream together with ONE asynchronous device->host copy of the (B,H,W) uint8 ids; anything else is
+        the reference's per-sample `run_on_tensor` call (main.py:273), resolved in `_masks_end`."""
+        ex = self.plane_masks_extraction
+        if not hasattr(ex, "run_on_batch"):
+            return None
+        ids = ex.run_on_batch(rgb)
+        if getattr(self, "_ids_host", None) is None or self._ids_host.shape != ids.shape:
+            self._ids_host = torch.empty(ids.shape, dtype=torch.uint8, pin_memory=True)
+        self._ids_host.copy_(ids, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def _masks_end(self, handle, images, H, W):
+        if handle is None:
+            return [np.asarray(self.plane_masks_extraction.run_on_tensor(images[i])).reshape(H, W) for i in range(images.shape[0])]
+        handle.synchronize()
+        return [m.copy() for m in self._ids_host.numpy()]
+
     # ---- the hot path ------------------------------------------------------------------------------------------------
     def _stage1(self, input_batch, slot=0, planes=None, rng=None):
         """warp + surface-normal net + plane block, enqueued on the current stream (main.py:262-283)."""
@@ -121,6 +143,7 @@ class DepthCompletionPipeline:
         planes = planes or self.planes
         ds = input_batch["sparse_depth"].to(dev, non_blocking=True)
         rgb = input_batch["image"].to(dev, non_blocking=True)
+        mh = self._masks_begin(rgb) if self.args.enriched_samples != 0 else None      # the id maps travel to the host under the normal net
         if self.use_gravity:
             normals = self.surface_normal_cnn.enqueue(rgb, input_batch["gravity"].to(dev), input_batch["aligned_direction"].to(dev), slot)
         else:
@@ -129,8 +152,7 @@ class DepthCompletionPipeline:
         st = {"ds": ds, "rgb": rgb, "normals": normals, "di": None, "nnz": None, "rng": rng}
         if self.args.enriched_samples != 0:
             homo = input_batch["homogeneous_coordinates"].to(dev, non_blocking=True)
-            masks = [np.asarray(self.plane_masks_extraction.run_on_tensor(input_batch["image"][i])).reshape(ds.shape[-2], ds.shape[-1])
-                     for i in range(ds.shape[0])]
+            masks = self._masks_end(mh, input_batch["image"], ds.shape[-2], ds.shape[-1])
             st["di"], st["nnz"] = planes.plane_depth(normals, masks, ds, homo, rng=rng)
         return st
 
@@ -204,6 +226,7 @@ class DepthCompletionPipeline:
                 prog.tensor(prog.inputs["dc_normal"]).copy_(prog.tensor(prog.outputs["normals"]), non_blocking=True)
                 prog.tensor(prog.inputs["dc_depth"]).copy_(prev["depth_in"], non_blocking=True)
             if batch is not None:
+                mh = self._masks_begin(rgb) if self.args.enriched_samples != 0 else None    # ids reach the host while segment 0 runs
                 prog.tensor(prog.inputs["sn_image"]).copy_(rgb, non_blocking=True)
                 prog.storage[prog.inputs["gravity"].buf][: B * 3].copy_(batch["gravity"].to(dev).reshape(-1), non_blocking=True)
                 prog.storage[prog.inputs["aligned"].buf][: B * 3].copy_(batch["aligned_direction"].to(dev).reshape(-1), non_blocking=True)
@@ -216,7 +239,7 @@ class DepthCompletionPipeline:
                 pending = None
                 if self.args.enriched_samples != 0:
                     homo = batch["homogeneous_coordinates"].to(dev, non_blocking=True)
-                    masks = [np.asarray(self.plane_masks_extraction.run_on_tensor(batch["image"][i])).reshape(H, W) for i in range(B)]
+                    masks = self._masks_end(mh, batch["image"], H, W)
                     di, info = self.planes.plane_depth(normals, masks, ds, homo, rng=self.rng)
                     pending = (di, info, self.planes.read_info_async(info))
             elif prev is not None:

@@ -39,8 +39,15 @@ class _Buffers:
         self.scores = torch.zeros(B, slots, **f32)
         self.keep = torch.zeros(B, slots, **i32)
         self.n_keep = torch.zeros(B, len(self.level_hw), **i32)
-        self.iota = torch.arange(max(self.level_k + [R]), **i32)
-        self.nms_scratch = torch.empty(L.lib().vidc_nms_scratch_bytes(max(self.level_k + [R])), dtype=torch.uint8, device=device)
+        nl = len(self.level_hw)
+        self.anchors = [N.cell_anchors(s, z).numpy().astype(np.float32).copy() for s, z in zip(N.ANCHOR_STRIDES, N.ANCHOR_SIZES)]
+        # NMS segments: one per (image, level) for the RPN, one per image for the detections (vidc_nms_segmented)
+        self.rpn_seg_off = torch.tensor([b * slots + int(self.level_off[l]) for b in range(B) for l in range(nl)], **i32)
+        self.rpn_seg_n = torch.tensor([self.level_k[l] for b in range(B) for l in range(nl)], **i32)
+        self.det_seg_off = torch.arange(B, **i32) * R
+        self.det_seg_n = torch.full((B,), R, **i32)
+        self.nms_scratch = torch.empty(max(L.lib().vidc_nms_segmented_scratch_bytes(B * nl, max(self.level_k)),
+                                           L.lib().vidc_nms_segmented_scratch_bytes(B, R)), dtype=torch.uint8, device=device)
         self.props = torch.zeros(B, R, 4, **f32)
         self.prop_scores = torch.zeros(B, R, **f32)
         self.n_props = torch.zeros(B, **i32)
@@ -102,14 +109,12 @@ class PlaneMaskDetector:
         for l, m in enumerate(rpn_maps):
             h, w = bf.level_hw[l]
             assert tuple(m.shape) == (B, h, w, 32) and m.is_contiguous()
-            anc = N.cell_anchors(N.ANCHOR_STRIDES[l], N.ANCHOR_SIZES[l]).numpy().astype(np.float32).copy()
+            anc = bf.anchors[l]
             off = int(bf.level_off[l])
             L.check(lib.vidc_rpn_topk_decode(L.ptr(m), B, h, w, 32, 3, N.ANCHOR_STRIDES[l], anc.ctypes.data, PRE_NMS_TOP_N, H, W,
                                              bf.boxes.data_ptr() + off * 16, bf.scores.data_ptr() + off * 4, bf.slots, st), "rpn_topk_decode")
-            for b in range(B):
-                L.check(lib.vidc_nms(bf.boxes.data_ptr() + (b * bf.slots + off) * 16, L.ptr(bf.iota), bf.level_k[l], RPN_NMS_THRESH,
-                                     int(self.nms_inclusive), bf.keep.data_ptr() + (b * bf.slots + off) * 4,
-                                     bf.n_keep.data_ptr() + (b * nl + l) * 4, L.ptr(bf.nms_scratch), st), "nms")
+        L.check(lib.vidc_nms_segmented(L.ptr(bf.boxes), L.ptr(bf.rpn_seg_off), L.ptr(bf.rpn_seg_n), B * nl, max(bf.level_k), RPN_NMS_THRESH,
+                                       int(self.nms_inclusive), POST_NMS_TOP_N, L.ptr(bf.keep), L.ptr(bf.n_keep), L.ptr(bf.nms_scratch), st), "nms_segmented")
         L.check(lib.vidc_rpn_select(L.ptr(bf.boxes), L.ptr(bf.scores), L.ptr(bf.keep), L.ptr(bf.n_keep), B, nl, bf.level_off.ctypes.data,
                                     POST_NMS_TOP_N, N.ROI_SLOTS, L.ptr(bf.props), L.ptr(bf.prop_scores), L.ptr(bf.n_props), st), "rpn_select")
         return bf.props, bf.prop_scores, bf.n_props
@@ -134,9 +139,8 @@ class PlaneMaskDetector:
         lib, st, R = L.lib(), L.current_stream(), N.ROI_SLOTS
         L.check(lib.vidc_det_candidates(L.ptr(head), 32, L.ptr(props), L.ptr(n_props), B, R, H, W, SCORE_THRESH, L.ptr(bf.cand_boxes),
                                         L.ptr(bf.cand_scores), L.ptr(bf.cand_src), L.ptr(bf.n_cand), st), "det_candidates")
-        for b in range(B):
-            L.check(lib.vidc_nms(bf.cand_boxes.data_ptr() + b * R * 16, L.ptr(bf.iota), R, DET_NMS_THRESH, int(self.nms_inclusive),
-                                 bf.det_keep.data_ptr() + b * R * 4, bf.n_det_keep.data_ptr() + b * 4, L.ptr(bf.nms_scratch), st), "nms")
+        L.check(lib.vidc_nms_segmented(L.ptr(bf.cand_boxes), L.ptr(bf.det_seg_off), L.ptr(bf.det_seg_n), B, R, DET_NMS_THRESH,
+                                       int(self.nms_inclusive), 0, L.ptr(bf.det_keep), L.ptr(bf.n_det_keep), L.ptr(bf.nms_scratch), st), "nms_segmented")
         L.check(lib.vidc_det_select(L.ptr(bf.cand_boxes), L.ptr(bf.cand_scores), L.ptr(bf.cand_src), L.ptr(bf.n_cand), L.ptr(bf.det_keep),
                                     L.ptr(bf.n_det_keep), B, R, L.ptr(bf.det_boxes), L.ptr(bf.det_scores), L.ptr(bf.n_det), st), "det_select")
         return bf.det_boxes, bf.det_scores, bf.n_det
