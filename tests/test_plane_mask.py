@@ -210,3 +210,40 @@ def test_run_on_tensor_end_to_end(detector, oracle_runs, name):
     agree = float((got == inst).mean())
     print("instance map agreement %s: %.4f, planes %d vs %d" % (name, agree, got.max(), inst.max()))
     assert agree >= 0.97
+
+
+@pytest.mark.gpu
+def test_pipeline_with_plane_head(detector, detector_weights, seeded_weights, golden_dir):
+    """RunDepthCompletion._call_cnn with the plane-mask predictor in the loop (main.py:254, 273) on a real demo frame: the pipeline's
+    device-side extraction path (`run_on_batch` on a side stream + one device->host copy of the ids) returns the ids of `run_on_tensor`,
+    and the whole path follows the oracle fed with the ORACLE's ids.  When the two id maps are identical the RANSAC / enrichment draws
+    coincide and the depth maps must agree to the north-star bar (RMSE < 1e-3); otherwise (a detection flipped, see
+    test_run_on_tensor_end_to_end) the draws differ and only the id agreement is asserted."""
+    from oracle import vidc_oracle as O
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline
+    g = np.load(os.path.join(golden_dir, "plane_mask_demo.npz"))
+    f = np.load(os.path.join(golden_dir, "demo_000000.npz"))
+    img = torch.from_numpy(g["image"])
+    sd = torch.zeros(240, 320)
+    rc = torch.from_numpy(f["sparse_rc"]).long()
+    sd[rc[:, 0], rc[:, 1]] = torch.from_numpy(f["sparse_val"])
+    batch = {"image": img[None], "sparse_depth": sd[None, None], "gravity": torch.from_numpy(f["gravity"])[None],
+             "aligned_direction": torch.from_numpy(f["aligned"])[None],
+             "homogeneous_coordinates": S.homogeneous_grid(S.DEMO_FC, S.DEMO_CC, 320, 240)[None]}
+    pipe = DepthCompletionPipeline(enriched_samples=200, rng=np.random.RandomState(5))
+    pipe.load_state_dicts(seeded_weights["sn"], seeded_weights["dc"])
+    pipe.plane_masks_extraction = detector
+    h = pipe._masks_begin(img[None].cuda())
+    ids_dev = pipe._masks_end(h, batch["image"], 240, 320)[0]
+    ids_ref = detector.run_on_tensor(img)
+    assert np.array_equal(ids_dev, ids_ref)
+    got = pipe._call_cnn(batch).cpu()
+    ids_or = PM.run_on_tensor(detector_weights, img)
+    agree = float((ids_ref == ids_or).mean())
+    assert agree >= 0.97 and torch.isfinite(got).all()
+    intr = O.Intrinsics(202.0, 202.0, 0.5 * 319.87654, 0.5 * 239.87603)
+    ref = O.call_cnn(seeded_weights["sn"], seeded_weights["dc"], batch, [ids_or], intr, 200, rng=np.random.RandomState(5))
+    rmse = float((got - ref).pow(2).mean().sqrt())
+    print("plane-head pipeline: id agreement %.4f, depth RMSE vs oracle %.3e" % (agree, rmse))
+    if agree == 1.0:
+        assert rmse < 1e-3

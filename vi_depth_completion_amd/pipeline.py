@@ -122,6 +122,7 @@ class DepthCompletionPipeline:
         ex = self.plane_masks_extraction
         if not hasattr(ex, "run_on_batch"):
             return None
+        # (on the current stream: running the detector on a side stream next to the networks measured 224 vs 235 frames/s)
         ids = ex.run_on_batch(rgb)
         if getattr(self, "_ids_host", None) is None or self._ids_host.shape != ids.shape:
             self._ids_host = torch.empty(ids.shape, dtype=torch.uint8, pin_memory=True)
