@@ -34,6 +34,9 @@ def main():
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / a.iters
         dense, box, mask = det.model.programs(B, a.height, 320, det.device)
+        for p in (dense, box, mask):          # run_on_batch replays ONE graph of the whole detector; the per-program graphs are for this table
+            type(det.model)._execute(p)
+        torch.cuda.synchronize()
         parts = {n: p.time(iters=20, use_graph=True) for n, p in (("dense", dense), ("box", box), ("mask", mask))}
         gf = {n: p.flops / 1e9 for n, p in (("dense", dense), ("box", box), ("mask", mask))}
         print("batch %d: run_on_batch %.3f ms = %.1f images/s; programs (graph replay) dense %.3f ms (%.1f GFLOP) box %.3f ms (%.1f) mask %.3f ms "

@@ -11,6 +11,7 @@ detector kernels of csrc/plane_mask.hip / csrc/detector.hip, static shapes, no h
 (csrc/cuda/nms.cu:57).  Default = the CPU rule, which is what the oracle (the reference imported on CPU) uses.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -72,8 +73,11 @@ class PlaneMaskDetector:
         self.confidence_threshold = float(confidence_threshold)
         self.nms_inclusive = bool(nms_inclusive)
         self._bufs = {}
+        self._graphs = {}          # (B, H, W, confidence, inclusive, parameter version) -> hipGraph of the whole detector
+        self._eager = False        # inside the capture the programs issue their kernels instead of replaying their own graphs
 
     def load_state_dict(self, state):
+        self._graphs.clear()
         self.model.load_state_dict(state)
 
     def state_dict(self):
@@ -87,9 +91,11 @@ class PlaneMaskDetector:
             self._bufs[key] = _Buffers(B, H, W, Hp, Wp, self.device)
         return self._bufs[key], self.model.programs(B, H, W, self.device)
 
-    @staticmethod
-    def _run(prog):
-        N._HipModule._execute(prog)
+    def _run(self, prog):
+        if self._eager:
+            prog.run()
+        else:
+            N._HipModule._execute(prog)
 
     def dense(self, images):
         """images (B,3,H,W) RGB in [0,1] on the GPU -> runs the dense program; returns its Program (outputs P2..P5, rpn0..rpn4)."""
@@ -97,7 +103,8 @@ class PlaneMaskDetector:
             raise RuntimeError("PlaneMaskDetector runs on the GPU only (no CPU fallback)")
         B, _, H, W = images.shape
         _bufs, (dense, _box, _mask) = self._ctx(B, H, W)
-        dense.tensor(dense.inputs["image"]).copy_(images, non_blocking=True)
+        if images.data_ptr() != dense.tensor(dense.inputs["image"]).data_ptr():
+            dense.tensor(dense.inputs["image"]).copy_(images, non_blocking=True)
         self._run(dense)
         return dense
 
@@ -165,7 +172,34 @@ class PlaneMaskDetector:
 
     # ---- the reference's entry points ---------------------------------------------------------------------------------------
     def run_on_batch(self, images):
-        """(B,3,H,W) in [0,1] on the GPU -> (B,H,W) uint8 instance ids on the GPU (a view of a reused buffer)."""
+        """(B,3,H,W) in [0,1] on the GPU -> (B,H,W) uint8 instance ids on the GPU (a view of a reused buffer).  Everything after the
+        copy of the input -- three programs and sixteen detector launches, all with static shapes and no host synchronisation -- is
+        replayed as ONE hipGraph (VIDC_EXEC=graph, the default), captured on first use."""
+        if not images.is_cuda:
+            raise RuntimeError("PlaneMaskDetector runs on the GPU only (no CPU fallback)")
+        if os.environ.get("VIDC_EXEC", "graph") != "graph":
+            return self._run_stages(images)
+        B, _, H, W = images.shape
+        bf, (dense, _b, _m) = self._ctx(B, H, W)
+        key = (B, H, W, self.confidence_threshold, self.nms_inclusive, self.model._version)
+        graph = self._graphs.get(key)
+        inp = dense.tensor(dense.inputs["image"])
+        if graph is None:
+            self._eager = True
+            try:
+                self._run_stages(images)                       # warm-up outside capture: kernel attributes, every buffer allocated
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._run_stages(inp)
+            finally:
+                self._eager = False
+            self._graphs[key] = graph
+        inp.copy_(images, non_blocking=True)
+        graph.replay()
+        return bf.inst
+
+    def _run_stages(self, images):
         B, _, H, W = images.shape
         dense = self.dense(images)
         feats = [dense.tensor(dense.outputs["P%d" % l]) for l in (2, 3, 4, 5)]
