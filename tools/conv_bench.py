@@ -35,6 +35,8 @@ KEY_SHAPES = [
     ((16, 20), 256, 256, 3, 1, 4, 22),     # joint 4-pyramid launch (pipeline.run_stream software pipelining)
     ((16, 20), 256, 1024, 1, 1, 4, 23),
     ((16, 20), 1024, 256, 1, 1, 4, 22),
+    ((512, 80), 768, 768, 3, 1, 1, 1),     # [20] the 54 GF decoder layer at batch 8 (M = 40 960)
+    ((128, 80), 768, 768, 3, 1, 1, 6),     # [21] the batch-8 M = 9600-class decoder layers (M = 10 240)
 ]
 
 

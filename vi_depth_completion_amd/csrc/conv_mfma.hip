@@ -107,8 +107,11 @@ __device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
 // Workgroup = WMW x WNW x WKW waves.  The (WMW x WNW) waves of one k-slice tile the BM x BN output; the WKW k-slices
 // split every pipeline stage's K range (32 floats each) and are summed through LDS at the end (deterministic order).
 // NS-deep LDS ring filled by global_load_lds (16 B per lane, 1 KiB = 8 rows x 128 B per wave-instruction); the 16-byte
-// chunks of a row are XOR-swizzled by (row & 7) through the per-lane SOURCE address so ds_read_b128 fragments are at
-// worst 2-way bank conflicted while the DMA destination stays lane-linear.
+// chunks of a row are XOR-swizzled by ((row >> 1) & 7) through the per-lane SOURCE address, so the DMA destination stays lane-linear
+// and ds_read_b128 fragments are bank-conflict free: the LDS is 256 B = two 128-byte rows wide, a ds_read_b128 is served in four
+// 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32), and within every group the eight even rows have eight different
+// (row >> 1) & 7 and so do the eight odd ones -> 16 different 16-byte slots.  (The first version keyed on row & 7: rows r and r + 8 of
+// a group then shared a slot, every fragment read was 2-way conflicted and the LDS delivered 128 instead of 256 B/clk.)
 // PREC 0: fp32 operands, v_mfma_f32_32x32x2_f32.  PREC 1 ("bf16x3"): both operands arrive pre-split as bf16 hi + lo
 // (each 32-channel K unit is stored as [32 x hi | 32 x lo] = the same 128 bytes per row as fp32, so addressing, DMA and
 // swizzle are identical) and every K unit is 3 x 2 v_mfma_f32_32x32x16_bf16: lo*hi + hi*lo + hi*hi, fp32 accumulate.
@@ -189,14 +192,16 @@ conv_igemm_f32(const ConvArgs a) {
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.x + g * a.x_gs), 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.w + g * a.w_gs), 0, w_bytes, 0x00020000);
     const int lrow = lane >> 3;
-    const int csw = ((lane & 7) ^ lrow) * 4;            // swizzled 16-byte chunk this lane fetches (row & 7 == lane >> 3)
+    // swizzled 16-byte chunk (in floats) this lane fetches for the j-th DMA of a stage: tile row = ... + (j * WPK + wq) * 8 + lrow, all
+    // other terms multiples of 32, so (row >> 1) & 7 = ((j * WPK + wq) & 1) * 4 + (lrow >> 1)
+    auto csw_of = [&](int j) { return ((lane & 7) ^ ((((j * WPK + wq) & 1) << 2) | (lrow >> 1))) * 4; };
     // ---- weights first: their DMAs need only (n, K unit) and they are the HBM-cold operand, so the prologue stages of B are in
     //      flight while the activation rows are decoded below ----------------------------------------------------------------
     unsigned b_off[B_J];
 #pragma unroll
     for (int j = 0; j < B_J; ++j) {
         const int n = n0 + (j * WPK + wq) * 8 + lrow;
-        b_off[j] = n < a.Cout ? (unsigned)((n * a.K + csw) * 4) : OOB;
+        b_off[j] = n < a.Cout ? (unsigned)((n * a.K + csw_of(j)) * 4) : OOB;
     }
     // K order: unit u = cu * (KH*KW) + tap -- channel unit major, tap minor -- so the KH*KW taps of one 32-channel unit run
     // back to back and the shifted re-reads of the same pixels hit L2 (tap-major order re-read every pixel KH*KW times with
@@ -239,7 +244,7 @@ conv_igemm_f32(const ConvArgs a) {
         const int mm = ok ? m : 0;
         if (pointwise) {
             a_taps[j] = ok ? 1u : 0u;
-            a_off[j] = (mm * a.ldx + csw) * 4;
+            a_off[j] = (mm * a.ldx + csw_of(j)) * 4;
             continue;
         }
         int b = (int)((float)mm * inv_howo);             // float reciprocal + fix-up: exact for M < 2^23
@@ -255,7 +260,7 @@ conv_igemm_f32(const ConvArgs a) {
 #pragma unroll
         for (int th = 0; th < 3; ++th) taps |= (th < a.KH && (unsigned)(iy0 + th * a.dil) < (unsigned)a.H) ? colm << (th * a.KW) : 0u;
         a_taps[j] = ok ? taps : 0u;
-        a_off[j] = (((b * a.H + iy0) * a.W + ix0) * a.ldx + csw) * 4;
+        a_off[j] = (((b * a.H + iy0) * a.W + ix0) * a.ldx + csw_of(j)) * 4;
     }
     VIDC_STAMP(10);     // activation rows decoded
     // One pipeline stage = A_J + B_J DMA instructions per wave, issued in two halves that the main loop places inside
@@ -371,7 +376,7 @@ conv_igemm_f32(const ConvArgs a) {
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) float*)smem);
     const unsigned a_base = lds0 + 4u * (unsigned)((kq * BM + wm * 32 * TM + li) * BK);
     const unsigned b_base = lds0 + 4u * (unsigned)((WKW * BM + kq * BN + wn * 32 * TN + li) * BK);
-    const int sw = li & 7;
+    const int sw = (li >> 1) & 7;       // = (tile row >> 1) & 7: the fragment rows start at multiples of 32
     unsigned coff[BK / 8];
 #pragma unroll
     for (int sub = 0; sub < BK / 8; ++sub) coff[sub] = (unsigned)(((sub * 2 + lh) ^ sw) * 16);
@@ -709,6 +714,9 @@ constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {
     {64, 32, 2, 1, 2, 3},     // VIDC_TILE_64x32_K2
     {64, 32, 2, 1, 2, 5},     // VIDC_TILE_64x32_K2_D5
     {64, 32, 2, 1, 2, 5},     // VIDC_TILE_64x32_K2_D5_L
+    // ---- 64x64 wave tiles: 0.67 KB of LDS fragment reads per MFMA instead of 1 KB ----
+    {128, 128, 2, 2, 1, 3},   // VIDC_TILE_128x128_D3
+    {128, 128, 2, 2, 1, 3},   // VIDC_TILE_128x128_D3_L
 };
 constexpr int kFirstLoaderTile = VIDC_TILE_32x64_K2_L;
 
@@ -860,6 +868,8 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         case VIDC_TILE_64x32_K2:       rc = launch_tile<64, 32, 2, 1, 2, 3>(a, st, dd.precision); break;
         case VIDC_TILE_64x32_K2_D5:    rc = launch_tile<64, 32, 2, 1, 2, 5>(a, st, dd.precision); break;
         case VIDC_TILE_64x32_K2_D5_L:  rc = launch_tile<64, 32, 2, 1, 2, 5, 1>(a, st, dd.precision); break;
+        case VIDC_TILE_128x128_D3:     rc = launch_tile<128, 128, 2, 2, 1, 3>(a, st, dd.precision); break;
+        case VIDC_TILE_128x128_D3_L:   rc = launch_tile<128, 128, 2, 2, 1, 3, 1>(a, st, dd.precision); break;
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
     return rc;
