@@ -24,13 +24,18 @@ SHAPES = {  # name: (H, W, cin, cout, k, G, tile, precision)
     "l3_1x1_256to1024_G4": (16, 20, 256, 1024, 1, 4, 4, 1),
     "l3_1x1_256to1024_G1": (16, 20, 256, 1024, 1, 1, 6, 1),
     "f1_3x3_768": (64, 80, 768, 768, 3, 1, 3, 1),
+    "f1_3x3_768_128x128d3L": (64, 80, 768, 768, 3, 1, 25, 1),
+    "f1_3x3_768_128x128d3": (64, 80, 768, 768, 3, 1, 24, 1),
 }
 
 
 def main():
     dev = "cuda"
     lib = L.lib()
+    only = os.environ.get("VIDC_PHASE_ONLY", "")
     for name, (H, W, cin, cout, k, G, tile, prec) in SHAPES.items():
+        if only and only not in name:
+            continue
         x = S.normal01(1, "x", (1, H, W, G * cin)).float().to(dev)
         w = S.normal01(1, "w", (G, cout, k * k * cin), scale=0.05).float().to(dev)
         s1, b1 = torch.ones(G, cout, device=dev), torch.zeros(G, cout, device=dev)
