@@ -90,7 +90,8 @@ TILE_TEMPLATE = {"128x128": (128, 128, 2, 2, 1, 2), "128x64": (128, 64, 2, 2, 1,
                  "32x64k2L": (32, 64, 1, 2, 2, 3), "32x64k2d5L": (32, 64, 1, 2, 2, 5), "32x32k4d4L": (32, 32, 1, 1, 4, 4), "64x64L": (64, 64, 2, 2, 1, 4),
                  "64x64k2d4L": (64, 64, 2, 2, 2, 4), "64x128L": (64, 128, 2, 2, 1, 3), "128x64L": (128, 64, 2, 2, 1, 3),
                  "64x32k2": (64, 32, 2, 1, 2, 3), "64x32k2d5": (64, 32, 2, 1, 2, 5), "64x32k2d5L": (64, 32, 2, 1, 2, 5),
-                 "128x128d3": (128, 128, 2, 2, 1, 3), "128x128d3L": (128, 128, 2, 2, 1, 3)}
+                 "128x128d3": (128, 128, 2, 2, 1, 3), "128x128d3L": (128, 128, 2, 2, 1, 3), "256x128": (256, 128, 4, 2, 1, 3),
+                 "128x256": (128, 256, 2, 4, 1, 3)}
 
 
 def conv_stack_times(prog, iters=5):

@@ -125,7 +125,9 @@ enum vidc_conv_tile { VIDC_TILE_AUTO = 0, VIDC_TILE_128x128 = 1, VIDC_TILE_128x6
                       VIDC_TILE_64x32_K2 = 21, VIDC_TILE_64x32_K2_D5 = 22, VIDC_TILE_64x32_K2_D5_L = 23,
                       /* 64x64 wave tiles (fewer LDS bytes per MFMA), 3-deep ring, with and without loader waves */
                       VIDC_TILE_128x128_D3 = 24, VIDC_TILE_128x128_D3_L = 25,
-                      VIDC_TILE_COUNT = 26 };
+                      /* 8 waves of 64x64: 128 FLOP per ingested byte (the large layers are bound by the L2 -> LDS DMA rate) */
+                      VIDC_TILE_256x128 = 26, VIDC_TILE_128x256 = 27,
+                      VIDC_TILE_COUNT = 28 };
 
 /* Arithmetic of the contraction.  FP32: v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32, the reference mode).
  * BF16X3: every operand is split as x = hi + lo (bf16 each, round-to-nearest-even) and each product is computed as

@@ -24,8 +24,8 @@ OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD,
 TILE_AUTO = 0
 TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "64x64k2", 6: "32x64k2", 7: "32x32k4", 8: "32x128",
               9: "32x32k8", 10: "32x64k2d5", 11: "32x32k4d4", 12: "32x128d6", 13: "64x64k2d4", 14: "32x64k2L", 15: "32x64k2d5L", 16: "32x32k4d4L", 17: "64x64L", 18: "64x64k2d4L",
-              19: "64x128L", 20: "128x64L", 21: "64x32k2", 22: "64x32k2d5", 23: "64x32k2d5L", 24: "128x128d3", 25: "128x128d3L"}
-TILE_COUNT = 26
+              19: "64x128L", 20: "128x64L", 21: "64x32k2", 22: "64x32k2d5", 23: "64x32k2d5L", 24: "128x128d3", 25: "128x128d3L", 26: "256x128", 27: "128x256"}
+TILE_COUNT = 28
 PREC_FP32, PREC_BF16X3 = 0, 1
 SPLITK_COUNTERS = 16384            # VIDC_SPLITK_COUNTERS: ticket counters at the head of a split-K workspace
 

@@ -717,6 +717,8 @@ constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {
     // ---- 64x64 wave tiles: 0.67 KB of LDS fragment reads per MFMA instead of 1 KB ----
     {128, 128, 2, 2, 1, 3},   // VIDC_TILE_128x128_D3
     {128, 128, 2, 2, 1, 3},   // VIDC_TILE_128x128_D3_L
+    {256, 128, 4, 2, 1, 3},   // VIDC_TILE_256x128   (8 waves, 144 KB of LDS)
+    {128, 256, 2, 4, 1, 3},   // VIDC_TILE_128x256
 };
 constexpr int kFirstLoaderTile = VIDC_TILE_32x64_K2_L;
 
@@ -870,6 +872,8 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         case VIDC_TILE_64x32_K2_D5_L:  rc = launch_tile<64, 32, 2, 1, 2, 5, 1>(a, st, dd.precision); break;
         case VIDC_TILE_128x128_D3:     rc = launch_tile<128, 128, 2, 2, 1, 3>(a, st, dd.precision); break;
         case VIDC_TILE_128x128_D3_L:   rc = launch_tile<128, 128, 2, 2, 1, 3, 1>(a, st, dd.precision); break;
+        case VIDC_TILE_256x128:        rc = launch_tile<256, 128, 4, 2, 1, 3>(a, st, dd.precision); break;
+        case VIDC_TILE_128x256:        rc = launch_tile<128, 256, 2, 4, 1, 3>(a, st, dd.precision); break;
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
     return rc;
