@@ -141,7 +141,7 @@ CONV_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)
-@pytest.mark.parametrize("tile", list(range(24)))       # 14..20, 23: the loader-wave variants
+@pytest.mark.parametrize("tile", list(range(28)))       # 14..20, 23, 25: the loader-wave variants; 24..27: 64x64 wave tiles
 def test_conv_tiles(shape, tile):
     from vi_depth_completion_amd import ops
     B, H, W, cin, cout, k, stride, groups = shape
@@ -181,7 +181,7 @@ def _split_bf16(t):
 
 
 @pytest.mark.parametrize("shape", [CONV_SHAPES[1], CONV_SHAPES[2], CONV_SHAPES[4], CONV_SHAPES[5], CONV_SHAPES[7], CONV_SHAPES[8]])
-@pytest.mark.parametrize("tile", [0, 1, 4, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize("tile", [0, 1, 4, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27])
 def test_conv_bf16x3(shape, tile):
     """Split-bf16 3-pass mode vs an exact CPU emulation of the same arithmetic (hi*hi + hi*lo + lo*hi in fp32:
     bf16 x bf16 products are exact in fp32, so only the summation order differs) and vs true fp32 (2^-16 class)."""
@@ -247,7 +247,7 @@ def test_conv_is_deterministic():
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("tile", [4, 5, 13, 17, 18, 21, 23])
+@pytest.mark.parametrize("tile", [4, 5, 13, 17, 18, 21, 23, 25, 27])
 @pytest.mark.parametrize("prec", [0, 1])
 def test_conv_splitk_shared_workspace_repeatable(tile, prec):
     """The fused split-K reduction (last-arriving k-slice workgroup sums the partials in slice order) on ONE workspace reused by
