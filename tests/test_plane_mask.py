@@ -294,3 +294,50 @@ def test_degenerate_inputs_vs_oracle(detector, detector_weights):
         got = detector.run_on_tensor(img)
         ref = PM.run_on_tensor(detector_weights, img)
         assert got.shape == (240, 320) and float((got == ref).mean()) >= 0.90, float((got == ref).mean())
+
+
+@pytest.mark.gpu
+def test_instance_map_tied_components_and_overlap(detector):
+    """get_biggest_plane keeps EVERY component of the maximal size and overlay_mask sizes the plane by their sum (predictor.py:289-317);
+    later (smaller) planes overwrite earlier ones where they overlap.  Hand-made masks, checked against the oracle."""
+    masks = torch.zeros(1, 50, 240, 320, dtype=torch.uint8)
+    masks[0, 0, 10:80, 10:70] = 1            # two components of 4200 px each: together 8400
+    masks[0, 0, 150:220, 200:260] = 1
+    masks[0, 0, 100:110, 100:110] = 1        # and a small one that must be dropped
+    masks[0, 1, 60:130, 40:120] = 1          # 5600 px, overlaps the first component of slot 0
+    masks[0, 2, 0:50, 250:320] = 1           # 3500 px: below 5 % of 76 800
+    masks[0, 3, 200:240, 0:100] = 1          # 4000 px, but its score is below the threshold
+    scores = torch.zeros(1, 50)
+    scores[0, :4] = torch.tensor([0.95, 0.99, 0.97, 0.5])
+    n = torch.tensor([4], dtype=torch.int32)
+    expect = PM.instance_map(masks[0, :4], scores[0, :4], (240, 320), 0.9)
+    got = detector.instance_map(masks.cuda(), scores.cuda(), n.cuda(), 1, 240, 320)[0].cpu().numpy()
+    assert np.array_equal(got, expect)
+    assert got.max() == 2 and got[20, 20] == 1 and got[160, 210] == 1 and got[100, 100] == 2 and got[105, 105] == 2 and got[210, 50] == 0
+
+
+@pytest.mark.gpu
+def test_no_detection_passes_the_score_threshold(detector):
+    """Every proposal classified as background: no detection, no mask, all-background ids (the reference returns an empty BoxList)."""
+    head = torch.zeros(50, 32)
+    head[:, 0], head[:, 1] = 10.0, -10.0
+    props = torch.zeros(1, 50, 4)
+    props[0, :, 2:] = 40.0
+    db, ds, nd = detector.detections(head.cuda(), props.cuda(), torch.tensor([50], dtype=torch.int32).cuda(), 1, 240, 320)
+    assert int(nd[0]) == 0 and float(ds.abs().max()) == 0.0
+    pasted = detector.paste(torch.zeros(50, 14, 56, 32).cuda(), db, nd, 1, 240, 320)
+    assert int(pasted.sum()) == 0
+    assert int(detector.instance_map(pasted, ds, nd, 1, 240, 320).sum()) == 0
+
+
+@pytest.mark.gpu
+def test_other_image_size_end_to_end(detector, detector_weights):
+    """A 200x300 image (padded to 224x320: P5 is 7x10, P6 4x5 by the stride-2 subsampling): every buffer and level size follows the
+    image; ids vs the oracle >= 97 %."""
+    img = S.uniform01(77, "plane_mask.other", (3, 200, 300))
+    got = detector.run_on_tensor(img)
+    ref = PM.run_on_tensor(detector_weights, img)
+    assert got.shape == (200, 300)
+    agree = float((got == ref).mean())
+    print("200x300: agreement %.4f, planes %d vs %d" % (agree, got.max(), ref.max()))
+    assert agree >= 0.97

@@ -62,7 +62,7 @@ def main():
             bm = int(L.TILE_NAMES[t].split("x")[0])
             if bm >= 4 * max(32, M):
                 continue
-            for sk in (1, 2, 4, 8, 16):
+            for sk in (1, 2, 3, 4, 6, 8):
                 if sk > 1 and (K // 32) // sk < 2:
                     continue
                 if (t, sk) == (ent[0], ent[1]):

@@ -435,11 +435,11 @@ __device__ inline bool slot_live(const float* det_scores, const int32_t* n_det, 
     return k < n_det[b] && det_scores[(size_t)b * R + k] > confidence;
 }
 __global__ void __launch_bounds__(256)
-ccl_init_kernel(const uint8_t* __restrict__ m, int* __restrict__ lab, int* __restrict__ cnt, int* __restrict__ biggest, int HW,
+ccl_init_kernel(const uint8_t* __restrict__ m, int* __restrict__ lab, int* __restrict__ cnt, int* __restrict__ biggest, int* __restrict__ n_ties, int HW,
                 const float* __restrict__ det_scores, const int32_t* __restrict__ n_det, float confidence) {
     const int b = blockIdx.z, k = blockIdx.y, R = gridDim.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p == 0) biggest[b * R + k] = 0;
+    if (p == 0) { biggest[b * R + k] = 0; n_ties[b * R + k] = 0; }
     if (p >= HW || !slot_live(det_scores, n_det, b, k, R, confidence)) return;
     const size_t base = ((size_t)b * R + k) * HW;
     lab[base + p] = m[base + p] ? p : -1;
@@ -485,11 +485,24 @@ ccl_count_kernel(int* __restrict__ lab, int* __restrict__ cnt, int* __restrict__
         todo &= ~same;
     }
 }
+// number of components of the maximal size per slot (get_biggest_plane keeps ALL of them, predictor.py:317, and overlay_mask sizes
+// the plane by their sum): roots whose count equals the maximum
+__global__ void __launch_bounds__(256)
+ccl_ties_kernel(const int* __restrict__ lab, const int* __restrict__ cnt, const int* __restrict__ biggest, int* __restrict__ n_ties, int HW,
+                const float* __restrict__ det_scores, const int32_t* __restrict__ n_det, float confidence) {
+    const int b = blockIdx.z, k = blockIdx.y, R = gridDim.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW || !slot_live(det_scores, n_det, b, k, R, confidence)) return;
+    const size_t base = ((size_t)b * R + k) * HW;
+    if (lab[base + p] == p && cnt[base + p] == biggest[b * R + k]) atomicAdd(&n_ties[b * R + k], 1);
+}
+
 // One workgroup (64 threads) per image: confident detections by descending score (select_top_predictions), then the stable sort by
 // biggest-component size (sorted(..., reverse=True) keeps the score order among equal sizes), area filter; rank[k] = id of slot k or 0.
 __global__ void __launch_bounds__(64)
-plane_rank_kernel(const float* __restrict__ det_scores, const int32_t* __restrict__ n_det, const int* __restrict__ biggest, int R,
-                  float confidence, float min_size, int* __restrict__ order /*[B][R]: slot painted i-th, -1 = none*/) {
+plane_rank_kernel(const float* __restrict__ det_scores, const int32_t* __restrict__ n_det, const int* __restrict__ biggest,
+                  const int* __restrict__ n_ties, int R, float confidence, float min_size,
+                  int* __restrict__ order /*[B][R]: slot painted i-th, -1 = none*/) {
     __shared__ float key[64];
     __shared__ int idx[64];
     __shared__ int by_score[64];
@@ -501,7 +514,7 @@ plane_rank_kernel(const float* __restrict__ det_scores, const int32_t* __restric
     by_score[t] = key[t] > 0.f ? idx[t] : -1;
     __syncthreads();
     const int slot = by_score[t];
-    const int size = slot >= 0 ? biggest[b * R + slot] : -1;
+    const int size = slot >= 0 ? biggest[b * R + slot] * max(n_ties[b * R + slot], 1) : -1;
     key[t] = (slot >= 0 && (float)size >= min_size) ? (float)size : -1.f;       // sizes <= 76800 are exact in fp32
     idx[t] = t;                                                         // index = rank by score: ties keep the score order
     bitonic_sort_desc(key, idx, 64);
@@ -645,7 +658,7 @@ extern "C" int vidc_mask_paste(const float* mask_logits, int ld, int cls, int M,
 }
 
 extern "C" size_t vidc_instance_map_scratch_bytes(int B, int R, int H, int W) {
-    return ((size_t)B * R * H * W * 2 + (size_t)B * R * 2 + 64) * sizeof(int32_t);
+    return ((size_t)B * R * H * W * 2 + (size_t)B * R * 3 + 64) * sizeof(int32_t);
 }
 
 extern "C" int vidc_instance_map(const uint8_t* pasted, const float* det_scores, const int32_t* n_det, int B, int R, int H, int W, float confidence,
@@ -658,14 +671,18 @@ extern "C" int vidc_instance_map(const uint8_t* pasted, const float* det_scores,
     int* cnt = lab + (size_t)B * R * HW;
     int* biggest = cnt + (size_t)B * R * HW;
     int* order = biggest + (size_t)B * R;
+    int* n_ties = order + (size_t)B * R;
     const dim3 grid(vidc::cdiv(HW, 256), R, B);
-    hipLaunchKernelGGL(ccl_init_kernel, grid, dim3(256), 0, st, pasted, lab, cnt, biggest, HW, det_scores, n_det, confidence);
+    hipLaunchKernelGGL(ccl_init_kernel, grid, dim3(256), 0, st, pasted, lab, cnt, biggest, n_ties, HW, det_scores, n_det, confidence);
     VIDC_CHECK_LAUNCH("ccl_init_kernel");
     hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, st, pasted, lab, H, W, det_scores, n_det, confidence);
     VIDC_CHECK_LAUNCH("ccl_merge_kernel");
     hipLaunchKernelGGL(ccl_count_kernel, grid, dim3(256), 0, st, lab, cnt, biggest, HW, det_scores, n_det, confidence);
     VIDC_CHECK_LAUNCH("ccl_count_kernel");
-    hipLaunchKernelGGL(plane_rank_kernel, dim3(B), dim3(64), 0, st, det_scores, n_det, biggest, R, confidence, min_fraction * (float)HW, order);
+    hipLaunchKernelGGL(ccl_ties_kernel, grid, dim3(256), 0, st, lab, cnt, biggest, n_ties, HW, det_scores, n_det, confidence);
+    VIDC_CHECK_LAUNCH("ccl_ties_kernel");
+    hipLaunchKernelGGL(plane_rank_kernel, dim3(B), dim3(64), 0, st, det_scores, n_det, biggest, n_ties, R, confidence, min_fraction * (float)HW,
+                       order);
     VIDC_CHECK_LAUNCH("plane_rank_kernel");
     hipLaunchKernelGGL(plane_paint_kernel, dim3(vidc::cdiv(HW, 256), B), dim3(256), 0, st, lab, cnt, biggest, order, R, HW, inst);
     VIDC_CHECK_LAUNCH("plane_paint_kernel");

@@ -29,7 +29,8 @@ class _Buffers:
 
     def __init__(self, B, H, W, Hp, Wp, device):
         R = N.ROI_SLOTS
-        self.level_hw = [(Hp // s, Wp // s) for s in N.ANCHOR_STRIDES]
+        self.level_hw = [(Hp // s, Wp // s) for s in N.ANCHOR_STRIDES[:4]]          # P2..P5: Hp, Wp are multiples of 32
+        self.level_hw.append(((self.level_hw[3][0] - 1) // 2 + 1, (self.level_hw[3][1] - 1) // 2 + 1))     # P6 = max_pool2d(P5, 1, 2, 0)
         self.level_k = [min(PRE_NMS_TOP_N, 3 * h * w) for h, w in self.level_hw]
         self.level_off = np.concatenate(([0], np.cumsum(self.level_k))).astype(np.int32)
         slots = int(self.level_off[-1])
