@@ -317,6 +317,13 @@ int vidc_upsample_nearest2x(const float* x, float* y, int B, int h, int w, int C
  * boxes [B][out_stride][4] / scores [B][out_stride]: the first k entries of every image are written. */
 int vidc_rpn_topk_decode(const float* rpn_map, int B, int h, int w, int ld, int A, int stride, const float* cell_anchors_host,
                          int pre_nms_top_n, int img_h, int img_w, float* boxes, float* scores, long long out_stride, vidc_stream_t stream);
+/* The same for all pyramid levels in ONE launch (grid = images x levels): maps_host [n_levels] device pointers, hw_host [n_levels][2],
+ * strides_host [n_levels], cell_anchors_host [n_levels][A][4], level_offsets_host [n_levels] = first slot of the level inside a row of
+ * boxes / scores (all host arrays).  Level l writes its k_l = min(pre_nms_top_n, A*h_l*w_l) entries at level_offsets_host[l]. */
+int vidc_rpn_topk_decode_levels(const float* const* maps_host, const int32_t* hw_host, const int32_t* strides_host,
+                                const float* cell_anchors_host, const int32_t* level_offsets_host, int n_levels, int B, int ld, int A,
+                                int pre_nms_top_n, int img_h, int img_w, float* boxes, float* scores, long long out_stride,
+                                vidc_stream_t stream);
 /* The first per_level NMS survivors of every level (keep / n_keep as written by vidc_nms per level: keep [B][slots] at the level's
  * offset, indices relative to it; n_keep [B][n_levels]), then the `total` best over all levels (modeling/rpn/inference.py:103-108,
  * 148-190).  level_offsets_host [n_levels + 1] (host memory).  proposals [B][total][4] (zero-filled beyond n_proposals[b]). */

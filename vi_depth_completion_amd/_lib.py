@@ -102,6 +102,7 @@ SIGNATURES = {
     "vidc_det_stem_im2col": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
     "vidc_upsample_nearest2x": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_rpn_topk_decode": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, C.c_longlong, _vp]),
+    "vidc_rpn_topk_decode_levels": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, C.c_longlong, _vp]),
     "vidc_rpn_select": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "vidc_roi_align_fpn": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "vidc_det_candidates": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),

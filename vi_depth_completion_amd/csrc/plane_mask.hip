@@ -102,9 +102,9 @@ struct Anchors { float a[3][4]; };
 
 // One workgroup per image: sorts the A*h*w objectness values of one level (LDS, n2 = next power of two), decodes the top k.
 // map: [B][h][w][ld], channels 0..A-1 = objectness logits, A..5A-1 = box deltas in (anchor, coordinate) order.
-__global__ void __launch_bounds__(1024)
-rpn_topk_decode_kernel(const float* __restrict__ map, int h, int w, int ld, int A, int stride, Anchors cell, int n2, int k, float img_w,
-                       float img_h, float* __restrict__ boxes, float* __restrict__ scores, long long out_stride) {
+__device__ __forceinline__ void
+rpn_topk_decode_body(const float* __restrict__ map, int h, int w, int ld, int A, int stride, const Anchors& cell, int n2, int k, float img_w,
+                     float img_h, float* __restrict__ boxes, float* __restrict__ scores, long long out_stride) {
     extern __shared__ unsigned char lds[];
     float* key = reinterpret_cast<float*>(lds);
     int* idx = reinterpret_cast<int*>(lds) + n2;
@@ -133,9 +133,9 @@ rpn_topk_decode_kernel(const float* __restrict__ map, int h, int w, int ld, int 
 // The same result for n > 1024 >= k without sorting everything: a 3-level radix select (11 + 11 + 10 bits of the float pattern; sigmoid
 // outputs are positive, so the bit patterns order like the values) finds the k-th largest value T exactly, everything above T plus the
 // lowest-index `need` elements equal to T are compacted (<= 1024 items), and only those are sorted.  16 K keys: ~50 us instead of ~300.
-__global__ void __launch_bounds__(1024)
-rpn_topk_select_decode_kernel(const float* __restrict__ map, int h, int w, int ld, int A, int stride, Anchors cell, int k, float img_w,
-                              float img_h, float* __restrict__ boxes, float* __restrict__ scores, long long out_stride) {
+__device__ __forceinline__ void
+rpn_topk_select_decode_body(const float* __restrict__ map, int h, int w, int ld, int A, int stride, const Anchors& cell, int k, float img_w,
+                            float img_h, float* __restrict__ boxes, float* __restrict__ scores, long long out_stride) {
     extern __shared__ unsigned char lds[];
     const int b = blockIdx.x, n = A * h * w;
     unsigned* key = reinterpret_cast<unsigned*>(lds);                  // [n]
@@ -216,6 +216,29 @@ rpn_topk_select_decode_kernel(const float* __restrict__ map, int h, int w, int l
         ob[0] = o[0]; ob[1] = o[1]; ob[2] = o[2]; ob[3] = o[3];
         scores[(size_t)b * out_stride + r] = skey[r];
     }
+}
+
+__global__ void __launch_bounds__(1024)
+rpn_topk_decode_kernel(const float* __restrict__ map, int h, int w, int ld, int A, int stride, Anchors cell, int n2, int k, float img_w,
+                       float img_h, float* __restrict__ boxes, float* __restrict__ scores, long long out_stride) {
+    rpn_topk_decode_body(map, h, w, ld, A, stride, cell, n2, k, img_w, img_h, boxes, scores, out_stride);
+}
+__global__ void __launch_bounds__(1024)
+rpn_topk_select_decode_kernel(const float* __restrict__ map, int h, int w, int ld, int A, int stride, Anchors cell, int k, float img_w,
+                              float img_h, float* __restrict__ boxes, float* __restrict__ scores, long long out_stride) {
+    rpn_topk_select_decode_body(map, h, w, ld, A, stride, cell, k, img_w, img_h, boxes, scores, out_stride);
+}
+// All pyramid levels in one launch: grid (B, n_levels); every workgroup runs the path its level's size asks for.
+struct LevelDesc { const float* map; int h, w, stride, k, n2, off; Anchors cell; };
+struct LevelSet { LevelDesc lv[5]; };
+__global__ void __launch_bounds__(1024)
+rpn_topk_levels_kernel(LevelSet ls, int ld, int A, float img_w, float img_h, float* __restrict__ boxes, float* __restrict__ scores,
+                       long long out_stride) {
+    const LevelDesc& d = ls.lv[blockIdx.y];
+    float* bo = boxes + (size_t)d.off * 4;
+    float* so = scores + d.off;
+    if (A * d.h * d.w > 1024 && d.k <= 1024) rpn_topk_select_decode_body(d.map, d.h, d.w, ld, A, d.stride, d.cell, d.k, img_w, img_h, bo, so, out_stride);
+    else                                     rpn_topk_decode_body(d.map, d.h, d.w, ld, A, d.stride, d.cell, d.n2, d.k, img_w, img_h, bo, so, out_stride);
 }
 
 struct Levels { int n_levels; int off[8]; };      // off[l]..off[l+1]: slots of level l inside the per-image candidate arrays
@@ -588,6 +611,40 @@ extern "C" int vidc_rpn_topk_decode(const float* rpn_map, int B, int h, int w, i
     hipLaunchKernelGGL(rpn_topk_decode_kernel, dim3(B), dim3(1024), lds, vidc::as_stream(stream), rpn_map, h, w, ld, A, stride, cell, n2, k,
                        (float)img_w, (float)img_h, boxes, scores, out_stride);
     VIDC_CHECK_LAUNCH("rpn_topk_decode_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_rpn_topk_decode_levels(const float* const* maps_host, const int32_t* hw_host, const int32_t* strides_host,
+                                           const float* cell_anchors_host, const int32_t* level_offsets_host, int n_levels, int B, int ld, int A,
+                                           int pre_nms_top_n, int img_h, int img_w, float* boxes, float* scores, long long out_stride,
+                                           vidc_stream_t stream) {
+    VIDC_REQUIRE(maps_host && hw_host && strides_host && cell_anchors_host && level_offsets_host && boxes && scores, VIDC_ERR_NULL,
+                 "vidc_rpn_topk_decode_levels: null pointer");
+    VIDC_REQUIRE(B > 0 && A == 3 && n_levels >= 1 && n_levels <= 5 && ld >= 5 * A, VIDC_ERR_SHAPE, "vidc_rpn_topk_decode_levels: needs A == 3, <= 5 levels");
+    LevelSet ls;
+    size_t lds = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        LevelDesc& d = ls.lv[l];
+        d.map = maps_host[l]; d.h = hw_host[2 * l]; d.w = hw_host[2 * l + 1]; d.stride = strides_host[l]; d.off = level_offsets_host[l];
+        VIDC_REQUIRE(d.map, VIDC_ERR_NULL, "vidc_rpn_topk_decode_levels: null map");
+        const int n = A * d.h * d.w;
+        VIDC_REQUIRE(n > 0 && n <= 16384, VIDC_ERR_SHAPE, "vidc_rpn_topk_decode_levels: A*h*w = %d out of range (1..16384)", n);
+        d.k = pre_nms_top_n < n ? pre_nms_top_n : n;
+        d.n2 = 64;
+        while (d.n2 < n) d.n2 <<= 1;
+        for (int a = 0; a < 3; ++a) for (int c = 0; c < 4; ++c) d.cell.a[a][c] = cell_anchors_host[(l * 3 + a) * 4 + c];
+        const size_t need = (n > 1024 && d.k <= 1024) ? (size_t)(n + 2048 + 2048) * 4 : (size_t)d.n2 * 8;
+        lds = need > lds ? need : lds;
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        VIDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_topk_levels_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+        attr_done = true;
+    }
+    VIDC_REQUIRE(lds <= 16384 * 8, VIDC_ERR_SHAPE, "vidc_rpn_topk_decode_levels: LDS need %zu", lds);
+    hipLaunchKernelGGL(rpn_topk_levels_kernel, dim3(B, n_levels), dim3(1024), lds, vidc::as_stream(stream), ls, ld, A, (float)img_w, (float)img_h,
+                       boxes, scores, out_stride);
+    VIDC_CHECK_LAUNCH("rpn_topk_levels_kernel");
     return VIDC_OK;
 }
 

@@ -42,7 +42,9 @@ class _Buffers:
         self.keep = torch.zeros(B, slots, **i32)
         self.n_keep = torch.zeros(B, len(self.level_hw), **i32)
         nl = len(self.level_hw)
-        self.anchors = [N.cell_anchors(s, z).numpy().astype(np.float32).copy() for s, z in zip(N.ANCHOR_STRIDES, N.ANCHOR_SIZES)]
+        self.anchors_arr = np.stack([N.cell_anchors(s, z).numpy() for s, z in zip(N.ANCHOR_STRIDES, N.ANCHOR_SIZES)]).astype(np.float32).copy()
+        self.level_hw_arr = np.asarray(self.level_hw, dtype=np.int32).copy()
+        self.strides_arr = np.asarray(N.ANCHOR_STRIDES, dtype=np.int32).copy()
         # NMS segments: one per (image, level) for the RPN, one per image for the detections (vidc_nms_segmented)
         self.rpn_seg_off = torch.tensor([b * slots + int(self.level_off[l]) for b in range(B) for l in range(nl)], **i32)
         self.rpn_seg_n = torch.tensor([self.level_k[l] for b in range(B) for l in range(nl)], **i32)
@@ -115,12 +117,11 @@ class PlaneMaskDetector:
         lib, st = L.lib(), L.current_stream()
         nl = len(bf.level_hw)
         for l, m in enumerate(rpn_maps):
-            h, w = bf.level_hw[l]
-            assert tuple(m.shape) == (B, h, w, 32) and m.is_contiguous()
-            anc = bf.anchors[l]
-            off = int(bf.level_off[l])
-            L.check(lib.vidc_rpn_topk_decode(L.ptr(m), B, h, w, 32, 3, N.ANCHOR_STRIDES[l], anc.ctypes.data, PRE_NMS_TOP_N, H, W,
-                                             bf.boxes.data_ptr() + off * 16, bf.scores.data_ptr() + off * 4, bf.slots, st), "rpn_topk_decode")
+            assert tuple(m.shape) == (B,) + tuple(bf.level_hw[l]) + (32,) and m.is_contiguous()
+        maps = (C.c_void_p * nl)(*[m.data_ptr() for m in rpn_maps])
+        L.check(lib.vidc_rpn_topk_decode_levels(maps, bf.level_hw_arr.ctypes.data, bf.strides_arr.ctypes.data, bf.anchors_arr.ctypes.data,
+                                                bf.level_off.ctypes.data, nl, B, 32, 3, PRE_NMS_TOP_N, H, W, L.ptr(bf.boxes), L.ptr(bf.scores),
+                                                bf.slots, st), "rpn_topk_decode_levels")
         L.check(lib.vidc_nms_segmented(L.ptr(bf.boxes), L.ptr(bf.rpn_seg_off), L.ptr(bf.rpn_seg_n), B * nl, max(bf.level_k), RPN_NMS_THRESH,
                                        int(self.nms_inclusive), POST_NMS_TOP_N, L.ptr(bf.keep), L.ptr(bf.n_keep), L.ptr(bf.nms_scratch), st), "nms_segmented")
         L.check(lib.vidc_rpn_select(L.ptr(bf.boxes), L.ptr(bf.scores), L.ptr(bf.keep), L.ptr(bf.n_keep), B, nl, bf.level_off.ctypes.data,
