@@ -341,3 +341,34 @@ def test_other_image_size_end_to_end(detector, detector_weights):
     agree = float((got == ref).mean())
     print("200x300: agreement %.4f, planes %d vs %d" % (agree, got.max(), ref.max()))
     assert agree >= 0.97
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_connected_components_on_random_masks(detector, seed):
+    """The union-find labelling (run-start labels, one union per overlapping row segment) against scipy.ndimage.label on masks with many
+    irregular components: thresholded smooth noise at several densities, pure noise, a checkerboard (no 4-connected neighbours at all)
+    and a spiral (one long thin component)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    masks = torch.zeros(1, 50, 240, 320, dtype=torch.uint8)
+    for k in range(8):
+        noise = torch.rand(1, 1, 30, 40, generator=g)
+        smooth = F.interpolate(noise, size=(240, 320), mode="bicubic", align_corners=False)[0, 0]
+        masks[0, k] = (smooth > 0.35 + 0.04 * k).to(torch.uint8)
+    masks[0, 8] = (torch.rand(240, 320, generator=g) > 0.4).to(torch.uint8)
+    yy, xx = torch.meshgrid(torch.arange(240), torch.arange(320), indexing="ij")
+    masks[0, 9] = ((yy + xx) % 2 == 0).to(torch.uint8)
+    spiral = torch.zeros(240, 320, dtype=torch.uint8)
+    t, b_, l, r = 2, 237, 2, 317
+    while t < b_ and l < r:
+        spiral[t, l:r + 1] = 1; spiral[t:b_ + 1, r] = 1; spiral[b_, l + 4:r + 1] = 1; spiral[t + 4:b_ + 1, l + 4] = 1
+        spiral[t + 4, l + 4:r - 3] = 1
+        t, b_, l, r = t + 8, b_ - 8, l + 8, r - 8
+    masks[0, 10] = spiral
+    scores = torch.zeros(1, 50)
+    scores[0, :11] = torch.linspace(0.999, 0.95, 11)
+    n = torch.tensor([11], dtype=torch.int32)
+    expect = PM.instance_map(masks[0, :11], scores[0, :11], (240, 320), 0.9)
+    got = detector.instance_map(masks.cuda(), scores.cuda(), n.cuda(), 1, 240, 320)[0].cpu().numpy()
+    assert np.array_equal(got, expect), float((got == expect).mean())

@@ -459,13 +459,24 @@ __device__ inline bool slot_live(const float* det_scores, const int32_t* n_det, 
 }
 __global__ void __launch_bounds__(256)
 ccl_init_kernel(const uint8_t* __restrict__ m, int* __restrict__ lab, int* __restrict__ cnt, int* __restrict__ biggest, int* __restrict__ n_ties, int HW,
-                const float* __restrict__ det_scores, const int32_t* __restrict__ n_det, float confidence) {
+                int W, const float* __restrict__ det_scores, const int32_t* __restrict__ n_det, float confidence) {
     const int b = blockIdx.z, k = blockIdx.y, R = gridDim.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p == 0) { biggest[b * R + k] = 0; n_ties[b * R + k] = 0; }
-    if (p >= HW || !slot_live(det_scores, n_det, b, k, R, confidence)) return;
+    if (!slot_live(det_scores, n_det, b, k, R, confidence)) return;                 // uniform per workgroup
     const size_t base = ((size_t)b * R + k) * HW;
-    lab[base + p] = m[base + p] ? p : -1;
+    // Every pixel starts out pointing at the first pixel of its horizontal run inside this wave's 64 pixels (two ballots), so the
+    // merge pass only has to join runs across wave boundaries and rows -- not every pair of neighbours.
+    const int lane = threadIdx.x & 63;
+    const bool on = p < HW && m[base + p];
+    const unsigned long long bal = __ballot(on);
+    const bool prev = lane > 0 && ((bal >> (lane - 1)) & 1ull);
+    const bool start = on && (!prev || (p % W) == 0);
+    const unsigned long long sb = __ballot(start);
+    if (p >= HW) return;
+    int l = -1;
+    if (on) l = p - (lane - (63 - __clzll((long long)(sb & ((2ull << lane) - 1ull)))));
+    lab[base + p] = l;
     cnt[base + p] = 0;
 }
 __global__ void __launch_bounds__(256)
@@ -476,8 +487,10 @@ ccl_merge_kernel(const uint8_t* __restrict__ m, int* __restrict__ lab, int H, in
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= H * W || !slot_live(det_scores, n_det, b, k, R, confidence) || !m[base + p]) return;
     const int y = p / W, x = p - y * W;
-    if (x + 1 < W && m[base + p + 1]) uf_union(lab + base, p, p + 1);
-    if (y + 1 < H && m[base + p + W]) uf_union(lab + base, p, p + W);
+    const bool left = x > 0 && m[base + p - 1];
+    if ((threadIdx.x & 63) == 0 && left) uf_union(lab + base, p, p - 1);              // a run that continues across the wave boundary
+    // rows: one union per overlapping segment (its first pixel), not one per pixel
+    if (y + 1 < H && m[base + p + W] && !(left && m[base + p + W - 1])) uf_union(lab + base, p, p + W);
 }
 // Flattens the labels and counts the component sizes.  The lanes of a wave that found the same root add their number with ONE atomic
 // (neighbouring pixels mostly share a component; a device-scope atomic per pixel on a handful of addresses serialises: 330 us per
@@ -730,7 +743,7 @@ extern "C" int vidc_instance_map(const uint8_t* pasted, const float* det_scores,
     int* order = biggest + (size_t)B * R;
     int* n_ties = order + (size_t)B * R;
     const dim3 grid(vidc::cdiv(HW, 256), R, B);
-    hipLaunchKernelGGL(ccl_init_kernel, grid, dim3(256), 0, st, pasted, lab, cnt, biggest, n_ties, HW, det_scores, n_det, confidence);
+    hipLaunchKernelGGL(ccl_init_kernel, grid, dim3(256), 0, st, pasted, lab, cnt, biggest, n_ties, HW, W, det_scores, n_det, confidence);
     VIDC_CHECK_LAUNCH("ccl_init_kernel");
     hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, st, pasted, lab, H, W, det_scores, n_det, confidence);
     VIDC_CHECK_LAUNCH("ccl_merge_kernel");
