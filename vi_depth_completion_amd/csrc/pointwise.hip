@@ -58,15 +58,14 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
 __global__ void __launch_bounds__(256)
 maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int ldx, int Ho, int Wo, int ldy,
                unsigned short* __restrict__ ysp) {
-    const int q = C / 4;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)B * Ho * Wo * q;
-    if (idx >= total) return;
-    const int c = (int)(idx % q) * 4;
-    long long t = idx / q;
-    const int ox = (int)(t % Wo); t /= Wo;
-    const int oy = (int)(t % Ho);
-    const int b = (int)(t / Ho);
+    // grid.y = output row (image, oy): wave-uniform, so the per-thread index math is one 32-bit division (the first version
+    // decomposed a 64-bit linear index with three emulated 64-bit divisions per thread: VALU-bound at 52-62 % of the HBM peak)
+    const unsigned q = (unsigned)C / 4u;
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned)Wo * q) return;
+    const int ox = (int)(i / q);
+    const int c = (int)(i - (unsigned)ox * q) * 4;
+    const int b = (int)(blockIdx.y / (unsigned)Ho), oy = (int)(blockIdx.y - (unsigned)b * (unsigned)Ho);
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -99,15 +98,12 @@ __device__ inline void src_index(int dst, int in, int out, int& i0, int& i1, flo
 __global__ void __launch_bounds__(256)
 upsample_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int h, int w, int C, int ldx, int H, int W, int ldy,
                 int flags, unsigned short* __restrict__ ysp) {
-    const int q = C / 4;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)B * H * W * q;
-    if (idx >= total) return;
-    const int c = (int)(idx % q) * 4;
-    long long t = idx / q;
-    const int ox = (int)(t % W); t /= W;
-    const int oy = (int)(t % H);
-    const int b = (int)(t / H);
+    const unsigned q = (unsigned)C / 4u;                   // grid.y = output row (image, oy), see maxpool_kernel
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned)W * q) return;
+    const int ox = (int)(i / q);
+    const int c = (int)(i - (unsigned)ox * q) * 4;
+    const int b = (int)(blockIdx.y / (unsigned)H), oy = (int)(blockIdx.y - (unsigned)b * (unsigned)H);
     int y0, y1, x0, x1; float ly, lx;
     src_index(oy, h, H, y0, y1, ly);
     src_index(ox, w, W, x0, x1, lx);
@@ -269,8 +265,8 @@ extern "C" int vidc_maxpool3x3s2(const float* x, float* y, int B, int H, int W, 
     VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C,
                  VIDC_ERR_SHAPE, "vidc_maxpool3x3s2: bad shape (C, ldx, ldy must be multiples of 4)");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    long long total = (long long)B * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vidc::as_stream(stream), x, y, B, H, W,
+    VIDC_REQUIRE((long long)B * Ho <= 65535, VIDC_ERR_SHAPE, "vidc_maxpool3x3s2: B * Ho = %lld rows exceed the grid", (long long)B * Ho);
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)vidc::cdiv(Wo * (C / 4), 256), (unsigned)(B * Ho)), dim3(256), 0, vidc::as_stream(stream), x, y, B, H, W,
                        C, ldx, Ho, Wo, ldy, reinterpret_cast<unsigned short*>(y_split));
     VIDC_CHECK_LAUNCH("maxpool_kernel");
     return VIDC_OK;
@@ -284,8 +280,8 @@ extern "C" int vidc_upsample_bilinear_ac(const float* x, float* y, int B, int h,
     VIDC_REQUIRE(ldx >= C * (((flags >> 8) & 0xFF) > 1 ? ((flags >> 8) & 0xFF) : 1) && ldy >= C, VIDC_ERR_SHAPE, "vidc_upsample_bilinear_ac: bad channel strides");
     VIDC_REQUIRE(B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, VIDC_ERR_SHAPE,
                  "vidc_upsample_bilinear_ac: bad shape");
-    long long total = (long long)B * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vidc::as_stream(stream), x, y, B, h, w,
+    VIDC_REQUIRE((long long)B * H <= 65535, VIDC_ERR_SHAPE, "vidc_upsample_bilinear_ac: B * H = %lld rows exceed the grid", (long long)B * H);
+    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)vidc::cdiv(W * (C / 4), 256), (unsigned)(B * H)), dim3(256), 0, vidc::as_stream(stream), x, y, B, h, w,
                        C, ldx, H, W, ldy, flags, reinterpret_cast<unsigned short*>(y_split));
     VIDC_CHECK_LAUNCH("upsample_kernel");
     return VIDC_OK;
