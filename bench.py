@@ -120,13 +120,14 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)     # (one rank per GPU; the modulo only matters when
+    torch.cuda.set_device(local)                                                            #  the launch path is tried on a box with fewer GPUs)
     dev = torch.device("cuda", local)
     torch.set_grad_enabled(False)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        backend = os.environ.get("VIDC_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" to try the N > 1 path on a 1-GPU box
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     H, W, B = args.height, args.width, args.batch
     pipe, sn_sd, dc_sd, cc, det_sd = build_pipeline(H, W, dev, args.plane_head)

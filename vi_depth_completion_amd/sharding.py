@@ -22,6 +22,8 @@ def gather_records(rec):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return rec.detach().cpu()[None]
+    if dist.get_backend() == "gloo":
+        rec = rec.detach().cpu()
     out = [torch.zeros_like(rec) for _ in range(dist.get_world_size())]
     dist.all_gather(out, rec)
     return torch.stack(out).cpu()
