@@ -36,6 +36,9 @@ def main():
     model.load_state_dict(sd)
     demo = np.load(os.path.join(GOLD, "preprocess_demo_000000.npz"))["image"]
     images = {"demo": torch.from_numpy(demo), "synthetic": S.uniform01(1234, "plane_mask.image", (3, 240, 320))}
+    for fr in ("000068", "000085"):          # the other two demo frames of the whole-path fixtures (image_u8 as DemoDataset produced it)
+        u8 = np.load(os.path.join(GOLD, "demo_%s.npz" % fr))["image_u8"]
+        images["demo_" + fr] = torch.from_numpy(u8).permute(2, 0, 1).float().div(255)
     coco = object.__new__(COCODemo)
     coco.confidence_threshold = 0.9
     coco.cfg = cfg

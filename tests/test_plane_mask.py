@@ -31,7 +31,7 @@ def detector_weights(golden_dir):
 def oracle_runs(golden_dir, detector_weights):
     """name -> (golden npz, oracle taps, oracle instance map)"""
     out = {}
-    for name in ("demo", "synthetic"):
+    for name in ("demo", "synthetic", "demo_000068", "demo_000085"):
         g = np.load(os.path.join(golden_dir, "plane_mask_%s.npz" % name))
         taps = {}
         inst = PM.run_on_tensor(detector_weights, torch.from_numpy(g["image"]), taps=taps)
@@ -45,7 +45,7 @@ def test_anchor_buffers_match_reference(golden_dir):
     assert np.array_equal(mine, man["anchors"])
 
 
-@pytest.mark.parametrize("name", ["demo", "synthetic"])
+@pytest.mark.parametrize("name", ["demo", "synthetic", "demo_000068", "demo_000085"])
 def test_oracle_matches_reference_golden(oracle_runs, name):
     """Every stage of the restatement against the reference's own outputs.  Floats: 1e-5 (same torch-CPU kernels; observed 0);
     discrete results (detections kept, pasted masks, instance-id map): exact."""
@@ -64,7 +64,8 @@ def test_oracle_matches_reference_golden(oracle_runs, name):
     assert np.abs(t["det_scores"].numpy() - g["det_scores"]).max() < 1e-6
     assert np.abs(t["mask_prob"].numpy() - g["mask_prob"].astype(np.float32)).max() < 1e-3          # stored as fp16
     assert np.array_equal(np.packbits(t["pasted"].numpy().astype(bool), axis=-1), g["pasted_packed"])
-    assert np.array_equal(inst, g["instance_map"]) and inst.max() >= 2
+    assert np.array_equal(inst, g["instance_map"])
+    assert inst.max() >= 2 or name == "demo_000085"          # (that frame: no detection passes 0.9 with the seeded weights -- all background)
 
 
 def test_fast_nms_equals_pinned_nms():
@@ -119,7 +120,7 @@ def _rpn_maps(taps, dev="cuda"):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["demo", "synthetic"])
+@pytest.mark.parametrize("name", ["demo", "synthetic", "demo_000068", "demo_000085"])
 def test_dense_program_matches_oracle(detector, oracle_runs, name):
     """Backbone + FPN + RPN head.  Tolerance: activations are O(1) (max ~3); bf16x3 / fp32-MFMA summation-order noise through ~110
     convs: max |diff| 5e-3, mean 2e-4 (observed ~1e-3 / 3e-5)."""
@@ -139,7 +140,7 @@ def test_dense_program_matches_oracle(detector, oracle_runs, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["demo", "synthetic"])
+@pytest.mark.parametrize("name", ["demo", "synthetic", "demo_000068", "demo_000085"])
 def test_proposals_from_oracle_rpn_maps(detector, oracle_runs, name):
     """Top-k, decode, clip, NMS, selection over levels on the ORACLE's RPN maps: same proposals in the same order (boxes 1e-3 px: expf)."""
     g, t, _ = oracle_runs[name]
@@ -151,7 +152,7 @@ def test_proposals_from_oracle_rpn_maps(detector, oracle_runs, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["demo", "synthetic"])
+@pytest.mark.parametrize("name", ["demo", "synthetic", "demo_000068", "demo_000085"])
 def test_box_head_and_detections_from_oracle_inputs(detector, oracle_runs, name):
     g, t, _ = oracle_runs[name]
     feats = [_nhwc(f).cuda() for f in t["feats"][:4]]
@@ -171,7 +172,7 @@ def test_box_head_and_detections_from_oracle_inputs(detector, oracle_runs, name)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["demo", "synthetic"])
+@pytest.mark.parametrize("name", ["demo", "synthetic", "demo_000068", "demo_000085"])
 def test_mask_head_paste_and_instance_map_from_oracle_inputs(detector, oracle_runs, name):
     g, t, inst = oracle_runs[name]
     feats = [_nhwc(f).cuda() for f in t["feats"][:4]]
@@ -199,7 +200,7 @@ def test_mask_head_paste_and_instance_map_from_oracle_inputs(detector, oracle_ru
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["demo", "synthetic"])
+@pytest.mark.parametrize("name", ["demo", "synthetic", "demo_000068", "demo_000085"])
 def test_run_on_tensor_end_to_end(detector, oracle_runs, name):
     """Image -> instance-id map, nothing teacher-forced.  Discrete decisions (top-k order, NMS, the 0.9 / 0.5 / 5 % thresholds) sit on
     floats that differ by ~1e-3 between the HIP convs and torch-CPU, so single detections may flip; bar: >= 97 % of the pixels carry the
