@@ -124,6 +124,7 @@ __device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
 // a loader passes it after ITS loads of stage s have landed (its own vmcnt), a compute wave after it has read stage s-1.
 template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC, int SPEC>
 __global__ void __launch_bounds__(64 * WMW * WNW * WKW * (SPEC ? 2 : 1))
+__attribute__((amdgpu_waves_per_eu((BM == 128 && BN == 128 && NS == 2 && !SPEC) ? 2 : 1)))
 conv_igemm_f32(const ConvArgs a) {
     constexpr int NW = WMW * WNW * WKW, WPK = WMW * WNW;
     constexpr int TM = BM / (32 * WMW), TN = BN / (32 * WNW);
