@@ -46,6 +46,15 @@ def test_error_reporting_without_gpu(lib):
     d.KH = d.KW = d.stride = d.groups = d.splitk = 1
     assert lib.vidc_conv2d_bn_act(C.byref(d), None) == -2
     assert b"Cin" in lib.vidc_last_error()
+    # Cout must be whole 32-channel MFMA tiles (the stores are guarded per tile, not per lane): 48 and 8 are refused up front
+    for cout in (48, 8):
+        d.Cin, d.ldx, d.Cout, d.ldy = 64, 64, cout, 64
+        assert lib.vidc_conv2d_bn_act(C.byref(d), None) == -2
+        assert b"Cout" in lib.vidc_last_error()
+    # one group's weights must stay addressable with 32-bit buffer offsets
+    d.Cout, d.ldy, d.Cin, d.ldx, d.KH, d.KW, d.pad = 8192, 8192, 8192, 8192, 3, 3, 1
+    assert lib.vidc_conv2d_bn_act(C.byref(d), None) == -2
+    assert b"2 GiB" in lib.vidc_last_error()
 
 
 @pytest.mark.parametrize("M,N,K", [(4800, 768, 6912), (80, 3072, 27648), (300, 256, 2304), (19200, 64, 576), (4800, 64, 128)])

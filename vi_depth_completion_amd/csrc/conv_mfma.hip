@@ -727,11 +727,13 @@ template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC, int SPEC>
 int launch_tile_p(const ConvArgs& a, hipStream_t st) {
     constexpr int NT = 64 * WMW * WNW * WKW * (SPEC ? 2 : 1);
     constexpr size_t lds = (size_t)NS * (BM + BN) * BK * WKW * sizeof(float);
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
+    static bool attr_set[64] = {};   // per device (the attribute is per device function); benign race: idempotent
+    int dev = 0;
+    VIDC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         VIDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WMW, WNW, WKW, NS, PREC, SPEC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n * a.splitk * a.groups, 1, 1);
     hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WMW, WNW, WKW, NS, PREC, SPEC>), grid, dim3(NT), lds, st, a);
@@ -750,7 +752,8 @@ int validate(const vidc_conv_desc* d) {
     VIDC_REQUIRE(d->x && d->w && d->y && d->scale1 && d->shift1, VIDC_ERR_NULL, "conv: null tensor pointer");
     VIDC_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, VIDC_ERR_SHAPE, "conv: bad spatial dims");
     VIDC_REQUIRE(d->Cin > 0 && d->Cin % BK == 0, VIDC_ERR_SHAPE, "conv: Cin=%d must be a multiple of %d", d->Cin, BK);
-    VIDC_REQUIRE(d->Cout > 0 && d->Cout % 4 == 0, VIDC_ERR_SHAPE, "conv: Cout=%d must be a multiple of 4", d->Cout);
+    // whole 32-channel MFMA tiles only: the epilogue / split-K stores guard per tile, not per lane (include/vidc.h documents Cout % 32 == 0)
+    VIDC_REQUIRE(d->Cout > 0 && d->Cout % 32 == 0, VIDC_ERR_SHAPE, "conv: Cout=%d must be a multiple of 32", d->Cout);
     VIDC_REQUIRE(d->ldx >= d->Cin && d->ldy >= d->Cout && d->ldx % 4 == 0, VIDC_ERR_SHAPE, "conv: bad channel strides");
     VIDC_REQUIRE(d->KH >= 1 && d->KW >= 1 && d->KH <= 3 && d->KW <= 3 && d->stride >= 1 && d->pad >= 0, VIDC_ERR_SHAPE,
                  "conv: bad kernel geometry (kernels up to 3x3)");
@@ -770,6 +773,8 @@ int validate(const vidc_conv_desc* d) {
                  "conv: SPLIT_OUT needs y_split and Cout, ldy multiples of 32");
     VIDC_REQUIRE(!(d->flags & VIDC_NO_F32_OUT) || (d->flags & VIDC_SPLIT_OUT), VIDC_ERR_SHAPE, "conv: NO_F32_OUT without SPLIT_OUT writes nothing");
     VIDC_REQUIRE((long long)d->B * d->Ho * d->Wo < (1ll << 31), VIDC_ERR_SHAPE, "conv: M overflows int32");
+    VIDC_REQUIRE((long long)d->Cout * d->KH * d->KW * d->Cin * 4 < (1ll << 31), VIDC_ERR_SHAPE,
+                 "conv: one group's weights must stay below 2 GiB (32-bit buffer offsets)");
     VIDC_REQUIRE((long long)d->B * d->Ho * d->Wo * d->ldy < (1ll << 31) && (long long)d->B * d->H * d->W * d->ldx < (1ll << 29),
                  VIDC_ERR_SHAPE, "conv: tensor too large for 32-bit offsets (M*ldy < 2^31 elements, input < 2 GiB)");
     return VIDC_OK;
@@ -822,7 +827,7 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
     if (dd.tile == VIDC_TILE_AUTO) {
         int sk = dd.splitk;
         vidc_conv2d_plan(&dd);
-        if (!dd.workspace) dd.splitk = 1; else if (sk > 1) dd.splitk = sk;
+        dd.splitk = dd.workspace ? sk : 1;      // the caller sized the workspace for ITS splitk: the planner only picks the tile here
     }
     ConvArgs a;
     a.x = dd.x; a.w = dd.w; a.y = dd.y; a.scale1 = dd.scale1; a.shift1 = dd.shift1; a.scale2 = dd.scale2; a.shift2 = dd.shift2;

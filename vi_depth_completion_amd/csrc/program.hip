@@ -123,9 +123,15 @@ extern "C" int vidc_program_create(const vidc_op* ops, int n_ops, vidc_program**
         }
         if (op.stream_id + 1 > p->n_streams) p->n_streams = op.stream_id + 1;
     }
-    for (int k = 1; k < p->n_streams; ++k) VIDC_HIP(hipStreamCreateWithFlags(&p->side[k], hipStreamNonBlocking));
-    for (int k = 0; k < p->n_streams; ++k) VIDC_HIP(hipEventCreateWithFlags(&p->ev[k], hipEventDisableTiming));
-    VIDC_HIP(hipEventCreateWithFlags(&p->fork_ev, hipEventDisableTiming));
+    hipError_t e = hipSuccess;
+    for (int k = 1; k < p->n_streams && e == hipSuccess; ++k) e = hipStreamCreateWithFlags(&p->side[k], hipStreamNonBlocking);
+    for (int k = 0; k < p->n_streams && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->ev[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->fork_ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        vidc::set_error("vidc_program_create: stream/event creation failed: %s", hipGetErrorString(e));
+        vidc_program_destroy(p);      // frees whatever was created
+        return VIDC_ERR_HIP;
+    }
     *out = p;
     return VIDC_OK;
 }

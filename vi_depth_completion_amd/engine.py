@@ -676,6 +676,10 @@ class Program:
         L.check(lib.vidc_program_create(ops, len(ops), C.byref(h)), "program_create")
         self.handle = h
         self.captured = False
+        # The pack / fold kernels above ran on the stream that was current while this program was built, and their results are
+        # cached in the WeightStore: a program built later for another slot launches on ANOTHER stream and must not race them.
+        # One host wait here (not on the hot path) orders every later consumer after the packing.
+        torch.cuda.current_stream(self.device).synchronize()
         return self
 
     # ---- execution ----------------------------------------------------------------------------------------
