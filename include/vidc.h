@@ -191,10 +191,8 @@ int vidc_head_conv1x1_upsample(const float* x, const float* w, const float* bias
  * Per-slot result record (VIDC_PLANE_RECORD floats):
  *   [0..2] n_bar  [3] plane offset d  [4] n_inliers (normal RANSAC)  [5] mean |angle| in degrees  [6] accepted (<= 20 deg)
  *   [7] n_pts (sparse depths on the inliers)  [8] mean_depth  [9] n_offset_inliers
- *   [10] 1 = depth written, 0 = plane failed the validity tests, -1 = n_pts > VIDC_MAX_HYP (needs the host permutation
- *        of main.py:78; not done on device)  [11] n projected pixels  [12] best hypothesis row */
-
-#define VIDC_MAX_SPARSE 4096      /* most sparse-depth pixels per image the plane-offset stage will look at */
+ *   [10] 1 = depth written, 0 = plane failed the validity tests, -1 = n_pts > VIDC_MAX_HYP and no host draw was supplied
+ *        for this slot (main.py:75-78; see vidc_plane_offset_dense)  [11] n projected pixels  [12] best hypothesis row */
 
 /* Bytes of device scratch the three plane stages below share for one batch (chunk partial sums, validity statistics,
  * the per-image row-major list of sparse-depth pixels). */
@@ -217,6 +215,16 @@ int vidc_plane_offset(const float* homo, const float* depth, const int32_t* slot
                       const uint8_t* inlier_mask, const int32_t* counts, int HW, void* scratch, float* records,
                       vidc_stream_t stream);
 
+/* The same, with the subsampled branch of plane_offset_ransac (main.py:75-78: more than 300 points on a plane ->
+ * hypotheses = np.random.permutation(np.r_[0:n_pts])[0:300]).  The permutation is a HOST draw from numpy's legacy generator in
+ * the reference's draw order, so the protocol has two passes: the first call (dense_* NULL, or dense_n[slot] != n_pts) flags
+ * such slots (record[10] = -1, record[7] = n_pts); the host draws and calls again with dense_hyp [n_slots][VIDC_MAX_HYP] = the
+ * 300 ranks (into the row-major list of the plane's points), dense_n [n_slots] = the n_pts each row was drawn for (0 = none),
+ * dense_dots [n_slots][HW] floats of scratch.  All three NULL = vidc_plane_offset. */
+int vidc_plane_offset_dense(const float* homo, const float* depth, const int32_t* slots, int n_slots, int B,
+                            const uint8_t* inlier_mask, const int32_t* counts, int HW, void* scratch, float* records,
+                            const int32_t* dense_hyp, const int32_t* dense_n, float* dense_dots, vidc_stream_t stream);
+
 /* generate_depth_from_plane (main.py:110-127) -- the normal->depth plane projection: depth = -d/(n.homo) on
  * mask & |n.homo| > 1e-3; the plane is dropped when > 5% of its values exceed 10*mean_depth, any exceeds 10 m or any
  * is negative; otherwise the values are written into plane_depth [B][HW] (pre-initialised with the sparse depth). */
@@ -237,6 +245,11 @@ int vidc_plane_finalize(const float* depth, float* plane_depth, int B, int HW, c
  * exclusive prefix sums of the chunk counts returned by vidc_plane_finalize. */
 int vidc_enrich_scatter(const float* plane_depth, const int32_t* sub, const int32_t* sub_offsets, const int32_t* chunk_base,
                         int B, int HW, float* enriched, vidc_stream_t stream);
+
+/* The same with main.py:286 (`depth_enriched = ds.clone()`) fused in: EVERY pixel of enriched [B][HW] is written (the sparse depth,
+ * or the selected plane depth), so the caller neither clones nor initialises it; sub_offsets[b+1] == sub_offsets[b] gives a plain copy. */
+int vidc_enrich_scatter_from(const float* plane_depth, const float* sparse_depth, const int32_t* sub, const int32_t* sub_offsets,
+                             const int32_t* chunk_base, int B, int HW, float* enriched, vidc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * frame pre-processing on the device   (dataset.py:461-510)

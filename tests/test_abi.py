@@ -76,7 +76,7 @@ def test_rng_draws_follow_reference_order():
     from vi_depth_completion_amd import plane, synthetic as S
     ids = S.plane_id_map(240, 320)
     np.random.seed(3)
-    slots, hyp = plane.draw_normal_hypotheses([ids])
+    slots, hyp, _ = plane.draw_normal_hypotheses([ids])
     np.random.seed(3)
     flat = ids.reshape(-1)
     exp = []
@@ -92,8 +92,18 @@ def test_rng_draws_follow_reference_order():
     e2 = np.unique(np.random.randint(0, 50, size=50))
     assert offs.tolist() == [0, len(e0), len(e0), len(e0) + len(e2)]
     assert np.array_equal(sub, np.concatenate([e0, e2]))
+    # a plane with > 300 sparse points (known from a first device pass): plane_offset_ransac's permutation (main.py:78) is drawn
+    # right after that plane's normal hypotheses and before the next plane's
+    np.random.seed(3)
+    slots_d, hyp_d, dense = plane.draw_normal_hypotheses([ids], dense={0: 500})
+    np.random.seed(3)
+    e1 = np.random.permutation(np.r_[0:int((flat == 1).sum())])[0:300]
+    ed = np.random.permutation(np.r_[0:500])[0:300]
+    e2 = np.random.permutation(np.r_[0:int((flat == 2).sum())])[0:300]
+    assert np.array_equal(dense[0], ed) and list(dense) == [0]
+    assert np.array_equal(hyp_d, np.concatenate([np.flatnonzero(flat == 1)[e1], np.flatnonzero(flat == 2)[e2]]))
     # background-only map: no slots (main.py:135-137)
-    s2, h2 = plane.draw_normal_hypotheses([np.zeros((240, 320), np.uint8)])
+    s2, h2, _ = plane.draw_normal_hypotheses([np.zeros((240, 320), np.uint8)])
     assert s2.shape == (0, 4) and h2.size == 0
 
 

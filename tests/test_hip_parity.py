@@ -437,6 +437,10 @@ def _golden_batch(f, name):
             "homogeneous_coordinates": S.homogeneous_grid(S.DEMO_FC, S.DEMO_CC, 320, 240)[None]}
 
 
+def _intr():
+    return O.Intrinsics(202.0, 202.0, 0.5 * 319.87654, 0.5 * 239.87603)
+
+
 GOLDEN_FRAMES = ["demo_000000", "demo_000068", "demo_000085", "synthetic_f0"]
 
 
@@ -557,14 +561,60 @@ def test_plane_block_edge_cases_vs_oracle(pipeline, case):
         assert torch.equal((en.cpu() > 0), (want_en > 0))
 
 
-def test_plane_with_more_than_300_points_is_refused(pipeline):
-    """plane_offset_ransac subsamples with a host permutation above 300 points (main.py:78); that branch is not on the device:
-    the path must say so instead of returning something else."""
-    normals, ds, homo = _plane_scene(9, n_sparse=3000)
+@pytest.mark.parametrize("n_sparse,seed", [(3000, 9), (12000, 10), (700, 11)])
+def test_plane_with_more_than_300_points_subsamples_like_the_reference(pipeline, n_sparse, seed):
+    """plane_offset_ransac subsamples its hypotheses with a host permutation above 300 points on a plane (main.py:75-78), drawn
+    BETWEEN the normal-hypothesis draws of consecutive planes.  The device flags such planes, the host replays the draws in the
+    reference's order (plane.PlaneBlock._resolve_dense) and the result -- depths, enrichment, and the generator state afterwards
+    (i.e. the number and order of draws) -- is the oracle's.  Tolerances as in test_plane_block_edge_cases."""
+    normals, ds, homo = _plane_scene(seed, n_sparse=n_sparse)
     ids = S.plane_id_map(240, 320)
-    di, info = pipeline.planes.plane_depth(normals.to(DEV), [ids], ds.to(DEV), homo.to(DEV), rng=np.random.RandomState(3))
-    with pytest.raises(NotImplementedError, match="300"):
-        pipeline.planes.enrich(ds.to(DEV), di, info, 200, rng=np.random.RandomState(4))
+    rng_w, rng_g = np.random.RandomState(3), np.random.RandomState(3)
+    trace = []
+    want = O.extract_plane_depth(normals[0], torch.from_numpy(ids.astype(np.int64)), ds[0, 0], homo[0], rng=rng_w, trace=trace)
+    assert any(r["accepted"] for r in trace)
+    di, info = pipeline.planes.plane_depth(normals.to(DEV), [ids], ds.to(DEV), homo.to(DEV), rng=rng_g)
+    en = pipeline.planes.enrich(ds.to(DEV), di, info, 200, rng=rng_g).cpu()
+    assert pipeline.planes._ctx["dense"], "the scene was built to put > 300 sparse points on a plane"
+    got = di[0, 0].cpu()
+    rec = pipeline.planes.last_records.cpu().numpy()
+    for k, r in enumerate(trace):
+        assert bool(rec[k, 6]) == r["accepted"]
+        if r["accepted"]:
+            assert int(rec[k, 9]) == r["n_off_inl"], (k, rec[k], r)
+            assert abs(rec[k, 3] - r["offset"]) < 1e-4 * max(1.0, abs(r["offset"]))
+    written_w, written_g = (want > 0) & (ds[0, 0] == 0), (got > 0) & (ds[0, 0] == 0)
+    assert int((written_w != written_g).sum()) <= 5, (int(written_w.sum()), int(written_g.sum()))
+    both = written_w & written_g
+    assert both.any()
+    assert ((got - want)[both].abs() / want[both].clamp(min=1.0)).max() < 2e-3
+    assert torch.equal(got[ds[0, 0] > 0], ds[0, 0][ds[0, 0] > 0])
+    if int(pipeline.planes.last_nnz[0]) == int((want > 0).sum()):
+        want_en = O.enrich_sparse_depth(ds, want[None, None], 200, rng=rng_w)
+        assert torch.equal(en > 0, want_en > 0)
+        sa, sb = rng_w.get_state(), rng_g.get_state()
+        assert np.array_equal(sa[1], sb[1]) and sa[2] == sb[2], "host draws diverged from the reference's order"
+
+
+def test_dense_depth_input_in_the_pipeline(pipeline, seeded_weights):
+    """A frame with 5000 sparse-depth points (VOID / dense-KLT style) through `_call_cnn` and through `run_interleaved`: the
+    subsampled branch is taken mid-pipeline and the outputs are the oracle's (RMSE bar 1e-3, north_star)."""
+    batch = S.synthetic_batch(1, 240, 320, 1234, frame0=21)
+    g = torch.Generator().manual_seed(5)
+    ds = batch["sparse_depth"].clone()
+    pix = torch.randperm(240 * 320, generator=g)[:5000]
+    ds.view(-1)[pix] = 1.0 + 3.0 * torch.rand(5000, generator=g)
+    batch["sparse_depth"] = ds
+    masks = [S.plane_id_map(240, 320)]
+    intr = _intr()
+    ref = O.call_cnn(seeded_weights["sn"], seeded_weights["dc"], batch, masks, intr, 200, rng=np.random.RandomState(8))
+    pipeline.rng = np.random.RandomState(8)
+    got = pipeline._call_cnn(batch).cpu()
+    assert float((got - ref).pow(2).mean().sqrt()) < 1e-3
+    pipeline.rng = np.random.RandomState(8)
+    dev_batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    outs = [o.cpu() for o in pipeline.run_interleaved(iter([dev_batch]))]
+    assert float((outs[0] - ref).pow(2).mean().sqrt()) < 1e-3
 
 
 def test_enriched_samples_zero_skips_the_plane_block(pipeline, seeded_weights):

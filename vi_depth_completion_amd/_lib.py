@@ -84,10 +84,12 @@ SIGNATURES = {
     "vidc_plane_scratch_bytes": (C.c_size_t, [_i, _i, _i]),
     "vidc_plane_ransac_normal": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "vidc_plane_offset": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "vidc_plane_offset_dense": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vidc_plane_project_depth": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "vidc_plane_info_count": (C.c_int, [_i, _i]),
     "vidc_plane_finalize": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
     "vidc_enrich_scatter": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "vidc_enrich_scatter_from": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "vidc_resize_coeffs": (C.c_int, [_i, _i, _vp, _vp, _i, C.POINTER(C.c_int)]),
     "vidc_resize_bilinear_u8_to_chw": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "vidc_rasterize_sparse_depth": (C.c_int, [_vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_double, _vp, _i, _i, _vp]),

@@ -184,7 +184,8 @@ __global__ void __launch_bounds__(CH)
 plane_offset_kernel(const float* __restrict__ homo, const float* __restrict__ depth, const Slot* __restrict__ slots,
                     const uint8_t* __restrict__ inlier_mask, int HW, int n_chunks, const float* __restrict__ partial,
                     const float* __restrict__ apartial, const int32_t* __restrict__ sparse_idx, const int32_t* __restrict__ n_sparse,
-                    int max_sparse, const int32_t* __restrict__ counts, float* __restrict__ records) {
+                    int max_sparse, const int32_t* __restrict__ counts, float* __restrict__ records,
+                    const int32_t* __restrict__ dense_hyp, const int32_t* __restrict__ dense_n, float* __restrict__ dense_dots) {
     __shared__ float redf[CH / 64];
     __shared__ int redi[CH / 64];
     __shared__ float dots[VIDC_MAX_HYP];
@@ -242,6 +243,7 @@ plane_offset_kernel(const float* __restrict__ homo, const float* __restrict__ de
             for (int w = 0; w < wave; ++w) k += wcnt[w];
             k += __popcll(m & ((1ull << lane) - 1ull));
             if (f && k < VIDC_MAX_HYP) dots[k] = dt;
+            if (f && dense_dots) dense_dots[(size_t)blockIdx.x * HW + k] = dt;      // every on-plane point, for the subsampled branch
             dloc += d;
             for (int w = 0; w < CH / 64; ++w) total += wcnt[w];
         }
@@ -250,13 +252,40 @@ plane_offset_kernel(const float* __restrict__ homo, const float* __restrict__ de
     }
     __syncthreads();
     const int n_pts = s_n;
-    if (n_pts > VIDC_MAX_HYP || n_sparse[s.b] > max_sparse) {   // would need the host permutation (main.py:78): flagged, not faked
-        if (threadIdx.x == 0) { rec[7] = (float)n_pts; rec[9] = 0.f; rec[10] = -1.f; rec[6] = 0.f; }
-        return;
-    }
     float offset = 0.f;
     int n_inl = 0;
-    if (n_pts == 1) {
+    if (n_pts > VIDC_MAX_HYP) {
+        // main.py:75-78: more points than hypotheses -> the hypotheses are np.random.permutation(np.r_[0:n_pts])[0:300], a HOST draw
+        // (numpy's legacy generator, in the reference's draw order).  First pass: flag the slot and report n_pts; the host draws
+        // and calls again with dense_hyp[slot] = the 300 ranks and dense_n[slot] = the n_pts they were drawn for.
+        if (!dense_hyp || !dense_n || !dense_dots || dense_n[blockIdx.x] != n_pts) {
+            if (threadIdx.x == 0) { rec[7] = (float)n_pts; rec[9] = 0.f; rec[10] = -1.f; rec[6] = 0.f; }
+            return;
+        }
+        __threadfence_block();
+        __syncthreads();
+        const float* dd = dense_dots + (size_t)blockIdx.x * HW;
+        const int32_t* hy = dense_hyp + (size_t)blockIdx.x * VIDC_MAX_HYP;
+        for (int j = threadIdx.x; j < VIDC_MAX_HYP; j += CH) {
+            int c = 0;
+            const float hyp = -dd[hy[j]];
+            for (int i = 0; i < n_pts; ++i) c += (fabsf(hyp + dd[i]) < DIST_THR) ? 1 : 0;      // dd[i]: one broadcast load per step
+            hcnt[j] = c;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int bst = first_argmax(hcnt, VIDC_MAX_HYP);
+            if (threadIdx.x == 0) s_best = bst;
+        }
+        __syncthreads();
+        const float hyp = -dd[hy[s_best]];
+        float sdot = 0.f; int c = 0;
+        for (int i = threadIdx.x; i < n_pts; i += CH)
+            if (fabsf(hyp + dd[i]) < DIST_THR) { sdot += dd[i]; ++c; }
+        sdot = block_sum(sdot, redf);
+        n_inl = block_sum(c, redi);
+        offset = n_inl > 0 ? -(sdot / (float)n_inl) : 0.f;
+    } else if (n_pts == 1) {
         offset = -dots[0]; n_inl = 1;               // main.py:81-83
     } else if (n_pts > 1) {
         for (int j = threadIdx.x; j < n_pts; j += CH) {
@@ -446,14 +475,19 @@ plane_finalize_kernel(const float* __restrict__ depth, float* __restrict__ plane
 
 // ---- stage 5: copy the sub[]-th nonzeros (row-major order) of plane_depth into the enriched sparse depth -----------
 // chunk_base: [B][n_chunks] exclusive prefix of the chunk counts (computed by the host from `info`).
+// `sparse` != NULL: enriched = clone(sparse) with the selected plane depths copied in, in ONE pass (main.py:286 + :293-294) --
+// every pixel is written, so `enriched` needs no initialisation; NULL: only the selected pixels are written (the caller cloned).
 __global__ void __launch_bounds__(CH)
-enrich_scatter_kernel(const float* __restrict__ plane_depth, const int32_t* __restrict__ sub, const int32_t* __restrict__ sub_off,
-                      const int32_t* __restrict__ chunk_base, int HW, float* __restrict__ enriched) {
+enrich_scatter_kernel(const float* __restrict__ plane_depth, const float* __restrict__ sparse, const int32_t* __restrict__ sub,
+                      const int32_t* __restrict__ sub_off, const int32_t* __restrict__ chunk_base, int HW, float* __restrict__ enriched) {
     __shared__ int wave_base[CH / 64];
     const int b = blockIdx.y;
     const int s0 = sub_off[b], n_sub = sub_off[b + 1] - s0;
-    if (n_sub <= 0) return;
     const int p = blockIdx.x * CH + threadIdx.x;
+    if (n_sub <= 0) {
+        if (sparse && p < HW) enriched[(size_t)b * HW + p] = sparse[(size_t)b * HW + p];
+        return;
+    }
     const float v = p < HW ? plane_depth[(size_t)b * HW + p] : 0.f;
     const bool nz = v > 0.f;
     const unsigned long long m = __ballot(nz);
@@ -463,18 +497,23 @@ enrich_scatter_kernel(const float* __restrict__ plane_depth, const int32_t* __re
     int k = chunk_base[(size_t)b * gridDim.x + blockIdx.x];
     for (int w = 0; w < wave; ++w) k += wave_base[w];
     k += __popcll(m & ((1ull << lane) - 1ull));       // row-major rank of this pixel among the nonzeros of image b
-    if (!nz) return;
-    int lo = 0, hi = n_sub;                            // sub is sorted and unique: binary search for k
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sub[s0 + mid] < k) lo = mid + 1; else hi = mid; }
-    if (lo < n_sub && sub[s0 + lo] == k) enriched[(size_t)b * HW + p] = v;
+    bool hit = false;
+    if (nz) {
+        int lo = 0, hi = n_sub;                        // sub is sorted and unique: binary search for k
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sub[s0 + mid] < k) lo = mid + 1; else hi = mid; }
+        hit = lo < n_sub && sub[s0 + lo] == k;
+    }
+    if (hit) enriched[(size_t)b * HW + p] = v;
+    else if (sparse && p < HW) enriched[(size_t)b * HW + p] = sparse[(size_t)b * HW + p];
 }
 
 }  // namespace
 
 extern "C" size_t vidc_plane_scratch_bytes(int n_slots, int B, int HW) {
     const size_t nc = (size_t)vidc::cdiv(HW, CH);
-    // partial [slots][nc][4] f32 + apartial [slots][nc] f32 + stats [slots][nc][4] i32 + sparse list [B][VIDC_MAX_SPARSE] + n_sparse[B]
-    return (size_t)n_slots * nc * (4 + 1 + 4) * 4 + (size_t)B * (VIDC_MAX_SPARSE + 1) * 4 + 256;
+    // partial [slots][nc][4] f32 + apartial [slots][nc] f32 + stats [slots][nc][4] i32 + sparse list [B][HW] + n_sparse[B]
+    // (the list holds EVERY pixel with depth > 0: dense depth inputs take the subsampled branch of plane_offset_ransac, main.py:75-78)
+    return (size_t)n_slots * nc * (4 + 1 + 4) * 4 + (size_t)B * ((size_t)HW + 1) * 4 + 256;
 }
 
 extern "C" int vidc_plane_ransac_normal(const float* normals, const uint8_t* ids, const int32_t* slots, int n_slots,
@@ -501,18 +540,26 @@ extern "C" int vidc_plane_ransac_normal(const float* normals, const uint8_t* ids
 extern "C" int vidc_plane_offset(const float* homo, const float* depth, const int32_t* slots, int n_slots, int B,
                                  const uint8_t* inlier_mask, const int32_t* counts, int HW, void* scratch, float* records,
                                  vidc_stream_t stream) {
+    return vidc_plane_offset_dense(homo, depth, slots, n_slots, B, inlier_mask, counts, HW, scratch, records, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int vidc_plane_offset_dense(const float* homo, const float* depth, const int32_t* slots, int n_slots, int B,
+                                       const uint8_t* inlier_mask, const int32_t* counts, int HW, void* scratch, float* records,
+                                       const int32_t* dense_hyp, const int32_t* dense_n, float* dense_dots, vidc_stream_t stream) {
     VIDC_REQUIRE(homo && depth && slots && inlier_mask && counts && scratch && records, VIDC_ERR_NULL, "vidc_plane_offset: null pointer");
+    VIDC_REQUIRE((!dense_hyp && !dense_n && !dense_dots) || (dense_hyp && dense_n && dense_dots), VIDC_ERR_NULL,
+                 "vidc_plane_offset_dense: dense_hyp, dense_n and dense_dots go together");
     VIDC_REQUIRE(n_slots > 0 && HW > 0 && B > 0, VIDC_ERR_SHAPE, "vidc_plane_offset: bad shape");
     hipStream_t st = vidc::as_stream(stream);
     const int nc = vidc::cdiv(HW, CH);
     float* partial = reinterpret_cast<float*>(scratch);
     float* apartial = partial + (size_t)n_slots * nc * 4;
     int32_t* sparse_idx = reinterpret_cast<int32_t*>(apartial + (size_t)n_slots * nc) + (size_t)n_slots * nc * 4;
-    int32_t* n_sparse = sparse_idx + (size_t)B * VIDC_MAX_SPARSE;
-    hipLaunchKernelGGL(sparse_list_kernel, dim3(B), dim3(1024), 0, st, depth, HW, VIDC_MAX_SPARSE, sparse_idx, n_sparse);
+    int32_t* n_sparse = sparse_idx + (size_t)B * HW;
+    hipLaunchKernelGGL(sparse_list_kernel, dim3(B), dim3(1024), 0, st, depth, HW, HW, sparse_idx, n_sparse);
     VIDC_CHECK_LAUNCH("sparse_list_kernel");
     hipLaunchKernelGGL(plane_offset_kernel, dim3(n_slots), dim3(CH), 0, st, homo, depth, reinterpret_cast<const Slot*>(slots),
-                       inlier_mask, HW, nc, partial, apartial, sparse_idx, n_sparse, VIDC_MAX_SPARSE, counts, records);
+                       inlier_mask, HW, nc, partial, apartial, sparse_idx, n_sparse, HW, counts, records, dense_hyp, dense_n, dense_dots);
     VIDC_CHECK_LAUNCH("plane_offset_kernel");
     return VIDC_OK;
 }
@@ -548,8 +595,18 @@ extern "C" int vidc_enrich_scatter(const float* plane_depth, const int32_t* sub,
                                    int B, int HW, float* enriched, vidc_stream_t stream) {
     VIDC_REQUIRE(plane_depth && sub && sub_offsets && chunk_base && enriched, VIDC_ERR_NULL, "vidc_enrich_scatter: null pointer");
     VIDC_REQUIRE(B > 0 && HW > 0, VIDC_ERR_SHAPE, "vidc_enrich_scatter: bad shape");
-    hipLaunchKernelGGL(enrich_scatter_kernel, dim3(vidc::cdiv(HW, CH), B), dim3(CH), 0, vidc::as_stream(stream), plane_depth, sub,
-                       sub_offsets, chunk_base, HW, enriched);
+    hipLaunchKernelGGL(enrich_scatter_kernel, dim3(vidc::cdiv(HW, CH), B), dim3(CH), 0, vidc::as_stream(stream), plane_depth,
+                       (const float*)nullptr, sub, sub_offsets, chunk_base, HW, enriched);
+    VIDC_CHECK_LAUNCH("enrich_scatter_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_enrich_scatter_from(const float* plane_depth, const float* sparse_depth, const int32_t* sub, const int32_t* sub_offsets,
+                                        const int32_t* chunk_base, int B, int HW, float* enriched, vidc_stream_t stream) {
+    VIDC_REQUIRE(plane_depth && sparse_depth && sub && sub_offsets && chunk_base && enriched, VIDC_ERR_NULL, "vidc_enrich_scatter_from: null pointer");
+    VIDC_REQUIRE(B > 0 && HW > 0 && enriched != sparse_depth, VIDC_ERR_SHAPE, "vidc_enrich_scatter_from: bad shape (enriched must not alias sparse_depth)");
+    hipLaunchKernelGGL(enrich_scatter_kernel, dim3(vidc::cdiv(HW, CH), B), dim3(CH), 0, vidc::as_stream(stream), plane_depth, sparse_depth,
+                       sub, sub_offsets, chunk_base, HW, enriched);
     VIDC_CHECK_LAUNCH("enrich_scatter_kernel");
     return VIDC_OK;
 }

@@ -372,8 +372,10 @@ class Program:
         self._emit("warp_fwd", [x, params], [y], x=x, p=params, y=y, intr=intr, ac=int(align_corners))
         return y
 
-    def warp_inv(self, x, params, intr, align_corners, normalize=True):
-        y = T(self._new_buf(x.B * 3 * x.H * x.W), x.B, x.H, x.W, 3, nchw=True)
+    def warp_inv(self, x, params, intr, align_corners, normalize=True, out=None):
+        """`out`: an existing NCHW (B,3,H,W) tensor to write into (e.g. the input buffer a later tick reads the normals from)."""
+        y = out if out is not None else T(self._new_buf(x.B * 3 * x.H * x.W), x.B, x.H, x.W, 3, nchw=True)
+        assert y.nchw and (y.B, y.C, y.H, y.W) == (x.B, 3, x.H, x.W)
         self._emit("warp_inv", [x, params], [y], x=x, p=params, y=y, intr=intr, ac=int(align_corners), norm=int(normalize))
         return y
 

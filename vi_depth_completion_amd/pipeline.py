@@ -59,7 +59,10 @@ def build_frame_program(sn, dc, B, H, W, device, dry_run=False, weights=None):
     zs = emit_decoder(prog, sn, sn_levels, "sn/")
     h = prog.conv(zs, "sn/feature_concat.0", relu=True, padding=1)
     y, _low = prog.head(h, "sn/feature_concat.2", 0, (H, W), relu=False)
-    z = prog.warp_inv(y, params, wp, wp.align_corners, normalize=True)
+    # The normals of frame t are written straight into the buffer the normal pyramid of the depth network reads them from one
+    # tick later: its stem (earlier in this very segment, same stream) has consumed frame t-1's normals by then, so the
+    # hand-over costs no copy.
+    z = prog.warp_inv(y, params, wp, wp.align_corners, normalize=True, out=nrm)
     prog.mark_output("normals", z)
     prog.cut()
     zd = emit_decoder(prog, dc, dc_levels, "dc/")
@@ -163,7 +166,7 @@ class DepthCompletionPipeline:
         depth_in = st["ds"]
         if st["di"] is not None:
             depth_in = planes.enrich(st["ds"], st["di"], st["nnz"], self.args.enriched_samples, rng=st["rng"])
-            st["enriched"] = depth_in
+            st["enriched"] = depth_in          # (buffers of `planes`: valid until its next batch)
         return self.cnn.enqueue(st["rgb"], st["normals"], depth_in, slot)
 
     @torch.no_grad()
@@ -173,7 +176,8 @@ class DepthCompletionPipeline:
         if taps is not None:
             taps["normals"] = st["normals"].clone()
             if st["di"] is not None:
-                taps.update(plane_depth=st["di"], enriched=st["enriched"], records=self.planes.last_records)
+                taps.update(plane_depth=st["di"].clone(), enriched=st["enriched"].clone(), records=self.planes.last_records.clone()
+                            if self.planes.last_records is not None else None)
         return out
 
     # ---- software-pipelined throughput mode ------------------------------------------------------------------------
@@ -185,21 +189,25 @@ class DepthCompletionPipeline:
         return self._frame_prog
 
     @torch.no_grad()
-    def run_interleaved(self, batches):
+    def run_interleaved(self, batches, copy_outputs=True):
         """Throughput mode, software-pipelined over frames: tick t runs the surface-normal network + plane block of frame
         t and the depth-completion network of frame t-1 as ONE program (build_frame_program).  Yields the depth map of
         every batch, in order; n batches take n+1 ticks.  Per frame the arithmetic is that of `_call_cnn` (same kernels;
         the 4-group launches may use another tile than the 1-/3-group ones, i.e. fp32 sums in a different order), and the
-        RANSAC / enrichment draws come off `self.rng` in the same order as back-to-back `_call_cnn` calls."""
+        RANSAC / enrichment draws come off `self.rng` in the same order as back-to-back `_call_cnn` calls.
+
+        Data movement per tick: the frame is copied into the program's input buffer once (and from there to the depth
+        network's image input one tick later, device to device); the normals and the enriched sparse depth are WRITTEN where the
+        next tick reads them (no copies).  The caller's tensors are not referenced after the call that consumed them.
+        copy_outputs=False hands out the program's own output buffer: valid until the next item is requested."""
         import itertools
         import os
         if not self.use_gravity:
             raise NotImplementedError("run_interleaved pipelines the gravity-aligned surface-normal network; use _call_cnn with use_gravity=False")
         dev = self.device
         prog = None
-        prev = None            # frame waiting for its depth network: dict(rgb, enriched)
+        have_prev = False      # a frame is waiting for its depth network (its inputs sit in the program's buffers)
         for batch in itertools.chain(batches, [None]):
-            cur = None
             if batch is not None:
                 rgb = batch["image"].to(dev, non_blocking=True)
                 ds = batch["sparse_depth"].to(dev, non_blocking=True)
@@ -219,41 +227,42 @@ class DepthCompletionPipeline:
                             prog.run()            # warm-up outside capture (sets kernel attributes)
                             prog.capture_segments()
                         torch.cuda.current_stream().wait_stream(side)
+                    sn_image, dc_image = prog.tensor(prog.inputs["sn_image"]), prog.tensor(prog.inputs["dc_image"])
+                    dc_depth = prog.tensor(prog.inputs["dc_depth"])
+                    grav = prog.storage[prog.inputs["gravity"].buf][: B * 3]
+                    algn = prog.storage[prog.inputs["aligned"].buf][: B * 3]
             elif prog is None:
                 return
             graph = prog.captured
-            if prev is not None:      # inputs of frame t-1's depth network; `normals` still holds frame t-1's output here
-                prog.tensor(prog.inputs["dc_image"]).copy_(prev["rgb"], non_blocking=True)
-                prog.tensor(prog.inputs["dc_normal"]).copy_(prog.tensor(prog.outputs["normals"]), non_blocking=True)
-                prog.tensor(prog.inputs["dc_depth"]).copy_(prev["depth_in"], non_blocking=True)
+            if have_prev:             # frame t-1's image is still in the surface-normal input buffer; its normals and its enriched
+                dc_image.copy_(sn_image, non_blocking=True)       # depth were written in place by the previous tick
+            pending = None
             if batch is not None:
                 mh = self._masks_begin(rgb) if self.args.enriched_samples != 0 else None    # ids reach the host while segment 0 runs
-                prog.tensor(prog.inputs["sn_image"]).copy_(rgb, non_blocking=True)
-                prog.storage[prog.inputs["gravity"].buf][: B * 3].copy_(batch["gravity"].to(dev).reshape(-1), non_blocking=True)
-                prog.storage[prog.inputs["aligned"].buf][: B * 3].copy_(batch["aligned_direction"].to(dev).reshape(-1), non_blocking=True)
+                sn_image.copy_(rgb, non_blocking=True)
+                grav.copy_(batch["gravity"].to(dev).reshape(-1), non_blocking=True)
+                algn.copy_(batch["aligned_direction"].to(dev).reshape(-1), non_blocking=True)
                 prog.launch_segment(0) if graph else prog.run_segment(0)
                 normals = prog.tensor(prog.outputs["normals"])
-                # the depth network of this frame runs in the NEXT tick: keep private copies of what it will read then, in case the
-                # caller recycles its input tensors (a host->device transfer above already made one)
-                own = lambda t, src: t if t.data_ptr() != src.data_ptr() else t.clone()
-                cur = {"rgb": own(rgb, batch["image"]), "depth_in": own(ds, batch["sparse_depth"])}
-                pending = None
                 if self.args.enriched_samples != 0:
                     homo = batch["homogeneous_coordinates"].to(dev, non_blocking=True)
                     masks = self._masks_end(mh, batch["image"], H, W)
                     di, info = self.planes.plane_depth(normals, masks, ds, homo, rng=self.rng)
                     pending = (di, info, self.planes.read_info_async(info))
-            elif prev is not None:
+                else:
+                    dc_depth.copy_(ds, non_blocking=True)     # (segment 0 above has read the previous frame's depth input)
+            elif have_prev:
                 # drain tick: no new frame; the pyramids still run 4 groups (group 0 recomputes the last frame's features)
                 prog.launch_segment(0) if graph else prog.run_segment(0)
-            if prev is not None:
+            if have_prev:
                 prog.launch_segment(1) if graph else prog.run_segment(1)
-            if batch is not None and pending is not None:
-                di, info, info_host = pending       # the host waits for the counts while segment 1 keeps the GPU busy
-                cur["depth_in"] = self.planes.enrich(ds, di, info, self.args.enriched_samples, rng=self.rng, info_host=info_host)
-            if prev is not None:
-                yield prog.tensor(prog.outputs["depth"]).clone()
-            prev = cur
+            if pending is not None:
+                di, info, info_host = pending       # the host waits for the counts while segment 1 keeps the GPU busy;
+                self.planes.enrich(ds, di, info, self.args.enriched_samples, rng=self.rng, info_host=info_host, out=dc_depth)   # written in place
+            if have_prev:
+                out = prog.tensor(prog.outputs["depth"])
+                yield out.clone() if copy_outputs else out
+            have_prev = batch is not None
 
     @torch.no_grad()
     def run_stream(self, batches, in_flight=2, frame_rng=None):

@@ -14,11 +14,14 @@ from . import _lib as L
 NUM_HYPOTHESES = 300   # main.py:38,68
 
 
-def draw_normal_hypotheses(id_maps, rng=np.random):
+def draw_normal_hypotheses(id_maps, rng=np.random, dense=None):
     """For every image and every plane id > 0 (ascending, like torch.unique), draw the hypothesis rows exactly as
     mean_normal_ranasc does (main.py:43) and convert them to flat pixel indices.
-    Returns (slots int32 [n,4] = (b, cls, hyp_offset, n_hyp), hyp_pix int32)."""
-    slots, hyp = [], []
+    `dense`: {slot index: n_pts} -- planes known (from a first device pass) to be accepted with n_pts > 300 sparse points on
+    them: plane_offset_ransac then draws np.random.permutation(np.r_[0:n_pts])[0:300] (main.py:78) right after the plane's normal
+    hypotheses and before the next plane's, which is where it is drawn here.
+    Returns (slots int32 [n,4] = (b, cls, hyp_offset, n_hyp), hyp_pix int32, {slot index: offset hypothesis ranks int32 [300]})."""
+    slots, hyp, dense_hyp = [], [], {}
     off = 0
     for b, m in enumerate(id_maps):
         flat = np.asarray(m).reshape(-1)
@@ -38,11 +41,14 @@ def draw_normal_hypotheses(id_maps, rng=np.random):
             n = pix.shape[0]
             idx = rng.permutation(np.r_[0:n])[0:min(NUM_HYPOTHESES, n)]
             hyp.append(pix[idx].astype(np.int32))
+            k = len(slots)
             slots.append((b, int(cls), off, len(idx)))
             off += len(idx)
+            if dense and k in dense:
+                dense_hyp[k] = rng.permutation(np.r_[0:dense[k]])[0:NUM_HYPOTHESES].astype(np.int32)
     slots = np.asarray(slots, dtype=np.int32).reshape(-1, 4)
     hyp = np.concatenate(hyp).astype(np.int32) if hyp else np.zeros(0, dtype=np.int32)
-    return slots, hyp
+    return slots, hyp, dense_hyp
 
 
 def draw_enrichment(nnz, goal, rng=np.random):
@@ -58,13 +64,45 @@ def draw_enrichment(nnz, goal, rng=np.random):
     return sub, np.asarray(offs, dtype=np.int32)
 
 
+class _Upload:
+    """One host->device transfer per call through a reused pinned staging buffer (a pageable source would make the runtime stage and
+    synchronise on every call).  The staging buffer is rewritten only after the previous transfer out of it has completed."""
+
+    def __init__(self):
+        self.host = self.dev = self.event = None
+
+    def __call__(self, arrays, device):
+        n = sum(a.size for a in arrays)
+        if self.host is None or self.host.numel() < n or self.dev.device != device:
+            cap = max(4096, 2 * n)
+            self.host = torch.empty(cap, dtype=torch.int32, pin_memory=True)
+            self.dev = torch.empty(cap, dtype=torch.int32, device=device)
+            self.event = torch.cuda.Event()
+        else:
+            self.event.synchronize()
+        hv = self.host.numpy()
+        offs, o = [], 0
+        for a in arrays:
+            hv[o:o + a.size] = a.reshape(-1)
+            offs.append(self.dev.data_ptr() + 4 * o)
+            o += a.size
+        self.dev[:n].copy_(self.host[:n], non_blocking=True)
+        self.event.record()
+        return offs
+
+
 class PlaneBlock:
-    """Device buffers are cached per (B, HW, n_slots); id maps are re-uploaded only when they change."""
+    """Device buffers persist per (device, B, HW) and grow with the number of plane slots; id maps are re-uploaded only when they
+    change.  `plane_depth()` and `enrich()` of one batch go together: `enrich` is where the host reads the device's counts (the one
+    synchronisation of the path) and where a plane with more than 300 sparse points is resolved (main.py:75-78)."""
 
     def __init__(self):
         self._ids_key = None
         self._ids_dev = None
         self.last_records = None
+        self._bufs = {}
+        self._up1, self._up2 = _Upload(), _Upload()
+        self._ctx = None
 
     def _upload_ids(self, id_maps, device):
         key = tuple(id(m) for m in id_maps)
@@ -75,40 +113,74 @@ class PlaneBlock:
             self._ids_key = key
         return self._ids_dev
 
+    def _buffers(self, dev, B, HW, n_slots):
+        key = (dev, B, HW)
+        b = self._bufs.get(key)
+        if b is None or b["cap"] < n_slots:
+            cap = max(8, n_slots, 2 * (b["cap"] if b else 0))
+            lib = L.lib()
+            b = {"cap": cap,
+                 "mask": torch.empty((cap, HW), dtype=torch.uint8, device=dev),
+                 "counts": torch.empty((cap, L.MAX_HYP), dtype=torch.int32, device=dev),
+                 "rec": torch.zeros((cap, L.PLANE_RECORD), dtype=torch.float32, device=dev),
+                 "scratch": torch.empty(lib.vidc_plane_scratch_bytes(cap, B, HW), dtype=torch.uint8, device=dev),
+                 "di": torch.empty((B, HW), dtype=torch.float32, device=dev),
+                 "info": torch.empty(lib.vidc_plane_info_count(B, HW), dtype=torch.int32, device=dev),
+                 "enriched": torch.empty((B, HW), dtype=torch.float32, device=dev)}
+            self._bufs[key] = b
+        return b
+
     def plane_depth(self, normals, id_maps, sparse_depth, homo, rng=np.random):
         """normals (B,3,H,W), sparse_depth (B,1,H,W), homo (B,H,W,3): GPU fp32.  id_maps: B numpy (H,W) integer maps.
         Returns (di (B,1,H,W), info): `info` is the device int32 buffer vidc_plane_finalize fills (per-chunk candidate
-        counts + the error flag); `enrich()` reads it back -- the single device->host sync of the path."""
+        counts + the number of flagged slots); `enrich()` reads it back -- the single device->host sync of the path.  `di` is
+        a buffer of this object: valid until the next `plane_depth` call."""
         if not normals.is_cuda:
             raise RuntimeError("PlaneBlock runs on the GPU only (no CPU fallback)")
+        self._ctx = {"normals": normals.contiguous(), "ids": id_maps, "ds": sparse_depth.contiguous(), "homo": homo.contiguous(),
+                     "rng": rng, "state0": rng.get_state(), "dense": {}}
+        return self._launch(self._ctx)
+
+    def _launch(self, ctx):
         lib, st = L.lib(), L.current_stream()
+        normals, homo, rng = ctx["normals"], ctx["homo"], ctx["rng"]
         B, _, H, W = normals.shape
         HW = H * W
         dev = normals.device
-        normals, homo = normals.contiguous(), homo.contiguous()
-        ds = sparse_depth.contiguous().view(B, HW)
-        slots, hyp = draw_normal_hypotheses(id_maps, rng)
-        di = ds.clone()
+        ds = ctx["ds"].view(B, HW)
+        slots, hyp, dense_hyp = draw_normal_hypotheses(ctx["ids"], rng, ctx["dense"])
         n_slots = slots.shape[0]
+        bufs = self._buffers(dev, B, HW, n_slots)
+        di = bufs["di"]
+        di.copy_(ds)
         rec = None
         if n_slots > 0:
-            ids = self._upload_ids(id_maps, dev)
-            host = np.concatenate([slots.reshape(-1), hyp]).astype(np.int32)          # one upload: slots then hypotheses
-            host_d = torch.from_numpy(host).to(dev, non_blocking=True)
-            slots_p, hyp_p = host_d.data_ptr(), host_d.data_ptr() + 4 * slots.size
-            mask = torch.empty((n_slots, HW), dtype=torch.uint8, device=dev)
-            counts = torch.empty((n_slots, L.MAX_HYP), dtype=torch.int32, device=dev)
-            rec = torch.empty((n_slots, L.PLANE_RECORD), dtype=torch.float32, device=dev)
-            scratch = torch.empty(lib.vidc_plane_scratch_bytes(n_slots, B, HW), dtype=torch.uint8, device=dev)
+            ids = self._upload_ids(ctx["ids"], dev)
+            arrays = [slots, hyp]
+            if dense_hyp:
+                dh = np.zeros((n_slots, L.MAX_HYP), dtype=np.int32)
+                dn = np.zeros(n_slots, dtype=np.int32)
+                for k, v in dense_hyp.items():
+                    dh[k], dn[k] = v, ctx["dense"][k]
+                arrays += [dh, dn]
+            ptrs = self._up1(arrays, dev)
+            slots_p, hyp_p = ptrs[0], ptrs[1]
+            mask, counts, rec, scratch = bufs["mask"], bufs["counts"], bufs["rec"][:n_slots], bufs["scratch"]
             L.check(lib.vidc_plane_ransac_normal(L.ptr(normals), L.ptr(ids), slots_p, n_slots, hyp_p, HW, L.ptr(mask), L.ptr(counts),
                                                  L.ptr(scratch), st), "plane_ransac_normal")
-            L.check(lib.vidc_plane_offset(L.ptr(homo), L.ptr(ds), slots_p, n_slots, B, L.ptr(mask), L.ptr(counts), HW, L.ptr(scratch),
-                                          L.ptr(rec), st), "plane_offset")
+            if dense_hyp:
+                if bufs.get("dense_dots") is None or bufs["dense_dots"].shape[0] < n_slots:
+                    bufs["dense_dots"] = torch.empty((bufs["cap"], HW), dtype=torch.float32, device=dev)
+                L.check(lib.vidc_plane_offset_dense(L.ptr(homo), L.ptr(ds), slots_p, n_slots, B, L.ptr(mask), L.ptr(counts), HW,
+                                                    L.ptr(scratch), L.ptr(rec), ptrs[2], ptrs[3], L.ptr(bufs["dense_dots"]), st),
+                        "plane_offset_dense")
+            else:
+                L.check(lib.vidc_plane_offset(L.ptr(homo), L.ptr(ds), slots_p, n_slots, B, L.ptr(mask), L.ptr(counts), HW, L.ptr(scratch),
+                                              L.ptr(rec), st), "plane_offset")
             L.check(lib.vidc_plane_project_depth(L.ptr(homo), slots_p, n_slots, L.ptr(mask), HW, L.ptr(scratch), L.ptr(rec), L.ptr(di), st),
                     "plane_project_depth")
-            self._keep = (host_d, scratch, counts)
-        self.last_records, self.last_slots, self.last_mask = rec, slots, (mask if n_slots > 0 else None)
-        info = torch.empty(lib.vidc_plane_info_count(B, HW), dtype=torch.int32, device=dev)
+        self.last_records, self.last_slots, self.last_mask = rec, slots, (bufs["mask"][:n_slots] if n_slots > 0 else None)
+        info = bufs["info"]
         L.check(lib.vidc_plane_finalize(L.ptr(ds), L.ptr(di), B, HW, L.ptr(rec), n_slots, L.ptr(info), st), "plane_finalize")
         return di.view(B, 1, H, W), info
 
@@ -122,9 +194,32 @@ class PlaneBlock:
         self._info_event.record()
         return self._info_pinned, self._info_event
 
-    def enrich(self, sparse_depth, di, info, goal, rng=np.random, info_host=None):
+    def _resolve_dense(self, info_h):
+        """Slow path, taken only when a plane carries more than 300 sparse-depth points (main.py:75-78).  The reference draws the
+        plane-offset hypotheses of such a plane with np.random.permutation between the normal-hypothesis draws of this plane and of
+        the next one, so every later draw moves: rewind the generator to where this batch started, replay the draws with the extra
+        permutation(s) in place and run the plane kernels again -- one plane (in draw order) and one extra host sync per pass,
+        until no slot is flagged.  The draws before the first flagged plane are reproduced bit for bit."""
+        ctx = self._ctx
+        di = info = None
+        while info_h[-1] != 0:
+            rec = self.last_records.cpu().numpy()
+            flagged = [k for k in np.flatnonzero(rec[:, 10] < 0) if k not in ctx["dense"]]
+            if not flagged:
+                raise RuntimeError("plane block: a slot stays flagged after its offset hypotheses were supplied")
+            k = int(flagged[0])
+            ctx["dense"] = {j: n for j, n in ctx["dense"].items() if j < k}       # later planes are re-drawn: their counts may change
+            ctx["dense"][k] = int(rec[k, 7])
+            ctx["rng"].set_state(ctx["state0"])
+            di, info = self._launch(ctx)
+            info_h = info.cpu().numpy()
+        return di, info_h
+
+    def enrich(self, sparse_depth, di, info, goal, rng=np.random, info_host=None, out=None):
         """main.py:285-294.  One device->host read (the reference syncs on torch.nonzero here): per-chunk candidate counts
-        + the flag for planes that would need the >300-point host permutation (main.py:78), which is not done on device."""
+        + the number of planes that need the >300-point host permutation (main.py:78; resolved by `_resolve_dense`).
+        `out`: (B,1,H,W) tensor to write the enriched depth into (every pixel is written); default: a buffer of this object,
+        valid until the next `enrich` call."""
         lib, st = L.lib(), L.current_stream()
         B, _, H, W = sparse_depth.shape
         dev = sparse_depth.device
@@ -135,19 +230,15 @@ class PlaneBlock:
         else:
             info_h = info.cpu().numpy()
         if info_h[-1] != 0:
-            raise NotImplementedError("a plane has more than %d sparse depth points; the subsampled plane-offset RANSAC "
-                                      "(main.py:78) is not implemented on device" % L.MAX_HYP)
+            di, info_h = self._resolve_dense(info_h)
         chunks = info_h[:-1].reshape(B, -1)
         nnz_h = chunks.sum(axis=1)
         sub, offs = draw_enrichment(nnz_h, goal, rng)
-        out = sparse_depth.clone()
+        if out is None:
+            out = self._buffers(dev, B, H * W, 0)["enriched"].view(B, 1, H, W)
         self.last_sub, self.last_nnz = (sub, offs), nnz_h
-        if len(sub):
-            base = (np.cumsum(chunks, axis=1) - chunks).astype(np.int32)
-            host = np.concatenate([sub, offs, base.reshape(-1)]).astype(np.int32)      # one upload
-            host_d = torch.from_numpy(host).to(dev, non_blocking=True)
-            p0 = host_d.data_ptr()
-            L.check(lib.vidc_enrich_scatter(L.ptr(di), p0, p0 + 4 * len(sub), p0 + 4 * (len(sub) + len(offs)), B, H * W, L.ptr(out), st),
-                    "enrich_scatter")
-            self._keep2 = host_d
+        base = (np.cumsum(chunks, axis=1) - chunks).astype(np.int32)
+        p = self._up2([sub if len(sub) else np.zeros(1, dtype=np.int32), offs, base], dev)
+        L.check(lib.vidc_enrich_scatter_from(L.ptr(di), L.ptr(sparse_depth.contiguous()), p[0], p[1], p[2], B, H * W, L.ptr(out), st),
+                "enrich_scatter")
         return out
