@@ -53,6 +53,7 @@ def parse():
                          "+ depth-completion net of frame t-1 as one 4-group program); streams: --in-flight frames on separate HIP "
                          "streams; sequential: back-to-back _call_cnn")
     ap.add_argument("--in-flight", type=int, default=2, help="frames executing concurrently in --mode streams")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the second leg (the same steps with every conv in exact fp32 MFMA arithmetic)")
     return ap.parse_args()
 
 
@@ -94,6 +95,10 @@ TILE_TEMPLATE = {"128x128": (128, 128, 2, 2, 1, 2), "128x64": (128, 64, 2, 2, 1,
                  "128x256": (128, 256, 2, 4, 1, 3)}
 
 
+def kernel_name(tile, prec):
+    return "conv_igemm_f32<%s, %d, %d>" % (", ".join(str(v) for v in TILE_TEMPLATE[tile]), prec, int(tile.endswith("L")))
+
+
 def conv_stack_times(prog, iters=5):
     """Per-op durations of one program execution: HIP events recorded between consecutive ops on the launch stream
     (eager issue, averaged over `iters`), rescaled by (hipGraph replay time of the program / eager time of the program):
@@ -116,19 +121,11 @@ def conv_stack_times(prog, iters=5):
     return out, total, list(zip(prog.op_names, per))
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)     # (one rank per GPU; the modulo only matters when
-    torch.cuda.set_device(local)                                                            #  the launch path is tried on a box with fewer GPUs)
-    dev = torch.device("cuda", local)
-    torch.set_grad_enabled(False)
-    if world > 1:
-        import torch.distributed as dist
-        backend = os.environ.get("VIDC_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" to try the N > 1 path on a 1-GPU box
-        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-
+def measure(args, dev, rank, world, precision):
+    """One leg: builds the pipeline in `precision` mode ("mixed" | "fp32": engine.precision_mode reads VIDC_PRECISION when a program is
+    recorded), runs W untimed + K timed steps bracketed by barrier + synchronize, then (rank 0) the live roofline of what was timed."""
+    import torch.distributed as dist
+    os.environ["VIDC_PRECISION"] = precision
     H, W, B = args.height, args.width, args.batch
     pipe, sn_sd, dc_sd, cc, det_sd = build_pipeline(H, W, dev, args.plane_head)
 
@@ -156,14 +153,15 @@ def main():
 
     def run(n):
         """n steps (= n frames of batch B through the whole hot path); all n outputs are complete on return."""
+        out = None
         if args.mode == "sequential" or (args.mode == "streams" and args.in_flight <= 1):
             for b_ in frames(n):
                 out = pipe._call_cnn(b_)
         elif args.mode == "streams":
             for out in pipe.run_stream(frames(n), in_flight=args.in_flight):
                 pass
-        else:       # n frames = n + 1 pipeline ticks, all inside the timed region
-            for out in pipe.run_interleaved(frames(n)):
+        else:       # n frames = n + 1 pipeline ticks, all inside the timed region; outputs stay in the program's buffer (valid until the
+            for out in pipe.run_interleaved(frames(n), copy_outputs=False):      # next item is requested: documented lifetime)
                 pass
         return out
 
@@ -214,11 +212,11 @@ def main():
             prec = 1 if mode == "bf16x3" else 0
             peak = PEAK_BF16_MFMA_TFLOPS if prec else PEAK_F32_MFMA_TFLOPS
             r = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                 "kernel": "conv_igemm_f32<%s, %d, %d>" % (", ".join(str(v) for v in TILE_TEMPLATE[tile]), prec, int(tile.endswith("L"))),
+                 "kernel": kernel_name(tile, prec),
                  "arithmetic": ("bf16x3: 3 x v_mfma_f32_32x32x16_bf16 per fp32-equivalent product" if prec else "v_mfma_f32_32x32x2_f32"),
                  "launches_per_frame": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2), "gflop_per_launch": round(fl / cnt / 1e9, 3),
                  "ms_per_frame": round(ms, 3),
-                 "traffic_note": "PMC FETCH_SIZE/WRITE_SIZE of this kernel class: profiles/r1_pmc_summary.txt (rocprofv3 --pmc on the whole "
+                 "traffic_note": "PMC FETCH_SIZE/WRITE_SIZE of this kernel class: profiles/ (rocprofv3 --pmc on the whole "
                                  "bench process segfaults in rocprofv3 on this pool, so counters are collected on tools/conv_bench.py)"}
             if prec:
                 r.update(executed_tflops=round(3 * ach, 2), frac_executed=round(3 * ach / peak, 4))
@@ -245,38 +243,69 @@ def main():
                                 "tflops_bf16_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / (conv_ms * 1e-3) / 1e12, 2)},
                  "reference_formulation_gflop_per_frame": round(flops / 1e9, 2),
                  "conv_stack_tflops_reference_formulation": round(flops / (conv_ms * 1e-3) / 1e12, 2),
-                 "precision_mode": os.environ.get("VIDC_PRECISION", "mixed"),
+                 "precision_mode": precision,
                  "other_conv_kernels": [roof(k) for k in ranked[1:4]]}
         for r in extra["other_conv_kernels"]:
             r.pop("traffic_note", None)
-        if args.per_op:
+        if args.per_op and precision == "mixed":
             with open(args.per_op, "w") as f:
                 for name, ops in ((("frame_program" if args.mode == "interleaved" else "surface_normal"), sn_ops), ("depth_completion", dc_ops)):
                     for n, t in ops:
                         f.write("%s\t%.2f\t%s\n" % (name, t * 1e3, n))
+    return {"elapsed": elapsed, "pipe": pipe, "sn_sd": sn_sd, "dc_sd": dc_sd, "cc": cc, "det_sd": det_sd, "roofline": roofline, "extra": extra,
+            "frames": frames, "pre": pre}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)     # (one rank per GPU; the modulo only matters when
+    torch.cuda.set_device(local)                                                            #  the launch path is tried on a box with fewer GPUs)
+    dev = torch.device("cuda", local)
+    torch.set_grad_enabled(False)
+    if world > 1:
+        import torch.distributed as dist
+        backend = os.environ.get("VIDC_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" to try the N > 1 path on a 1-GPU box
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+
+    H, W, B = args.height, args.width, args.batch
+    # Two legs over the same steps, both inside this process (no re-exec): the default mixed mode (bf16x3 MFMA on the layers the
+    # measured table selects) is the headline; the second leg runs EVERY conv in the reference's own arithmetic (fp32 MFMA, exact
+    # fp32 products and sums) and is reported beside it (value_fp32, ms_per_step_fp32, rmse_vs_oracle_fp32, roofline_fp32).
+    main_mode = os.environ.get("VIDC_PRECISION", "mixed")
+    legs = [main_mode] + ([] if (main_mode == "fp32" or args.no_fp32_leg) else ["fp32"])
+    res = {}
+    for mode in legs:
+        res[mode] = measure(args, dev, rank, world, mode)      # (both pipelines stay resident: ~6 GB of 288)
+    lead = res[main_mode]
+    cc = lead["cc"]
 
     # ---- parity of what was just timed: frame 0 of this rank against the CPU oracle (outside the timed region) ----
-    rec = torch.zeros(4, dtype=torch.float64, device=dev)   # frames, seconds, sum sq err, n px
-    rec[0], rec[1] = args.steps * B, elapsed
-    sq_err = n_px = 0.0
+    recs = {m: torch.zeros(4, dtype=torch.float64, device=dev) for m in legs}   # frames, seconds, sum sq err, n px
+    for m in legs:
+        recs[m][0], recs[m][1] = args.steps * B, res[m]["elapsed"]
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import vidc_oracle as O
         intr = O.Intrinsics(202.0, 202.0, cc[0], cc[1])
-        cpu_sn = {k: v.cpu() for k, v in sn_sd.items()}
-        cpu_dc = {k: v.cpu() for k, v in dc_sd.items()}
+        cpu_sn = {k: v.cpu() for k, v in lead["sn_sd"].items()}
+        cpu_dc = {k: v.cpu() for k, v in lead["dc_sd"].items()}
         hb = S.synthetic_batch(B, H, W, 1234, frame0=rank * B)
         if args.plane_head:      # the oracle's own detector (CPU) on the same frames
             from oracle import plane_mask_oracle as PM
-            cpu_det = {k: v.cpu() for k, v in det_sd.items()}
+            cpu_det = {k: v.cpu() for k, v in lead["det_sd"].items()}
             plane_masks = lambda batch: [PM.run_on_tensor(cpu_det, batch["image"][i]) for i in range(B)]
         else:
             plane_masks = lambda batch: [S.plane_id_map(H, W)] * B
         masks = plane_masks(hb)
         ref = O.call_cnn(cpu_sn, cpu_dc, hb, masks, intr, 200, rng=np.random.RandomState(77))   # also the warm-up
-        pipe.rng = np.random.RandomState(77)
-        got = pipe._call_cnn(next(frames(1)) if pre is None else {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in hb.items()}).cpu()
-        sq_err, n_px = float((got - ref).double().pow(2).sum()), float(ref.numel())
+        for m in legs:
+            pipe = res[m]["pipe"]
+            os.environ["VIDC_PRECISION"] = m
+            pipe.rng = np.random.RandomState(77)
+            got = pipe._call_cnn({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in hb.items()}).cpu()
+            recs[m][2], recs[m][3] = float((got - ref).double().pow(2).sum()), float(ref.numel())
         tc = time.perf_counter()
         for j in range(args.cpu_frames if world == 1 else 0):     # the CPU baseline is timed at N=1 only (the other ranks would idle in the gather)
             hbj = S.synthetic_batch(B, H, W, 1234, frame0=(j + 1) * B)
@@ -287,17 +316,16 @@ def main():
                         "sample": "%d frames of the same %dx%d batch-%d workload through oracle/vidc_oracle.call_cnn "
                                   "(torch CPU fp32, %d threads of %d host CPUs)" % (args.cpu_frames, W, H, B,
                                                                                     torch.get_num_threads(), os.cpu_count())}
-    rec[2], rec[3] = sq_err, n_px
 
-    allrec = sharding.gather_records(rec)                 # the only collective: 4 doubles per rank over RCCL/xGMI
+    jobs = {m: sharding.combine(sharding.gather_records(recs[m])) for m in legs}   # the only collective: 4 doubles per rank and leg over RCCL/xGMI
     if rank == 0:
-        job = sharding.combine(allrec)
+        job = jobs[main_mode]
         frames, t_max = job["frames"], job["seconds"]
         line = {
             "metric": "frames/sec", "value": round(frames / t_max, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32" if os.environ.get("VIDC_PRECISION", "mixed") == "fp32" else "f32+bf16x3"), "data": "synthetic",
+            "dtype": ("f32" if main_mode == "fp32" else "f32+bf16x3"), "data": "synthetic",
             "config": {"workload": (("BASELINE configs[1]: synthetic %dx%d RGB + 200-pt sparse depth, batch %d per GPU, plane mask "
                                     "%s; warp + surface-normal net + plane block/enrichment + depth-completion net" % (
                                         W, H, B, "from the Mask R-CNN plane head every frame" if args.plane_head else "fixed")) if not args.source else
@@ -308,9 +336,19 @@ def main():
                        "mode": args.mode, "frames_in_flight": (2 if args.mode == "interleaved" else args.in_flight if args.mode == "streams" else 1),
                        "sharding": "frames round-robin over %d rank(s), no data-path collective" % world},
             "rmse_vs_oracle": (round(job["rmse"], 8) if job["rmse"] is not None else None),
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": lead["roofline"], "cpu_baseline": cpu_baseline,
         }
-        line.update(extra)
+        line.update(lead["extra"])
+        if "fp32" in jobs and main_mode != "fp32":
+            j32, r32 = jobs["fp32"], res["fp32"]
+            line.update({
+                "value_fp32": round(j32["frames"] / j32["seconds"], 3), "ms_per_step_fp32": round(1e3 * j32["seconds"] / args.steps, 4),
+                "dtype_fp32": "f32", "rmse_vs_oracle_fp32": (round(j32["rmse"], 8) if j32["rmse"] is not None else None),
+                "roofline_fp32": r32["roofline"],
+                "fp32_leg": {"what": "the same %d steps with every conv on v_mfma_f32_32x32x2_f32 (exact fp32 products and sums: the reference's "
+                                     "arithmetic), fresh pipeline in this process" % args.steps,
+                             "program_ms": r32["extra"].get("program_ms"), "conv_ms_per_frame": r32["extra"].get("conv_ms_per_frame"),
+                             "conv_stack": r32["extra"].get("conv_stack")}})
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -33,3 +33,23 @@ def seeded_weights():
         return S.seeded_state_dict(shapes, 1234)
 
     return {"sn": build("sn"), "dc": build("dc")}
+
+
+@pytest.fixture(scope="session")
+def detector_weights(golden_dir):
+    """Seeded plane-mask detector state_dict (seed 1234) on CPU, from the committed key/shape/anchor manifest."""
+    import numpy as np
+    import torch
+    from vi_depth_completion_amd import synthetic as S
+    man = np.load(os.path.join(golden_dir, "plane_mask_manifest.npz"))
+    shapes, a = {}, 0
+    for k, s in zip(man["keys"], man["shapes"]):
+        shp = eval(s)
+        if "anchor_generator" in k:
+            shapes[str(k)] = torch.from_numpy(man["anchors"][a:a + shp[0]].copy())
+            a += shp[0]
+        else:
+            shapes[str(k)] = torch.empty(shp, device="meta")
+    return S.seeded_detector_state_dict(shapes, 1234)
+
+

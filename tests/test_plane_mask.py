@@ -14,20 +14,6 @@ torch.set_grad_enabled(False)
 
 
 @pytest.fixture(scope="session")
-def detector_weights(golden_dir):
-    man = np.load(os.path.join(golden_dir, "plane_mask_manifest.npz"))
-    shapes, a = {}, 0
-    for k, s in zip(man["keys"], man["shapes"]):
-        shp = eval(s)
-        if "anchor_generator" in k:
-            shapes[str(k)] = torch.from_numpy(man["anchors"][a:a + shp[0]].copy())
-            a += shp[0]
-        else:
-            shapes[str(k)] = torch.empty(shp, device="meta")
-    return S.seeded_detector_state_dict(shapes, 1234)
-
-
-@pytest.fixture(scope="session")
 def oracle_runs(golden_dir, detector_weights):
     """name -> (golden npz, oracle taps, oracle instance map)"""
     out = {}
@@ -202,15 +188,16 @@ def test_mask_head_paste_and_instance_map_from_oracle_inputs(detector, oracle_ru
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["demo", "synthetic", "demo_000068", "demo_000085"])
 def test_run_on_tensor_end_to_end(detector, oracle_runs, name):
-    """Image -> instance-id map, nothing teacher-forced.  Discrete decisions (top-k order, NMS, the 0.9 / 0.5 / 5 % thresholds) sit on
-    floats that differ by ~1e-3 between the HIP convs and torch-CPU, so single detections may flip; bar: >= 97 % of the pixels carry the
-    reference's id."""
+    """Image -> instance-id map, nothing teacher-forced, on the four golden frames (three demo_dataset frames + the synthetic one):
+    the id map is index work and must be the reference's, pixel for pixel.  (The discrete decisions -- top-k order, NMS, the
+    0.9 / 0.5 / 5 % thresholds -- sit on floats that differ by ~1e-3 between the HIP convs and torch-CPU; on these frames no
+    decision sits that close to its threshold.  If a kernel change ever moves one, the message says how many pixels flipped.)"""
     g, _t, inst = oracle_runs[name]
     got = detector.run_on_tensor(torch.from_numpy(g["image"]))
     assert got.shape == inst.shape and got.dtype == np.uint8
-    agree = float((got == inst).mean())
-    print("instance map agreement %s: %.4f, planes %d vs %d" % (name, agree, got.max(), inst.max()))
-    assert agree >= 0.97
+    flipped = int((got != inst).sum())
+    print("instance map %s: %d of %d pixels differ, planes %d vs %d" % (name, flipped, got.size, got.max(), inst.max()))
+    assert np.array_equal(got, inst), "%d pixels differ from the reference's id map (planes %d vs %d)" % (flipped, got.max(), inst.max())
 
 
 @pytest.mark.gpu
@@ -218,8 +205,8 @@ def test_pipeline_with_plane_head(detector, detector_weights, seeded_weights, go
     """RunDepthCompletion._call_cnn with the plane-mask predictor in the loop (main.py:254, 273) on a real demo frame: the pipeline's
     device-side extraction path (`run_on_batch` on a side stream + one device->host copy of the ids) returns the ids of `run_on_tensor`,
     and the whole path follows the oracle fed with the ORACLE's ids.  When the two id maps are identical the RANSAC / enrichment draws
-    coincide and the depth maps must agree to the north-star bar (RMSE < 1e-3); otherwise (a detection flipped, see
-    test_run_on_tensor_end_to_end) the draws differ and only the id agreement is asserted."""
+    coincide and the depth maps must agree to the north-star bar (RMSE < 1e-3).  On this golden frame the ids are the oracle's
+    exactly (test_run_on_tensor_end_to_end), so both are asserted unconditionally."""
     from oracle import vidc_oracle as O
     from vi_depth_completion_amd.pipeline import DepthCompletionPipeline
     g = np.load(os.path.join(golden_dir, "plane_mask_demo.npz"))
@@ -241,13 +228,13 @@ def test_pipeline_with_plane_head(detector, detector_weights, seeded_weights, go
     got = pipe._call_cnn(batch).cpu()
     ids_or = PM.run_on_tensor(detector_weights, img)
     agree = float((ids_ref == ids_or).mean())
-    assert agree >= 0.97 and torch.isfinite(got).all()
+    assert np.array_equal(ids_ref, ids_or), "%d pixels differ from the oracle's id map" % int((ids_ref != ids_or).sum())
+    assert torch.isfinite(got).all()
     intr = O.Intrinsics(202.0, 202.0, 0.5 * 319.87654, 0.5 * 239.87603)
     ref = O.call_cnn(seeded_weights["sn"], seeded_weights["dc"], batch, [ids_or], intr, 200, rng=np.random.RandomState(5))
     rmse = float((got - ref).pow(2).mean().sqrt())
     print("plane-head pipeline: id agreement %.4f, depth RMSE vs oracle %.3e" % (agree, rmse))
-    if agree == 1.0:
-        assert rmse < 1e-3
+    assert rmse < 1e-3
 
 
 @pytest.mark.gpu
@@ -259,7 +246,9 @@ def test_batch_matches_single_images(detector, golden_dir):
     both = detector.run_on_batch(imgs.cuda()).cpu().numpy()
     for i in range(2):
         one = detector.run_on_tensor(imgs[i])
-        assert float((both[i] == one).mean()) >= 0.995 and both[i].max() == one.max()
+        flipped = int((both[i] != one).sum())
+        print("batch vs single, image %d: %d of %d pixels differ" % (i, flipped, one.size))
+        assert flipped <= 384 and both[i].max() == one.max()      # 0.5 % of 76 800: mask pixels next to the 0.5 iso-line only
     assert both[0].max() >= 2 and both[1].max() >= 2 and not np.array_equal(both[0], both[1])
 
 
