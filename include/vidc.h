@@ -286,6 +286,17 @@ int vidc_depth_metrics(const float* pred, const float* gt, long long n, double* 
 /* SaveDepthsToImage's pixel conversion: (depths * 1000).astype(np.uint32). */
 int vidc_depth_to_mm_u32(const float* depth, uint32_t* mm, long long n, vidc_stream_t stream);
 
+/* NORMAL ERROR STATS (network_run.py:204-214, 389-397).  pred, gt: [B][3][HW] fp32 (normalised here like the reference does),
+ * mask: [B][HW] fp32, valid where > 0.  err [B*HW] receives every pixel's angle error in degrees (fp32; all-ones bits where the mask is
+ * off); stats[8] (fp64) (+)= n, sum e, sum e^2, counts of e < 5, 7.5, 11.25, 22.5, 30.  scratch: vidc_depth_metrics_scratch_bytes(B*HW). */
+int vidc_normal_metrics(const float* pred, const float* gt, const float* mask, int B, int HW, float* err, double* stats,
+                        int accumulate, void* scratch, vidc_stream_t stream);
+
+/* One 16-bit radix digit of the bit patterns of n non-negative floats, counted into hist[65536] (uint32, accumulated: zero it first;
+ * all-ones entries are skipped).  hi_filter < 0: the upper 16 bits; otherwise the lower 16 bits of the values whose upper 16 bits equal
+ * hi_filter.  Two passes select any order statistic (the reference's np.median) exactly; the counts sum over batches and ranks. */
+int vidc_hist_u16(const float* vals, long long n, int hi_filter, uint32_t* hist, vidc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * plane-mask head: the two native kernels it reaches   (plane_mask_detection/maskrcnn_benchmark/csrc)
  * ---------------------------------------------------------------------------------------------- */

@@ -1,9 +1,31 @@
-"""CPU restatement of the reference's depth evaluation figures: TEST INFRASTRUCTURE (imported only by tests/).
-Follows `_network_evaluate` (network_run.py:212-223: mask gt > 0, ratio = max(gt/pred, pred/gt), abs error) and the DEPTH ERROR STATS
-line of `evaluate` (network_run.py:396-403), and `SaveDepthsToImage` (network_run.py:42-50).  Parity unpinned by reference tests (the
-reference has none); the formulas are restated line by line."""
+"""CPU restatement of the reference's evaluation figures: TEST INFRASTRUCTURE (imported only by tests/).
+Follows `_network_evaluate` (network_run.py:198-225: normals -- F.normalize both, clamped dot, acos / pi * 180 on mask > 0; depth -- mask
+gt > 0, ratio = max(gt/pred, pred/gt), abs error), the NORMAL / DEPTH ERROR STATS lines of `evaluate` (network_run.py:389-403) and
+`SaveDepthsToImage` (network_run.py:42-50).
+PINNED against the reference itself: oracle/tools/make_golden_eval.py imports network_run.py, runs `_network_evaluate` and `evaluate` on
+seeded inputs and stores the error arrays and the figures the reference logged (tests/golden/eval_reference.npz;
+tests/test_oracle_golden.py::test_eval_oracle_matches_reference)."""
 import numpy as np
 import torch
+import torch.nn.functional as F
+
+
+def normal_error_array(pred_normals, normals_gt, mask):
+    """network_run.py:204-214.  pred, gt: (B,3,H,W); mask: (B,H,W).  Returns the float32 angle errors (degrees) of the valid pixels."""
+    pred = F.normalize(pred_normals)
+    m = (mask > 0)[:, None, :, :]
+    gt = F.normalize(normals_gt)
+    dot = torch.clamp(torch.sum(pred * gt, dim=1), min=-1.0, max=1.0)
+    ang = torch.acos(dot) / np.pi * 180
+    return ang.numpy()[m[:, 0].numpy() > 0]
+
+
+def normal_error_stats(err):
+    """The NORMAL ERROR STATS figures (network_run.py:389-397) of the concatenated float32 error array."""
+    n = err.shape[0]
+    return {"n": n, "Mean": float(np.average(err)), "Median": float(np.median(err)), "Rmse": float(np.sqrt(np.sum(err * err) / n)),
+            "5deg": 100 * np.sum(err < 5) / n, "7.5deg": 100 * np.sum(err < 7.5) / n, "11.25deg": 100 * np.sum(err < 11.25) / n,
+            "22.5deg": 100 * np.sum(err < 22.5) / n, "30deg": 100 * np.sum(err < 30) / n}
 
 
 def depth_error_arrays(pred, gt):

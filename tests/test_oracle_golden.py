@@ -99,3 +99,24 @@ def test_seeded_weights_are_reproducible():
 
 
 KAT_U24 = [7660493, 12063154, 10042973, 7474002]   # uniform01(1234, "kat", 4) * 2^24
+
+
+def test_eval_oracle_matches_reference(golden_dir):
+    """oracle/eval_oracle.py against what the reference ITSELF produced (oracle/tools/make_golden_eval.py: `_network_evaluate` and the
+    figures `evaluate` logged, network_run.py:198-225, 349-403): the per-batch error arrays are the same torch/numpy calls -> exact;
+    the logged figures carry six decimals."""
+    from oracle import eval_oracle as E
+    f = np.load(os.path.join(golden_dir, "eval_reference.npz"))
+    nerr, ratio, aerr = [], [], []
+    for i in range(2):
+        ne = E.normal_error_array(torch.from_numpy(f["b%d.pred_normal" % i]), torch.from_numpy(f["b%d.gt_normal" % i]), torch.from_numpy(f["b%d.mask" % i]))
+        r, a = E.depth_error_arrays(torch.from_numpy(f["b%d.pred_depth" % i]), torch.from_numpy(f["b%d.gt_depth" % i]))
+        assert np.array_equal(ne, f["b%d.normal_error" % i])
+        assert np.array_equal(r, f["b%d.depth_ratio_error" % i], equal_nan=True) and np.array_equal(a, f["b%d.depth_abs_error" % i])
+        nerr.append(ne); ratio.append(r); aerr.append(a)
+    ns = E.normal_error_stats(np.concatenate(nerr))
+    ds = E.depth_error_stats(np.concatenate(ratio), np.concatenate(aerr))
+    got_n = [ns[k] for k in ("Mean", "Median", "Rmse", "5deg", "7.5deg", "11.25deg", "22.5deg", "30deg")]
+    got_d = [ds[k] for k in ("MAD", "RMSE", "1.05", "1.10", "1.25", "1.25^2", "1.25^3")]
+    assert np.abs(np.array(got_n) - f["normal_figures"]).max() < 2e-5, (got_n, f["normal_figures"])      # %f prints 6 decimals; the
+    assert np.abs(np.array(got_d) - f["depth_figures"]).max() < 2e-6, (got_d, f["depth_figures"])        # reference's fp32 pairwise mean

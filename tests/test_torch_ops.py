@@ -43,6 +43,54 @@ def test_shape_functions():
         assert h.shape == (2, 3, 3) and y.shape == (2, 3, 240, 320)
 
 
+def test_plane_op_shape_functions():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        n = torch.empty(2, 3, 240, 320)
+        ids = torch.empty(2, 240, 320, dtype=torch.uint8)
+        slots = torch.empty(5, 4, dtype=torch.int32)
+        mask, counts, scratch = torch.ops.vidc.plane_ransac_normal(n, ids, slots, torch.empty(1500, dtype=torch.int32))
+        assert mask.shape == (5, 76800) and mask.dtype == torch.uint8 and counts.shape == (5, 300) and counts.dtype == torch.int32
+        rec, sc = torch.ops.vidc.plane_offset(torch.empty(2, 240, 320, 3), torch.empty(2, 1, 240, 320), slots, mask, counts, scratch)
+        assert rec.shape == (5, 16) and sc.shape == scratch.shape
+        pd, rec2 = torch.ops.vidc.plane_project_depth(torch.empty(2, 240, 320, 3), slots, mask, sc, rec, torch.empty(2, 1, 240, 320))
+        assert pd.shape == (2, 1, 240, 320) and rec2.shape == (5, 16)
+        pd2, info = torch.ops.vidc.plane_finalize(torch.empty(2, 1, 240, 320), pd, rec2)
+        assert info.shape == (2 * 300 + 1,) and info.dtype == torch.int32
+        en = torch.ops.vidc.enrich_scatter(pd2, torch.empty(2, 1, 240, 320), torch.empty(7, dtype=torch.int32), torch.empty(3, dtype=torch.int32),
+                                           torch.empty(600, dtype=torch.int32))
+        assert en.shape == (2, 1, 240, 320)
+
+
+@pytest.mark.gpu
+def test_plane_ops_compose_to_the_plane_block():
+    """torch.ops.vidc.plane_* / enrich_scatter chained by hand, with the host draws of plane.draw_*: the same arithmetic as
+    plane.PlaneBlock (bit-identical), which test_hip_parity.py holds against the oracle and the reference's golden frames."""
+    from vi_depth_completion_amd import plane
+    b = S.synthetic_batch(2, 240, 320, 1234, frame0=3)
+    nrm = F.normalize(S.normal01(5, "ops.plane.n", (2, 3, 240, 320)).float() * 0.05 + torch.tensor([0.0, -0.8, -0.6]).view(1, 3, 1, 1), dim=1).cuda()
+    ids_np = [S.plane_id_map(240, 320)] * 2
+    ds, homo = b["sparse_depth"].cuda(), b["homogeneous_coordinates"].cuda()
+    pb = plane.PlaneBlock()
+    di_ref, info_ref = pb.plane_depth(nrm, ids_np, ds, homo, rng=np.random.RandomState(9))
+    di_ref, info_ref = di_ref.clone(), info_ref.clone()
+    en_ref = pb.enrich(ds, di_ref, info_ref, 200, rng=np.random.RandomState(10)).clone()
+    slots, hyp, _ = plane.draw_normal_hypotheses(ids_np, np.random.RandomState(9))
+    ids = torch.from_numpy(np.stack(ids_np)).cuda()
+    slots_d, hyp_d = torch.from_numpy(slots).cuda(), torch.from_numpy(hyp).cuda()
+    mask, counts, scratch = torch.ops.vidc.plane_ransac_normal(nrm, ids, slots_d, hyp_d)
+    rec, scratch = torch.ops.vidc.plane_offset(homo, ds, slots_d, mask, counts, scratch)
+    pd, rec = torch.ops.vidc.plane_project_depth(homo, slots_d, mask, scratch, rec, ds)
+    pd, info = torch.ops.vidc.plane_finalize(ds, pd, rec)
+    assert torch.equal(pd, di_ref) and torch.equal(info, info_ref) and torch.equal(rec, pb.last_records)
+    chunks = info.cpu().numpy()[:-1].reshape(2, -1)
+    sub, offs = plane.draw_enrichment(chunks.sum(axis=1), 200, np.random.RandomState(10))
+    base = (np.cumsum(chunks, axis=1) - chunks).astype(np.int32)
+    en = torch.ops.vidc.enrich_scatter(pd, ds, torch.from_numpy(sub).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(base.reshape(-1)).cuda())
+    assert torch.equal(en, en_ref)
+    assert int((en != ds).sum()) > 100
+
+
 @pytest.mark.gpu
 def test_warp_ops_match_oracle():
     b = S.synthetic_batch(2, 240, 320, 1234)

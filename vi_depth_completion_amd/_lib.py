@@ -96,6 +96,8 @@ SIGNATURES = {
     "vidc_depth_metrics_scratch_bytes": (C.c_size_t, [C.c_longlong]),
     "vidc_depth_metrics": (C.c_int, [_vp, _vp, C.c_longlong, _vp, _i, _vp, _vp]),
     "vidc_depth_to_mm_u32": (C.c_int, [_vp, _vp, C.c_longlong, _vp]),
+    "vidc_normal_metrics": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "vidc_hist_u16": (C.c_int, [_vp, C.c_longlong, _i, _vp, _vp]),
     "vidc_nms_scratch_bytes": (C.c_size_t, [_i]),
     "vidc_nms": (C.c_int, [_vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "vidc_nms_segmented_scratch_bytes": (C.c_size_t, [_i, _i]),

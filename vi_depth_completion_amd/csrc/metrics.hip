@@ -70,7 +70,82 @@ __global__ void __launch_bounds__(MT) depth_to_mm_kernel(const float* __restrict
     mm[i] = v >= 4294967296.0f ? 0xFFFFFFFFu : (v > 0.f ? (uint32_t)v : 0u);      // the path's depths are >= 0 (final ReLU)
 }
 
+// ---- normal-error statistics (network_run.py:204-214 + the NORMAL ERROR STATS line of evaluate(), :389-397) -------------------------
+// Per valid pixel (mask > 0): angle = acos(clamp(<normalize(pred), normalize(gt)>, -1, 1)) / pi * 180 in fp32, like the reference's
+// tensors.  The 8 sufficient statistics of the logged figures except the median -- n, sum e, sum e^2, counts below 5 / 7.5 / 11.25 /
+// 22.5 / 30 degrees -- are reduced exactly like the depth ones; the angle of every pixel is also written out (invalid pixels get
+// the all-ones bit pattern) so that the EXACT median can be selected later by two radix-histogram passes (hist_u16_kernel).
+__global__ void __launch_bounds__(MT)
+normal_metrics_partial_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ mask, int HW,
+                              long long n, int per, float* __restrict__ err, double* __restrict__ partial) {
+    __shared__ double red[4];
+    const float thr[5] = {5.0f, 7.5f, 11.25f, 22.5f, 30.0f};
+    double s[MSTATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long base = (long long)blockIdx.x * MT * per;
+    for (int k = 0; k < per; ++k) {
+        const long long i = base + (long long)k * MT + threadIdx.x;      // pixel index over B*HW
+        if (i >= n) break;
+        const long long b = i / HW, p = i - b * HW;
+        float e = __uint_as_float(0xFFFFFFFFu);
+        if (mask[i] > 0.f) {
+            const float* pp = pred + b * 3 * HW + p;
+            const float* gp = gt + b * 3 * HW + p;
+            const float p0 = pp[0], p1 = pp[HW], p2 = pp[2 * (long long)HW], g0 = gp[0], g1 = gp[HW], g2 = gp[2 * (long long)HW];
+            const float pn = fmaxf(sqrtf(p0 * p0 + p1 * p1 + p2 * p2), 1e-12f), gn = fmaxf(sqrtf(g0 * g0 + g1 * g1 + g2 * g2), 1e-12f);   // F.normalize
+            float d = (p0 / pn) * (g0 / gn) + (p1 / pn) * (g1 / gn) + (p2 / pn) * (g2 / gn);
+            d = fminf(fmaxf(d, -1.0f), 1.0f);
+            e = acosf(d) / 3.14159274f * 180.0f;
+            s[0] += 1.0;
+            s[1] += (double)e;
+            s[2] += (double)e * (double)e;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) s[3 + t] += (e < thr[t]) ? 1.0 : 0.0;
+        }
+        err[i] = e;
+    }
+#pragma unroll
+    for (int q = 0; q < MSTATS; ++q) {
+        const double v = wg_sum(s[q], red);
+        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * MSTATS + q] = v;
+    }
+}
+
+// hist[65536] += counts of a 16-bit digit of the values' bit patterns: hi_filter < 0: the upper 16 bits; else the lower 16 bits of
+// the values whose upper 16 bits equal hi_filter.  Non-negative floats order like their bit patterns, so two passes select any order
+// statistic exactly; counts are integers, hence mergeable over batches and ranks in any order.  The all-ones sentinel is skipped.
+__global__ void __launch_bounds__(MT) hist_u16_kernel(const float* __restrict__ vals, long long n, int hi_filter, unsigned* __restrict__ hist) {
+    const long long i = (long long)blockIdx.x * MT + threadIdx.x;
+    if (i >= n) return;
+    const unsigned u = __float_as_uint(vals[i]);
+    if (u == 0xFFFFFFFFu) return;
+    if (hi_filter < 0) atomicAdd(&hist[u >> 16], 1u);
+    else if ((int)(u >> 16) == hi_filter) atomicAdd(&hist[u & 0xFFFFu], 1u);
+}
+
 }  // namespace
+
+extern "C" int vidc_normal_metrics(const float* pred, const float* gt, const float* mask, int B, int HW, float* err, double* stats,
+                                   int accumulate, void* scratch, vidc_stream_t stream) {
+    VIDC_REQUIRE(pred && gt && mask && err && stats && scratch, VIDC_ERR_NULL, "vidc_normal_metrics: null pointer");
+    VIDC_REQUIRE(B > 0 && HW > 0, VIDC_ERR_SHAPE, "vidc_normal_metrics: bad shape");
+    const long long n = (long long)B * HW;
+    const int per = 16;
+    const int blocks = (int)((n + (long long)MT * per - 1) / ((long long)MT * per));
+    hipStream_t st = vidc::as_stream(stream);
+    hipLaunchKernelGGL(normal_metrics_partial_kernel, dim3(blocks), dim3(MT), 0, st, pred, gt, mask, HW, n, per, err, reinterpret_cast<double*>(scratch));
+    VIDC_CHECK_LAUNCH("normal_metrics_partial_kernel");
+    hipLaunchKernelGGL(depth_metrics_final_kernel, dim3(1), dim3(MT), 0, st, reinterpret_cast<const double*>(scratch), blocks, stats, accumulate);
+    VIDC_CHECK_LAUNCH("depth_metrics_final_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_hist_u16(const float* vals, long long n, int hi_filter, uint32_t* hist, vidc_stream_t stream) {
+    VIDC_REQUIRE(vals && hist, VIDC_ERR_NULL, "vidc_hist_u16: null pointer");
+    VIDC_REQUIRE(n > 0 && hi_filter < 65536, VIDC_ERR_SHAPE, "vidc_hist_u16: bad arguments");
+    hipLaunchKernelGGL(hist_u16_kernel, dim3((unsigned)((n + MT - 1) / MT)), dim3(MT), 0, vidc::as_stream(stream), vals, n, hi_filter, hist);
+    VIDC_CHECK_LAUNCH("hist_u16_kernel");
+    return VIDC_OK;
+}
 
 extern "C" size_t vidc_depth_metrics_scratch_bytes(long long n) {
     const long long blocks = (n + (long long)MT * 16 - 1) / ((long long)MT * 16);
