@@ -382,9 +382,25 @@ int vidc_instance_map(const uint8_t* pasted, const float* det_scores, const int3
  * programs: a whole network (or the whole frame) as one native call / one hipGraph
  * ---------------------------------------------------------------------------------------------- */
 
+/* ------------------------------------------------------------------------------------------------
+ * Persistent conv chains.  A run of consecutive small fused convs (vidc_conv_desc, same `groups` <= 8 and precision; e.g. the 22
+ * identical Bottlenecks of torchvision ResNet-101 layer3, networks/surface_normal.py:27-35) as ONE launch: group g runs entirely on
+ * XCD g, layers hand over through that XCD's L2 with per-XCD item counters (no grid barrier), and the weights of the next item
+ * stream in while the previous layer finishes.  Same arithmetic as vidc_conv2d_bn_act with tile VIDC_TILE_64x64_K2_D4, splitk 1
+ * (bit-identical).  descs[i] may read what descs[j < i] wrote; inputs produced outside the chain must be complete before the launch.
+ * create() uploads the layer table (synchronous); run() enqueues a counter reset + the kernel (capturable); status() synchronises
+ * and returns in *failed_layer the layer whose dependency wait timed out, or -1. */
+typedef struct vidc_chain vidc_chain;
+int vidc_chain_create(const vidc_conv_desc* descs, int n, vidc_chain** out);
+int vidc_chain_run(vidc_chain* chain, vidc_stream_t stream);
+int vidc_chain_status(vidc_chain* chain, int* failed_layer);
+int vidc_chain_info(const vidc_chain* chain, int* n_layers, int* total_items);
+int vidc_chain_destroy(vidc_chain* chain);
+
 enum vidc_op_kind { VIDC_OP_CONV = 1, VIDC_OP_STEM = 2, VIDC_OP_MAXPOOL = 3, VIDC_OP_UPSAMPLE = 4, VIDC_OP_HEAD = 5,
                     VIDC_OP_WARP_PARAMS = 6, VIDC_OP_WARP_FWD = 7, VIDC_OP_WARP_INV = 8, VIDC_OP_COPY = 9, VIDC_OP_SPLIT = 10,
-                    VIDC_OP_AVGPOOL = 11, VIDC_OP_NORMALIZE = 12, VIDC_OP_DET_IM2COL = 13, VIDC_OP_NEAREST2X = 14 };
+                    VIDC_OP_AVGPOOL = 11, VIDC_OP_NORMALIZE = 12, VIDC_OP_DET_IM2COL = 13, VIDC_OP_NEAREST2X = 14,
+                    VIDC_OP_CHAIN = 15 /* g.p[0] = vidc_chain* */ };
 
 typedef struct vidc_generic_args {   /* arguments of the non-conv launchers, in declaration order */
     const void* p[6];

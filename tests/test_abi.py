@@ -107,6 +107,22 @@ def test_rng_draws_follow_reference_order():
     assert s2.shape == (0, 4) and h2.size == 0
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _no_chains():
+    old = os.environ.get("VIDC_CHAIN")
+    os.environ["VIDC_CHAIN"] = "0"
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop("VIDC_CHAIN", None)
+        else:
+            os.environ["VIDC_CHAIN"] = old
+
+
 @pytest.fixture(scope="module")
 def recorded_programs(lib):
     """Both networks recorded on CPU in dry-run mode (no HIP calls): exercises all host-side program logic."""
@@ -116,7 +132,8 @@ def recorded_programs(lib):
     from vi_depth_completion_amd.networks.surface_normal import SurfaceNormalPrediction
     sn = SurfaceNormalPrediction(fc_img=np.array([202.0, 202.0])).eval()
     dc = ModifiedFPN().eval()
-    return sn.build_program(1, torch.device("cpu"), dry_run=True), dc.build_program(1, 240, 320, torch.device("cpu"), dry_run=True)
+    with _no_chains():        # the recording itself is under test here; the chain fusion pass has tests/test_chain.py
+        return sn.build_program(1, torch.device("cpu"), dry_run=True), dc.build_program(1, 240, 320, torch.device("cpu"), dry_run=True)
 
 
 @pytest.fixture(scope="module")
@@ -130,7 +147,8 @@ def recorded_frame_program(lib):
     from vi_depth_completion_amd.pipeline import build_frame_program
     sn = SurfaceNormalPrediction(fc_img=np.array([202.0, 202.0])).eval()
     dc = ModifiedFPN().eval()
-    return build_frame_program(sn, dc, 1, 240, 320, torch.device("cpu"), dry_run=True)
+    with _no_chains():
+        return build_frame_program(sn, dc, 1, 240, 320, torch.device("cpu"), dry_run=True)
 
 
 def test_frame_program_structure(recorded_frame_program, recorded_programs):

@@ -15,6 +15,7 @@
 //   the last one to arrive (ticket counter per tile) sums them in slice order and runs the same epilogue -- no second launch.  `groups` (blockIdx.z) runs the three ModifiedFPN pyramids in one launch.
 #include "common.h"
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -122,11 +123,15 @@ __device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
 // the compute waves' critical path (in-kernel stamps, M=320 layer-3 shapes: 853 clk per stage, 521 clk without the refills,
 // 829 clk without the MFMAs).  One loader and one compute wave share each SIMD; the per-stage s_barrier is the only hand-off:
 // a loader passes it after ITS loads of stage s have landed (its own vmcnt), a compute wave after it has read stage s-1.
-template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC, int SPEC>
-__global__ void __launch_bounds__(64 * WMW * WNW * WKW * (SPEC ? 2 : 1))
-__attribute__((amdgpu_waves_per_eu((BM == 128 && BN == 128 && NS == 2 && !SPEC) ? 2 : 1)))
-conv_igemm_f32(const ConvArgs a) {
+// CHAIN = true: the tile runs inside the persistent chain kernel (conv_chain_kernel below), where the activations it reads were
+// written by OTHER workgroups of the same launch: `dep()` (a workgroup-wide wait) is called after the weight prologue is in flight
+// and before the first activation / residual access, and those accesses bypass the per-CU L1 (sc1), which another CU's stores never
+// refresh.  CHAIN = false: the stand-alone kernel, `dep` is a no-op.
+template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC, int SPEC, bool CHAIN, typename Dep>
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const int tile_m, const int tile_n, const int kz, float* smem,
+                                          Dep&& dep) {
     constexpr int NW = WMW * WNW * WKW, WPK = WMW * WNW;
+    constexpr int A_AUX = CHAIN ? 16 : 0;      // cache policy of the activation DMAs: sc1 = served by L2, never by a stale L1 line
     constexpr int TM = BM / (32 * WMW), TN = BN / (32 * WNW);
     constexpr int A_J = (BM / 8) / WPK, B_J = (BN / 8) / WPK;      // DMA instructions per wave per stage
     constexpr int LPS = A_J + B_J;
@@ -134,7 +139,6 @@ conv_igemm_f32(const ConvArgs a) {
     static_assert((BM / 8) % WPK == 0 && (BN / 8) % WPK == 0, "tile rows must split evenly over the waves");
     static_assert(NS >= 2 && (NS - 2) * LPS <= 63, "vmcnt is a 6-bit counter");
     static_assert((WKW - 1) * WPK * TM * TN * 1024 <= NS * STAGE, "K-reduction scratch must fit in the ring");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef VIDC_CONV_TIMING
     // debug build only: per-workgroup phase stamps (shader clock + 100 MHz wall clock) into a.ws
     long long* dbg = reinterpret_cast<long long*>(a.ws) + (size_t)blockIdx.x * 16;
@@ -152,22 +156,6 @@ conv_igemm_f32(const ConvArgs a) {
     const int wave = is_loader ? wave_all - NW : wave_all;      // role-local index: loader l feeds what compute wave l would load
     const int kq = wave / WPK, wq = wave - kq * WPK;
     const int wm = wq / WNW, wn = wq - wm * WNW;
-    // XCD-aware workgroup mapping (guide T1).  Workgroup w runs on XCD w % 8 (observed, never relied on for
-    // correctness: the map below is a bijection).  Each XCD gets a CONTIGUOUS range of the work list ordered
-    // (group, n-tile, k-split, m-tile), so one (HBM-cold) weight tile is fetched by one XCD's L2 instead of by all
-    // eight; the small, just-produced activation tiles are what gets shared across XCDs.
-    int g, tile_n, tile_m, kz;
-    {
-        const int W = gridDim.x, w = blockIdx.x;
-        const int xcd = w & 7, j = w >> 3, q = W >> 3, r = W & 7;
-        const unsigned v0 = (unsigned)(xcd * q + min(xcd, r) + j);      // XCDs 0..r-1 own q+1 items, the rest q
-        const unsigned v1 = fast_div(v0, a.dv_tiles_m);
-        const unsigned v2 = fast_div(v1, a.dv_splitk);
-        tile_m = (int)(v0 - v1 * a.tiles_m);
-        kz = (int)(v1 - v2 * a.splitk);
-        g = (int)fast_div(v2, a.dv_tiles_n);
-        tile_n = (int)(v2 - g * a.tiles_n);
-    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     VIDC_STAMP(8);      // kernel arguments arrived, work item decoded
     const int units = a.ksteps;                                       // K in units of 32 floats
@@ -275,7 +263,7 @@ conv_igemm_f32(const ConvArgs a) {
         for (int j = 0; j < A_J; ++j) {
             const unsigned voff = (a_taps[j] & tapbit) ? (unsigned)(a_off[j] + tap_off) : OOB;
             float* dst = sbase + (kq * BM + (j * WPK + wq) * 8) * BK;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void_t*)dst, 16, (int)voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void_t*)dst, 16, (int)voff, 0, 0, A_AUX);
         }
     };
     auto issue_b = [&](int slot) {
@@ -315,6 +303,7 @@ conv_igemm_f32(const ConvArgs a) {
         if (a.flags & VIDC_AFFINE2) { e_s2[j] = a.scale2[ni]; e_b2[j] = a.shift2[ni]; }
     }
     VIDC_STAMP(11);     // scale/shift loads issued
+    dep();              // chain: everything this tile reads from earlier layers is complete (the weight prologue is already in flight)
     float e_res[TM][TN][16];
     if ((a.flags & VIDC_RESIDUAL) && a.splitk == 1 && !is_loader) {    // uniform branch; indices clamped so every load is unconditional
 #pragma unroll
@@ -325,7 +314,8 @@ conv_igemm_f32(const ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = min(m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.M - 1);
-                    e_res[i][j][r] = res[(size_t)m * a.ldr + n];
+                    if constexpr (CHAIN) e_res[i][j][r] = __hip_atomic_load(res + (size_t)m * a.ldr + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else e_res[i][j][r] = res[(size_t)m * a.ldr + n];
                 }
             }
     } else {
@@ -516,7 +506,7 @@ conv_igemm_f32(const ConvArgs a) {
     //      counter (head of the workspace; device-scope atomic), and the LAST one to arrive sums the splitk partials in slice
     //      order 0..splitk-1 (its own included, re-read from the workspace) and runs the normal epilogue below.  The sum does not
     //      depend on the arrival order, so the result is bit-reproducible; the counter is left at zero for the next launch.
-    if (a.splitk > 1) {
+    if (!CHAIN && a.splitk > 1) {
         float* part = a.ws + VIDC_SPLITK_COUNTERS;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -607,7 +597,8 @@ conv_igemm_f32(const ConvArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int dm = (r & 3) + 8 * (r >> 2);
-                        old[r] = (FULL || mrow + dm < a.M) ? yg[o0 + (unsigned)(dm * a.ldy)] : 0.f;
+                        if constexpr (CHAIN) old[r] = (FULL || mrow + dm < a.M) ? __hip_atomic_load(yg + o0 + (unsigned)(dm * a.ldy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                        else old[r] = (FULL || mrow + dm < a.M) ? yg[o0 + (unsigned)(dm * a.ldy)] : 0.f;
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v[r] += old[r];
@@ -633,6 +624,106 @@ conv_igemm_f32(const ConvArgs a) {
 #ifdef VIDC_CONV_TIMING
     if (threadIdx.x == 0) dbg[7] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC, int SPEC>
+__global__ void __launch_bounds__(64 * WMW * WNW * WKW * (SPEC ? 2 : 1))
+__attribute__((amdgpu_waves_per_eu((BM == 128 && BN == 128 && NS == 2 && !SPEC) ? 2 : 1)))
+conv_igemm_f32(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // XCD-aware workgroup mapping (guide T1).  Workgroup w runs on XCD w % 8 (observed, never relied on for
+    // correctness: the map below is a bijection).  Each XCD gets a CONTIGUOUS range of the work list ordered
+    // (group, n-tile, k-split, m-tile), so one (HBM-cold) weight tile is fetched by one XCD's L2 instead of by all
+    // eight; the small, just-produced activation tiles are what gets shared across XCDs.
+    int g, tile_n, tile_m, kz;
+    {
+        const int W = gridDim.x, w = blockIdx.x;
+        const int xcd = w & 7, j = w >> 3, q = W >> 3, r = W & 7;
+        const unsigned v0 = (unsigned)(xcd * q + min(xcd, r) + j);      // XCDs 0..r-1 own q+1 items, the rest q
+        const unsigned v1 = fast_div(v0, a.dv_tiles_m);
+        const unsigned v2 = fast_div(v1, a.dv_splitk);
+        tile_m = (int)(v0 - v1 * a.tiles_m);
+        kz = (int)(v1 - v2 * a.splitk);
+        g = (int)fast_div(v2, a.dv_tiles_n);
+        tile_n = (int)(v2 - g * a.tiles_n);
+    }
+    conv_tile<BM, BN, WMW, WNW, WKW, NS, PREC, SPEC, false>(a, g, tile_m, tile_n, kz, smem, [] {});
+}
+
+// ---- persistent chain kernel ------------------------------------------------------------------------------------------------------
+// A run of consecutive small convs (the 22 identical bottlenecks of ResNet-101 layer3 at M = B*300..320: 66 launches of ~15 us whose
+// time is launch/drain, prologue and HBM-cold weight latency, not arithmetic) executed by ONE launch.
+//
+// * Group g (one of the <= 8 pyramids of the grouped launch) runs ENTIRELY on XCD g: a workgroup reads the XCD it was placed on
+//   (HW_REG_XCC_ID) and serves that group.  All hand-offs of a group therefore stay inside one XCD's L2: producers store plainly
+//   (write-through L1 -> the shared L2) and drain (s_waitcnt vmcnt(0)); consumers read activations with sc1 loads (L2-served: a CU's
+//   L1 is never refreshed by another CU's stores); the counters are device atomics.  No grid-wide barrier, no cross-XCD fence.
+// * Work = the (layer, n-tile, m-tile) items of the group in layer order, CLAIMED dynamically from a per-XCD counter, so nothing
+//   depends on how many workgroups the dispatcher put on an XCD or on all of them being resident (a lone workgroup would walk the
+//   whole chain by itself).  An item of layer l may start when the XCD's `done` counter has reached the first item index of layer l
+//   (all earlier layers complete).  Claims are in order and every claimed item completes, so the wait always ends.
+// * The weight tiles of the claimed item are requested (LDS-DMA prologue) BEFORE that wait: the HBM-cold latency of layer l+1's
+//   weights hides under the tail of layer l, which separate launches cannot do.
+// * Every spin is bounded: on time-out the workgroup records an error code and leaves; the host reads it (vidc_chain_status).
+struct ChainLayer {
+    ConvArgs a;
+    int item_begin;      // index of this layer's first item in the group's item list
+    int pad_[3];
+};
+struct ChainArgs {
+    const ChainLayer* layers;
+    unsigned* state;     // [0..7] next item per XCD, [8..15] items done per XCD, [16] error code, [17] workgroups seen
+    int n_layers, total_items, groups, spin_limit;
+};
+
+template <int NS, int PREC>
+__global__ void __launch_bounds__(512) conv_chain_kernel(const ChainArgs c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ unsigned s_q;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;      // HW_REG_XCC_ID[3:0]
+    if ((int)xcc >= c.groups) return;               // this XCD serves no group of the launch
+    const int g = (int)xcc;
+    unsigned* next = c.state + xcc;
+    unsigned* done = c.state + 8 + xcc;
+    const int tid = threadIdx.x;
+    int l = 0;
+    if (tid == 0) s_q = atomicAdd(next, 1u);
+    __syncthreads();
+    unsigned q = s_q;
+    while (q < (unsigned)c.total_items) {
+        while (l + 1 < c.n_layers && q >= (unsigned)c.layers[l + 1].item_begin) ++l;     // uniform
+        const ChainLayer* L = c.layers + l;
+        const int item = (int)q - L->item_begin;
+        const int tiles_m = L->a.tiles_m;
+        const int tile_n = item / tiles_m, tile_m = item - tile_n * tiles_m;
+        const unsigned need = (unsigned)L->item_begin;
+        unsigned q_next = 0;
+        if (tid == 0) q_next = atomicAdd(next, 1u);          // the next claim travels while this item runs
+        bool failed = false;
+        auto dep = [&]() {
+            if (tid < 64) {                                  // one wave polls one word, relaxed, L2-served; bounded
+                int spins = 0;
+                while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > c.spin_limit || ((spins & 1023) == 0 && __hip_atomic_load(c.state + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        failed = true;                       // timed out, or another workgroup did: give up (the host reads state[16])
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+        };
+        conv_tile<64, 64, 2, 2, 2, NS, PREC, 0, true>(L->a, g, tile_m, tile_n, 0, smem, dep);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its outputs have reached the XCD's L2
+        __syncthreads();                                      // ... and every wave is done with the LDS ring
+        if (tid == 0) {
+            if (failed) atomicMax(c.state + 16, 1u + (unsigned)l);
+            atomicAdd(done, 1u);
+            s_q = failed ? 0xFFFFFFFFu : q_next;             // after a time-out this workgroup leaves
+        }
+        __syncthreads();
+        q = s_q;
+    }
 }
 
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
@@ -780,6 +871,32 @@ int validate(const vidc_conv_desc* d) {
     return VIDC_OK;
 }
 
+// Kernel arguments of one conv for tile `dd.tile` / `dd.splitk` (both already chosen).
+int make_args(const vidc_conv_desc& dd, ConvArgs& a) {
+    a.x = dd.x; a.w = dd.w; a.y = dd.y; a.scale1 = dd.scale1; a.shift1 = dd.shift1; a.scale2 = dd.scale2; a.shift2 = dd.shift2;
+    a.residual = dd.residual; a.ws = dd.workspace; a.y_split = reinterpret_cast<unsigned short*>(dd.y_split);
+    a.B = dd.B; a.H = dd.H; a.W = dd.W; a.Cin = dd.Cin; a.ldx = dd.ldx; a.Ho = dd.Ho; a.Wo = dd.Wo; a.Cout = dd.Cout;
+    a.ldy = dd.ldy; a.ldr = dd.ldr; a.KH = dd.KH; a.KW = dd.KW; a.stride = dd.stride; a.pad = dd.pad; a.flags = dd.flags;
+    a.groups = dd.groups; a.dil = dd.dilation > 1 ? dd.dilation : 1; a.x_gs = dd.x_gs; a.w_gs = dd.w_gs; a.y_gs = dd.y_gs; a.r_gs = dd.r_gs; a.p_gs = dd.p_gs;
+    a.M = dd.B * dd.Ho * dd.Wo; a.K = dd.KH * dd.KW * dd.Cin; a.ksteps = a.K / BK;
+    a.splitk = dd.splitk;
+    const TileInfo ti = kTiles[dd.tile];
+    a.tiles_m = (a.M + ti.bm - 1) / ti.bm;
+    a.tiles_n = (a.Cout + ti.bn - 1) / ti.bn;
+    {
+        const int stages = (a.ksteps + ti.wkw - 1) / ti.wkw;
+        if (a.splitk > stages) a.splitk = stages;
+        if ((long long)a.tiles_m * a.tiles_n * a.groups > VIDC_SPLITK_COUNTERS) a.splitk = 1;    // one ticket counter per output tile
+    }
+    fast_div_init((unsigned)a.tiles_m, a.dv_tiles_m);
+    fast_div_init((unsigned)a.splitk, a.dv_splitk);
+    fast_div_init((unsigned)a.tiles_n, a.dv_tiles_n);
+    fast_div_init((unsigned)(a.KH * a.KW), a.dv_ntaps);
+    fast_div_init((unsigned)a.KW, a.dv_kw);
+    VIDC_REQUIRE((long long)a.tiles_m * a.tiles_n * a.splitk * a.groups < (1ll << 31), VIDC_ERR_SHAPE, "conv: grid too large");
+    return VIDC_OK;
+}
+
 }  // namespace
 
 extern "C" int vidc_conv2d_plan(vidc_conv_desc* d) {
@@ -830,27 +947,8 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         dd.splitk = dd.workspace ? sk : 1;      // the caller sized the workspace for ITS splitk: the planner only picks the tile here
     }
     ConvArgs a;
-    a.x = dd.x; a.w = dd.w; a.y = dd.y; a.scale1 = dd.scale1; a.shift1 = dd.shift1; a.scale2 = dd.scale2; a.shift2 = dd.shift2;
-    a.residual = dd.residual; a.ws = dd.workspace; a.y_split = reinterpret_cast<unsigned short*>(dd.y_split);
-    a.B = dd.B; a.H = dd.H; a.W = dd.W; a.Cin = dd.Cin; a.ldx = dd.ldx; a.Ho = dd.Ho; a.Wo = dd.Wo; a.Cout = dd.Cout;
-    a.ldy = dd.ldy; a.ldr = dd.ldr; a.KH = dd.KH; a.KW = dd.KW; a.stride = dd.stride; a.pad = dd.pad; a.flags = dd.flags;
-    a.groups = dd.groups; a.dil = dd.dilation > 1 ? dd.dilation : 1; a.x_gs = dd.x_gs; a.w_gs = dd.w_gs; a.y_gs = dd.y_gs; a.r_gs = dd.r_gs; a.p_gs = dd.p_gs;
-    a.M = dd.B * dd.Ho * dd.Wo; a.K = dd.KH * dd.KW * dd.Cin; a.ksteps = a.K / BK;
-    a.splitk = dd.splitk;
-    const TileInfo ti = kTiles[dd.tile];
-    a.tiles_m = (a.M + ti.bm - 1) / ti.bm;
-    a.tiles_n = (a.Cout + ti.bn - 1) / ti.bn;
-    {
-        const int stages = (a.ksteps + ti.wkw - 1) / ti.wkw;
-        if (a.splitk > stages) a.splitk = stages;
-        if ((long long)a.tiles_m * a.tiles_n * a.groups > VIDC_SPLITK_COUNTERS) a.splitk = 1;    // one ticket counter per output tile
-    }
-    fast_div_init((unsigned)a.tiles_m, a.dv_tiles_m);
-    fast_div_init((unsigned)a.splitk, a.dv_splitk);
-    fast_div_init((unsigned)a.tiles_n, a.dv_tiles_n);
-    fast_div_init((unsigned)(a.KH * a.KW), a.dv_ntaps);
-    fast_div_init((unsigned)a.KW, a.dv_kw);
-    VIDC_REQUIRE((long long)a.tiles_m * a.tiles_n * a.splitk * a.groups < (1ll << 31), VIDC_ERR_SHAPE, "conv: grid too large");
+    rc = make_args(dd, a);
+    if (rc != VIDC_OK) return rc;
     hipStream_t st = vidc::as_stream(stream);
     switch (dd.tile) {
         case VIDC_TILE_128x128:  rc = launch_tile<128, 128, 2, 2, 1, 2>(a, st, dd.precision); break;
@@ -883,6 +981,106 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
     return rc;
+}
+
+// ---- persistent chain: host side ----------------------------------------------------------------------------------------------------
+struct vidc_chain {
+    ChainLayer* d_layers = nullptr;
+    unsigned* d_state = nullptr;
+    int n_layers = 0, total_items = 0, groups = 0, precision = 0, n_cu = 256;
+};
+
+namespace {
+constexpr int kChainNS = 4;
+constexpr int kChainTile = VIDC_TILE_64x64_K2_D4;
+constexpr size_t kChainLds = (size_t)kChainNS * (64 + 64) * BK * 2 * sizeof(float);
+constexpr int kChainStateWords = 32;
+
+template <int PREC>
+int chain_launch(const vidc_chain* ch, hipStream_t st) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    VIDC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        VIDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_chain_kernel<kChainNS, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kChainLds));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    ChainArgs c;
+    c.layers = ch->d_layers; c.state = ch->d_state; c.n_layers = ch->n_layers; c.total_items = ch->total_items; c.groups = ch->groups;
+    c.spin_limit = 1000000;
+    // one workgroup per CU (128 KB of LDS each); the groups' XCDs use theirs, the others leave at once
+    hipLaunchKernelGGL((conv_chain_kernel<kChainNS, PREC>), dim3(ch->n_cu), dim3(512), kChainLds, st, c);
+    VIDC_CHECK_LAUNCH("conv_chain_kernel");
+    return VIDC_OK;
+}
+}  // namespace
+
+extern "C" int vidc_chain_create(const vidc_conv_desc* descs, int n, vidc_chain** out) {
+    VIDC_REQUIRE(descs && out, VIDC_ERR_NULL, "vidc_chain_create: null pointer");
+    VIDC_REQUIRE(n >= 2, VIDC_ERR_SHAPE, "vidc_chain_create: a chain has at least two convs");
+    std::vector<ChainLayer> layers((size_t)n);
+    int items = 0;
+    for (int i = 0; i < n; ++i) {
+        int rc = validate(descs + i);
+        if (rc != VIDC_OK) return rc;
+        vidc_conv_desc dd = descs[i];
+        VIDC_REQUIRE(dd.groups == descs[0].groups && dd.groups <= 8, VIDC_ERR_SHAPE, "vidc_chain_create: every conv needs the same <= 8 groups (one XCD each)");
+        VIDC_REQUIRE(dd.precision == descs[0].precision, VIDC_ERR_SHAPE, "vidc_chain_create: one arithmetic mode per chain");
+        dd.tile = kChainTile;
+        dd.splitk = 1;
+        rc = make_args(dd, layers[i].a);
+        if (rc != VIDC_OK) return rc;
+        layers[i].item_begin = items;
+        items += layers[i].a.tiles_m * layers[i].a.tiles_n;
+    }
+    vidc_chain* ch = new vidc_chain();
+    ch->n_layers = n; ch->total_items = items; ch->groups = descs[0].groups; ch->precision = descs[0].precision;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ch->n_cu = prop.multiProcessorCount;
+    hipError_t e = hipMalloc(&ch->d_layers, sizeof(ChainLayer) * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc(&ch->d_state, sizeof(unsigned) * kChainStateWords);
+    if (e == hipSuccess) e = hipMemcpy(ch->d_layers, layers.data(), sizeof(ChainLayer) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(ch->d_state, 0, sizeof(unsigned) * kChainStateWords);
+    if (e != hipSuccess) {
+        vidc::set_error("vidc_chain_create: %s", hipGetErrorString(e));
+        vidc_chain_destroy(ch);
+        return VIDC_ERR_HIP;
+    }
+    *out = ch;
+    return VIDC_OK;
+}
+
+extern "C" int vidc_chain_run(vidc_chain* ch, vidc_stream_t stream) {
+    VIDC_REQUIRE(ch, VIDC_ERR_STATE, "vidc_chain_run: null chain");
+    hipStream_t st = vidc::as_stream(stream);
+    // claim / done counters start at zero EVERY launch (a memset node when captured); the error word [16] is sticky
+    VIDC_HIP(hipMemsetAsync(ch->d_state, 0, sizeof(unsigned) * 16, st));
+    return ch->precision == VIDC_PREC_BF16X3 ? chain_launch<1>(ch, st) : chain_launch<0>(ch, st);
+}
+
+extern "C" int vidc_chain_status(vidc_chain* ch, int* failed_layer) {
+    VIDC_REQUIRE(ch && failed_layer, VIDC_ERR_NULL, "vidc_chain_status: null pointer");
+    unsigned st[kChainStateWords];
+    VIDC_HIP(hipMemcpy(st, ch->d_state, sizeof(st), hipMemcpyDeviceToHost));      // synchronises
+    *failed_layer = (int)st[16] - 1;                                             // -1: no wait ever timed out
+    return VIDC_OK;
+}
+
+extern "C" int vidc_chain_info(const vidc_chain* ch, int* n_layers, int* total_items) {
+    VIDC_REQUIRE(ch, VIDC_ERR_STATE, "vidc_chain_info: null chain");
+    if (n_layers) *n_layers = ch->n_layers;
+    if (total_items) *total_items = ch->total_items;
+    return VIDC_OK;
+}
+
+extern "C" int vidc_chain_destroy(vidc_chain* ch) {
+    if (!ch) return VIDC_OK;
+    if (ch->d_layers) hipFree(ch->d_layers);
+    if (ch->d_state) hipFree(ch->d_state);
+    delete ch;
+    return VIDC_OK;
 }
 
 extern "C" int vidc_split_bf16x3(const float* x, void* y, long long rows, int C, int ldx, vidc_stream_t stream) {

@@ -134,6 +134,7 @@ class JointWeightStore(WeightStore):
 
 
 _TUNING = None
+CHAIN_TILE = 13      # VIDC_TILE_64x64_K2_D4: the tiling of the persistent chain kernel
 
 
 def tuning_table():
@@ -458,6 +459,94 @@ class Program:
         self.n_fused_splits = len(drop)
         self.ops = [op for i, op in enumerate(self.ops) if i not in drop]
 
+    def _fill_conv_desc(self, d, kw, addr, dry_run, chain=False):
+        """Fills one vidc_conv_desc from a recorded conv; returns the op's display name."""
+        lib = L.lib()
+        x, y, keys = kw["x"], kw["y"], kw["keys"]
+        co, ci, kh, kwid, Ho, Wo = kw["geom"]
+        prec = kw["precision"]
+        wp = self.ws.packed([k for k in keys], dry_run, prec)
+        s1, b1 = self.ws.affine(list(keys), list(kw["bn"]) if kw["bn"] is not None else None)
+        d.x, d.w, d.y = addr(x), wp.data_ptr(), addr(y)
+        d.scale1, d.shift1 = s1.data_ptr(), b1.data_ptr()
+        if kw["bn2"] is not None:
+            s2, b2 = self.ws.affine([None] * len(keys), list(kw["bn2"]))
+            d.scale2, d.shift2 = s2.data_ptr(), b2.data_ptr()
+            self._keep += [s2, b2]
+        r = kw["residual"]
+        if r is not None:
+            d.residual, d.ldr, d.r_gs = addr(r), r.ld, r.C
+        d.B, d.H, d.W, d.Cin, d.ldx = x.B, x.H, x.W, ci, x.ld
+        d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, co, y.ld
+        d.KH, d.KW, d.stride, d.pad = kh, kwid, kw["stride"], kw["pad"]
+        d.dilation = kw.get("dilation", 1)
+        d.flags, d.groups = kw["flags"], len(keys)
+        if kw.get("split_out") is not None:
+            d.y_split = addr(kw["split_out"])
+        d.x_gs, d.w_gs, d.y_gs, d.p_gs = x.C, co * kh * kwid * ci, y.C, co
+        d.tile, d.splitk, d.precision = 0, 1, prec
+        sig = conv_signature(d)
+        if chain:
+            d.tile, d.splitk = CHAIN_TILE, 1
+        elif os.environ.get("VIDC_FORCE_TILE"):           # (tests: the stand-alone kernel on the chain's tiling, for bit-exact comparisons)
+            d.tile, d.splitk = int(os.environ["VIDC_FORCE_TILE"]), 1
+        else:
+            ent = tuning_table().get(sig)
+            if ent is not None and (len(ent) < 5 or prec == ent[2]):
+                d.tile, d.splitk = ent[0], ent[1]
+            elif ent is not None and len(ent) >= 5:          # table holds the best fp32 config as well: [t, sk, prec, t32, sk32]
+                d.tile, d.splitk = ent[3], ent[4]
+            else:
+                L.check(lib.vidc_conv2d_plan(C.byref(d)), "conv plan")
+        self._keep += [wp, s1, b1]
+        return "conv:%s:%s:sk%d:%s %s" % (keys[0], L.TILE_NAMES[d.tile], d.splitk, "bf16x3" if prec else "fp32", sig)
+
+    def _fuse_chains(self):
+        """Runs of consecutive small convs (M <= VIDC_CHAIN_MAX_M, same groups <= 8, same arithmetic mode, one stream) become ONE
+        `chain` op = one persistent launch (csrc/conv_mfma.hip conv_chain_kernel): the 22 identical bottlenecks of ResNet-101 layer3
+        are 66 launches whose time is launch / prologue / HBM-cold latency, not arithmetic.  Same arithmetic per conv as the
+        stand-alone kernel with tile 64x64k2d4, split-K 1."""
+        max_m = int(os.environ.get("VIDC_CHAIN_MAX_M", "704"))
+        min_len = int(os.environ.get("VIDC_CHAIN_MIN", "6"))
+        cutset = {id(mk) for mk in self._cut_markers}
+
+        def eligible(op):
+            kind, _r, _w, kw = op
+            if kind != "conv" or kw["stream_id"] != 0 or kw["wait_mask"] != 0:
+                return False
+            co, ci, kh, kwid, Ho, Wo = kw["geom"]
+            return self.B * Ho * Wo <= max_m and len(kw["keys"]) <= 8 and kw.get("dilation", 1) == 1
+
+        out, run = [], []
+
+        def flush():
+            if len(run) >= min_len:
+                reads = [b for op in run for b in op[1]]
+                writes = [b for op in run for b in op[2]]
+                out.append(("chain", reads, writes, {"convs": [op[3] for op in run], "stream_id": 0, "wait_mask": 0}))
+                if id(run[-1]) in cutset:            # a segment boundary after the run: the marker moves to the chain op
+                    self._cut_markers = [out[-1] if mk is run[-1] else mk for mk in self._cut_markers]
+            else:
+                out.extend(run)
+            run.clear()
+
+        for op in self.ops:
+            if eligible(op) and (not run or (len(op[3]["keys"]) == len(run[0][3]["keys"]) and op[3]["precision"] == run[0][3]["precision"])):
+                run.append(op)
+                if id(op) in cutset:
+                    flush()
+            else:
+                flush()
+                if eligible(op):
+                    run.append(op)
+                    if id(op) in cutset:
+                        flush()
+                else:
+                    out.append(op)
+        flush()
+        self.n_chains = sum(1 for op in out if op[0] == "chain")
+        self.ops = out
+
     def _plan_buffers(self):
         n = len(self.buf_elems)
         multi_stream = any(kw["stream_id"] != 0 for _, _, _, kw in self.ops)
@@ -501,6 +590,9 @@ class Program:
         lib = L.lib()
         if os.environ.get("VIDC_FUSE_SPLIT", "1") == "1":
             self._fuse_splits()
+        self._chains, self._chain_descs, self.n_chains = [], [], 0
+        if os.environ.get("VIDC_CHAIN", "1") == "1":
+            self._fuse_chains()
         self.cuts = [next(i for i, op in enumerate(self.ops) if op is mk) + 1 for mk in self._cut_markers]
         assert len(self.cuts) < L.MAX_SEGMENTS and self.cuts == sorted(set(self.cuts))
         storage = self._plan_buffers()
@@ -519,45 +611,26 @@ class Program:
             op.stream_id, op.wait_mask = kw["stream_id"], kw["wait_mask"]
             g = op.u.g
             if kind == "conv":
-                x, y, keys = kw["x"], kw["y"], kw["keys"]
-                co, ci, kh, kwid, Ho, Wo = kw["geom"]
-                d = op.u.conv
                 op.kind = L.OP_CONV
-                prec = kw["precision"]
-                wp = self.ws.packed([k for k in keys], dry_run, prec)
-                s1, b1 = self.ws.affine(list(keys), list(kw["bn"]) if kw["bn"] is not None else None)
-                d.x, d.w, d.y = addr(x), wp.data_ptr(), addr(y)
-                d.scale1, d.shift1 = s1.data_ptr(), b1.data_ptr()
-                if kw["bn2"] is not None:
-                    s2, b2 = self.ws.affine([None] * len(keys), list(kw["bn2"]))
-                    d.scale2, d.shift2 = s2.data_ptr(), b2.data_ptr()
-                    self._keep += [s2, b2]
-                r = kw["residual"]
-                if r is not None:
-                    d.residual, d.ldr, d.r_gs = addr(r), r.ld, r.C
-                d.B, d.H, d.W, d.Cin, d.ldx = x.B, x.H, x.W, ci, x.ld
-                d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, co, y.ld
-                d.KH, d.KW, d.stride, d.pad = kh, kwid, kw["stride"], kw["pad"]
-                d.dilation = kw.get("dilation", 1)
-                d.flags, d.groups = kw["flags"], len(keys)
-                if kw.get("split_out") is not None:
-                    d.y_split = addr(kw["split_out"])
-                d.x_gs, d.w_gs, d.y_gs, d.p_gs = x.C, co * kh * kwid * ci, y.C, co
-                d.tile, d.splitk, d.precision = 0, 1, prec
-                sig = conv_signature(d)
-                ent = tuning_table().get(sig)
-                if ent is not None and (len(ent) < 5 or prec == ent[2]):
-                    d.tile, d.splitk = ent[0], ent[1]
-                elif ent is not None and len(ent) >= 5:          # table holds the best fp32 config as well: [t, sk, prec, t32, sk32]
-                    d.tile, d.splitk = ent[3], ent[4]
-                else:
-                    L.check(lib.vidc_conv2d_plan(C.byref(d)), "conv plan")
-                need = lib.vidc_conv2d_workspace_bytes(C.byref(d))
+                name = self._fill_conv_desc(op.u.conv, kw, addr, dry_run)
+                need = lib.vidc_conv2d_workspace_bytes(C.byref(op.u.conv))
                 if need:
                     ws_need[op.stream_id] = max(ws_need.get(op.stream_id, 0), need)
                 conv_ops.append(op)
-                self._keep += [wp, s1, b1]
-                self.op_names.append("conv:%s:%s:sk%d:%s %s" % (keys[0], L.TILE_NAMES[d.tile], d.splitk, "bf16x3" if prec else "fp32", sig))
+                self.op_names.append(name)
+            elif kind == "chain":
+                descs = (L.ConvDesc * len(kw["convs"]))()
+                names = [self._fill_conv_desc(descs[j], ckw, addr, dry_run, chain=True) for j, ckw in enumerate(kw["convs"])]
+                op.kind = L.OP_CHAIN
+                self._chain_descs.append(descs)
+                if not dry_run:
+                    h = C.c_void_p()
+                    L.check(lib.vidc_chain_create(descs, len(descs), C.byref(h)), "chain_create")
+                    self._chains.append(h)
+                    g.p[0] = h.value
+                fl = sum(2.0 * d.B * d.Ho * d.Wo * d.Cout * d.KH * d.KW * d.Cin * d.groups for d in descs)
+                self.op_names.append("chain:%d:%s:%s:F%d %s .. %s" % (len(descs), kw["convs"][0]["keys"][0], "bf16x3" if descs[0].precision else "fp32",
+                                                                     int(fl), names[0].split(" ")[-1], names[-1].split(" ")[-1]))
             elif kind == "stem":
                 x, y = kw["x"], kw["y"]
                 w = self.ws.raw(kw["key"] + ".weight").contiguous()
@@ -727,9 +800,21 @@ class Program:
                                           int(use_graph), ms, per), "program_time")
         return (ms[0], list(per)) if per_op else ms[0]
 
+    def check_chains(self):
+        """Synchronises and raises if a dependency wait of a persistent chain ever timed out (results would be garbage)."""
+        if self._chains:
+            torch.cuda.synchronize(self.device)
+        for h in self._chains:
+            failed = C.c_int(-1)
+            L.check(L.lib().vidc_chain_status(h, C.byref(failed)), "chain_status")
+            if failed.value >= 0:
+                raise RuntimeError("persistent conv chain: the wait for layer %d timed out (no workgroup on the group's XCD?)" % failed.value)
+
     def __del__(self):
         try:
             if self.handle is not None:
                 L.lib().vidc_program_destroy(self.handle)
+            for h in getattr(self, "_chains", []):
+                L.lib().vidc_chain_destroy(h)
         except Exception:
             pass

@@ -225,6 +225,7 @@ class DepthCompletionPipeline:
                         side.wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(side):
                             prog.run()            # warm-up outside capture (sets kernel attributes)
+                            prog.check_chains()
                             prog.capture_segments()
                         torch.cuda.current_stream().wait_stream(side)
                     sn_image, dc_image = prog.tensor(prog.inputs["sn_image"]), prog.tensor(prog.inputs["dc_image"])
