@@ -388,13 +388,17 @@ int vidc_instance_map(const uint8_t* pasted, const float* det_scores, const int3
  * XCD g, layers hand over through that XCD's L2 with per-XCD item counters (no grid barrier), and the weights of the next item
  * stream in while the previous layer finishes.  Same arithmetic as vidc_conv2d_bn_act with tile VIDC_TILE_64x64_K2_D4, splitk 1
  * (bit-identical).  descs[i] may read what descs[j < i] wrote; inputs produced outside the chain must be complete before the launch.
- * create() uploads the layer table (synchronous); run() enqueues a counter reset + the kernel (capturable); status() synchronises
+ * create() uploads the layer table (synchronous); run() enqueues the kernel (capturable; it leaves its counters at zero); status() synchronises
  * and returns in *failed_layer the layer whose dependency wait timed out, or -1. */
 typedef struct vidc_chain vidc_chain;
 int vidc_chain_create(const vidc_conv_desc* descs, int n, vidc_chain** out);
 int vidc_chain_run(vidc_chain* chain, vidc_stream_t stream);
 int vidc_chain_status(vidc_chain* chain, int* failed_layer);
 int vidc_chain_info(const vidc_chain* chain, int* n_layers, int* total_items);
+/* Debug: per-item time stamps.  enable != 0 allocates the trace buffer (later launches fill it); host_out != NULL copies it out
+ * (synchronous): [workgroup][160 items][8] int64 = 100 MHz clock at item start / dependency wait begin / end / main loop end / outputs
+ * drained / done counted, (layer << 32 | item), 0.  Returns the number of int64 words of the buffer. */
+int vidc_chain_trace(vidc_chain* chain, int enable, long long* host_out, int max_words);
 int vidc_chain_destroy(vidc_chain* chain);
 
 enum vidc_op_kind { VIDC_OP_CONV = 1, VIDC_OP_STEM = 2, VIDC_OP_MAXPOOL = 3, VIDC_OP_UPSAMPLE = 4, VIDC_OP_HEAD = 5,

@@ -79,6 +79,7 @@ SIGNATURES = {
     "vidc_chain_run": (C.c_int, [_vp, _vp]),
     "vidc_chain_status": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "vidc_chain_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vidc_chain_trace": (C.c_int, [_vp, _i, _vp, _i]),
     "vidc_chain_destroy": (C.c_int, [_vp]),
     "vidc_stem_conv3x3s2": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "vidc_maxpool3x3s2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -123,6 +123,11 @@ __device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
 // the compute waves' critical path (in-kernel stamps, M=320 layer-3 shapes: 853 clk per stage, 521 clk without the refills,
 // 829 clk without the MFMAs).  One loader and one compute wave share each SIMD; the per-stage s_barrier is the only hand-off:
 // a loader passes it after ITS loads of stage s have landed (its own vmcnt), a compute wave after it has read stage s-1.
+struct NoDep {
+    __device__ __forceinline__ void operator()() const {}
+    __device__ __forceinline__ void mark(int) const {}
+};
+
 // CHAIN = true: the tile runs inside the persistent chain kernel (conv_chain_kernel below), where the activations it reads were
 // written by OTHER workgroups of the same launch: `dep()` (a workgroup-wide wait) is called after the weight prologue is in flight
 // and before the first activation / residual access, and those accesses bypass the per-CU L1 (sc1), which another CU's stores never
@@ -303,7 +308,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
         if (a.flags & VIDC_AFFINE2) { e_s2[j] = a.scale2[ni]; e_b2[j] = a.shift2[ni]; }
     }
     VIDC_STAMP(11);     // scale/shift loads issued
+    dep.mark(1);
     dep();              // chain: everything this tile reads from earlier layers is complete (the weight prologue is already in flight)
+    dep.mark(2);
     float e_res[TM][TN][16];
     if ((a.flags & VIDC_RESIDUAL) && a.splitk == 1 && !is_loader) {    // uniform branch; indices clamped so every load is unconditional
 #pragma unroll
@@ -468,6 +475,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
     for (int s = n_main; s < nst; ++s) iteration(s, std::false_type{});
 
     VIDC_STAMP(3);      // main loop done
+    dep.mark(3);
     if (WKW > 1) {
         __syncthreads();
         float* red = smem;
@@ -647,7 +655,7 @@ conv_igemm_f32(const ConvArgs a) {
         g = (int)fast_div(v2, a.dv_tiles_n);
         tile_n = (int)(v2 - g * a.tiles_n);
     }
-    conv_tile<BM, BN, WMW, WNW, WKW, NS, PREC, SPEC, false>(a, g, tile_m, tile_n, kz, smem, [] {});
+    conv_tile<BM, BN, WMW, WNW, WKW, NS, PREC, SPEC, false>(a, g, tile_m, tile_n, kz, smem, NoDep{});
 }
 
 // ---- persistent chain kernel ------------------------------------------------------------------------------------------------------
@@ -672,8 +680,53 @@ struct ChainLayer {
 };
 struct ChainArgs {
     const ChainLayer* layers;
-    unsigned* state;     // [0..7] next item per XCD, [8..15] items done per XCD, [16] error code, [17] workgroups seen
+    unsigned* state;     // [0..7] next item per XCD, [8..15] items done per XCD, [16] error code (sticky), [17] workgroups that have left
+    long long* trace;    // NULL, or [workgroup][VIDC_CHAIN_TRACE_ITEMS][8] time stamps (debug: tools/chain_trace.py)
     int n_layers, total_items, groups, spin_limit;
+};
+constexpr int kChainTraceItems = 160;
+
+struct ChainDep {
+    unsigned* done;
+    unsigned* err;
+    unsigned need;
+    int spin_limit;
+    long long* tr;        // this item's 8 stamps, or NULL
+    bool* failed;
+    const float* wtile;   // this item's 64 weight rows (group base + n0 * K), K floats each
+    int wrows, K;
+    // The item's whole weight tile is pulled into the XCD's L2 while the workgroup waits for its dependency (the ring prologue only
+    // covers the first NS-1 stages): one 4-byte load per 128-byte line, every lane its own line -- the point is the number of lines
+    // in flight, which the LDS ring cannot provide (96 KB per workgroup against ~2.4 us of HBM-cold latency = 0.8 us per stage
+    // measured; L2 hits afterwards).  The loaded words are xor-ed into a value that is never stored.
+    __device__ __forceinline__ unsigned prefetch() const {
+        unsigned acc = 0;
+        const int lines_per_row = K >> 5;                         // 128-byte lines per row
+        const int total = wrows * lines_per_row;
+        for (int i = threadIdx.x; i < total; i += 512) {
+            const int r = i / lines_per_row, c = i - r * lines_per_row;
+            acc ^= __float_as_uint(__builtin_nontemporal_load(wtile + (size_t)r * K + c * 32));
+        }
+        return acc;
+    }
+    __device__ __forceinline__ void mark(int k) const {
+        if (tr && threadIdx.x == 0) tr[k] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+    __device__ __forceinline__ void operator()() const {
+        const unsigned junk = prefetch();
+        if (junk == 0x9E3779B9u && need == 0xFFFFFFFFu) *err = junk;      // never true: keeps the loads alive
+        if (threadIdx.x < 64) {                              // one wave polls one word, relaxed, L2-served; bounded
+            int spins = 0;
+            while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > spin_limit || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    *failed = true;                          // timed out, or another workgroup did: give up (the host reads state[16])
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
 };
 
 template <int NS, int PREC>
@@ -681,48 +734,56 @@ __global__ void __launch_bounds__(512) conv_chain_kernel(const ChainArgs c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ unsigned s_q;
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;      // HW_REG_XCC_ID[3:0]
-    if ((int)xcc >= c.groups) return;               // this XCD serves no group of the launch
-    const int g = (int)xcc;
-    unsigned* next = c.state + xcc;
-    unsigned* done = c.state + 8 + xcc;
     const int tid = threadIdx.x;
-    int l = 0;
-    if (tid == 0) s_q = atomicAdd(next, 1u);
-    __syncthreads();
-    unsigned q = s_q;
-    while (q < (unsigned)c.total_items) {
-        while (l + 1 < c.n_layers && q >= (unsigned)c.layers[l + 1].item_begin) ++l;     // uniform
-        const ChainLayer* L = c.layers + l;
-        const int item = (int)q - L->item_begin;
-        const int tiles_m = L->a.tiles_m;
-        const int tile_n = item / tiles_m, tile_m = item - tile_n * tiles_m;
-        const unsigned need = (unsigned)L->item_begin;
-        unsigned q_next = 0;
-        if (tid == 0) q_next = atomicAdd(next, 1u);          // the next claim travels while this item runs
-        bool failed = false;
-        auto dep = [&]() {
-            if (tid < 64) {                                  // one wave polls one word, relaxed, L2-served; bounded
-                int spins = 0;
-                while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > c.spin_limit || ((spins & 1023) == 0 && __hip_atomic_load(c.state + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                        failed = true;                       // timed out, or another workgroup did: give up (the host reads state[16])
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-        };
-        conv_tile<64, 64, 2, 2, 2, NS, PREC, 0, true>(L->a, g, tile_m, tile_n, 0, smem, dep);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its outputs have reached the XCD's L2
-        __syncthreads();                                      // ... and every wave is done with the LDS ring
-        if (tid == 0) {
-            if (failed) atomicMax(c.state + 16, 1u + (unsigned)l);
-            atomicAdd(done, 1u);
-            s_q = failed ? 0xFFFFFFFFu : q_next;             // after a time-out this workgroup leaves
-        }
+    if ((int)xcc < c.groups) {                      // (the other XCDs serve no group of this launch)
+        const int g = (int)xcc;
+        unsigned* next = c.state + xcc;
+        unsigned* done = c.state + 8 + xcc;
+        int l = 0, n_done = 0;
+        if (tid == 0) s_q = atomicAdd(next, 1u);
         __syncthreads();
-        q = s_q;
+        unsigned q = s_q;
+        while (q < (unsigned)c.total_items) {
+            while (l + 1 < c.n_layers && q >= (unsigned)c.layers[l + 1].item_begin) ++l;     // uniform
+            const ChainLayer* Lp = c.layers + l;
+            const ConvArgs a = Lp->a;                         // one batch of scalar loads per item instead of one per field use
+            const int item_begin = Lp->item_begin;
+            const int item = (int)q - item_begin;
+            const int tiles_m = a.tiles_m;
+            const int tile_n = item / tiles_m, tile_m = item - tile_n * tiles_m;
+            long long* tr = (c.trace && n_done < kChainTraceItems) ? c.trace + ((size_t)blockIdx.x * kChainTraceItems + n_done) * 8 : nullptr;
+            unsigned q_next = 0;
+            if (tid == 0) q_next = atomicAdd(next, 1u);          // the next claim travels while this item runs
+            bool failed = false;
+            const int n0w = tile_n * 64;
+            ChainDep dep{done, c.state + 16, (unsigned)item_begin, c.spin_limit, tr, &failed,
+                         a.w + g * a.w_gs + (size_t)n0w * a.K, min(64, a.Cout - n0w), a.K};
+            if (tr && tid == 0) tr[6] = ((long long)l << 32) | q;
+            dep.mark(0);
+            conv_tile<64, 64, 2, 2, 2, NS, PREC, 0, true>(a, g, tile_m, tile_n, 0, smem, dep);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its outputs have reached the XCD's L2
+            __syncthreads();                                      // ... and every wave is done with the LDS ring
+            dep.mark(4);
+            if (tid == 0) {
+                if (failed) atomicMax(c.state + 16, 1u + (unsigned)l);
+                atomicAdd(done, 1u);
+                s_q = failed ? 0xFFFFFFFFu : q_next;             // after a time-out this workgroup leaves
+            }
+            dep.mark(5);
+            __syncthreads();
+            q = s_q;
+            ++n_done;
+        }
+    }
+    // The claim / done counters are left at zero for the next launch by the LAST workgroup to leave (every workgroup is past its last
+    // access to them by then) -- no memset node: under hipGraph replay the launch must not depend on one.
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = atomicAdd(c.state + 17, 1u);
+        if (t == gridDim.x - 1) {
+            for (int i = 0; i < 16; ++i) atomicExch(c.state + i, 0u);
+            atomicExch(c.state + 17, 0u);
+        }
     }
 }
 
@@ -987,6 +1048,7 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
 struct vidc_chain {
     ChainLayer* d_layers = nullptr;
     unsigned* d_state = nullptr;
+    long long* d_trace = nullptr;
     int n_layers = 0, total_items = 0, groups = 0, precision = 0, n_cu = 256;
 };
 
@@ -1007,7 +1069,7 @@ int chain_launch(const vidc_chain* ch, hipStream_t st) {
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     ChainArgs c;
-    c.layers = ch->d_layers; c.state = ch->d_state; c.n_layers = ch->n_layers; c.total_items = ch->total_items; c.groups = ch->groups;
+    c.layers = ch->d_layers; c.state = ch->d_state; c.trace = ch->d_trace; c.n_layers = ch->n_layers; c.total_items = ch->total_items; c.groups = ch->groups;
     c.spin_limit = 1000000;
     // one workgroup per CU (128 KB of LDS each); the groups' XCDs use theirs, the others leave at once
     hipLaunchKernelGGL((conv_chain_kernel<kChainNS, PREC>), dim3(ch->n_cu), dim3(512), kChainLds, st, c);
@@ -1054,9 +1116,7 @@ extern "C" int vidc_chain_create(const vidc_conv_desc* descs, int n, vidc_chain*
 
 extern "C" int vidc_chain_run(vidc_chain* ch, vidc_stream_t stream) {
     VIDC_REQUIRE(ch, VIDC_ERR_STATE, "vidc_chain_run: null chain");
-    hipStream_t st = vidc::as_stream(stream);
-    // claim / done counters start at zero EVERY launch (a memset node when captured); the error word [16] is sticky
-    VIDC_HIP(hipMemsetAsync(ch->d_state, 0, sizeof(unsigned) * 16, st));
+    hipStream_t st = vidc::as_stream(stream);      // (the kernel leaves its claim / done counters at zero; the error word [16] is sticky)
     return ch->precision == VIDC_PREC_BF16X3 ? chain_launch<1>(ch, st) : chain_launch<0>(ch, st);
 }
 
@@ -1066,6 +1126,21 @@ extern "C" int vidc_chain_status(vidc_chain* ch, int* failed_layer) {
     VIDC_HIP(hipMemcpy(st, ch->d_state, sizeof(st), hipMemcpyDeviceToHost));      // synchronises
     *failed_layer = (int)st[16] - 1;                                             // -1: no wait ever timed out
     return VIDC_OK;
+}
+
+extern "C" int vidc_chain_trace(vidc_chain* ch, int enable, long long* host_out, int max_words) {
+    VIDC_REQUIRE(ch, VIDC_ERR_STATE, "vidc_chain_trace: null chain");
+    const size_t words = (size_t)ch->n_cu * kChainTraceItems * 8;
+    if (enable && !ch->d_trace) {
+        VIDC_HIP(hipMalloc(&ch->d_trace, words * sizeof(long long)));
+        VIDC_HIP(hipMemset(ch->d_trace, 0, words * sizeof(long long)));
+    }
+    if (host_out) {
+        VIDC_REQUIRE(ch->d_trace && (size_t)max_words >= words, VIDC_ERR_SHAPE, "vidc_chain_trace: needs %zu words", words);
+        VIDC_HIP(hipMemcpy(host_out, ch->d_trace, words * sizeof(long long), hipMemcpyDeviceToHost));
+    }
+    if (!enable && ch->d_trace) { hipFree(ch->d_trace); ch->d_trace = nullptr; }
+    return (int)words;
 }
 
 extern "C" int vidc_chain_info(const vidc_chain* ch, int* n_layers, int* total_items) {
@@ -1079,6 +1154,7 @@ extern "C" int vidc_chain_destroy(vidc_chain* ch) {
     if (!ch) return VIDC_OK;
     if (ch->d_layers) hipFree(ch->d_layers);
     if (ch->d_state) hipFree(ch->d_state);
+    if (ch->d_trace) hipFree(ch->d_trace);
     delete ch;
     return VIDC_OK;
 }

@@ -591,7 +591,9 @@ class Program:
         if os.environ.get("VIDC_FUSE_SPLIT", "1") == "1":
             self._fuse_splits()
         self._chains, self._chain_descs, self.n_chains = [], [], 0
-        if os.environ.get("VIDC_CHAIN", "1") == "1":
+        # Opt-in (VIDC_CHAIN=1): measured on MI355X the XCD-local persistent chain is SLOWER than the per-layer launches it replaces
+        # (1.69 ms vs 1.1 ms for the 79 layer3/4 convs of a tick: half the chip, LDS-DMA-latency-bound stages).
+        if os.environ.get("VIDC_CHAIN", "0") == "1":
             self._fuse_chains()
         self.cuts = [next(i for i, op in enumerate(self.ops) if op is mk) + 1 for mk in self._cut_markers]
         assert len(self.cuts) < L.MAX_SEGMENTS and self.cuts == sorted(set(self.cuts))
