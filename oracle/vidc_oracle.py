@@ -158,9 +158,13 @@ def warp_inverse_normals(x, g, a, intr, align_corners=False):
 # ----------------------------------------------------------------------------------------------
 # Networks (functional over a state_dict)
 # ----------------------------------------------------------------------------------------------
+BN_TRAINING = False      # oracle/train_oracle.py flips this for the training step: nn.BatchNorm2d in train() mode (batch statistics,
+#                          running statistics updated in place with momentum 0.1), the state the reference trains in (network_run.py:232)
+
+
 def _bn(x, sd, p):
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
-                        training=False, eps=1e-5)
+                        training=BN_TRAINING, momentum=0.1, eps=1e-5)
 
 
 def _conv(x, sd, p, stride=1, padding=0):

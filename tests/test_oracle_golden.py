@@ -120,3 +120,56 @@ def test_eval_oracle_matches_reference(golden_dir):
     got_d = [ds[k] for k in ("MAD", "RMSE", "1.05", "1.10", "1.25", "1.25^2", "1.25^3")]
     assert np.abs(np.array(got_n) - f["normal_figures"]).max() < 2e-5, (got_n, f["normal_figures"])      # %f prints 6 decimals; the
     assert np.abs(np.array(got_d) - f["depth_figures"]).max() < 2e-6, (got_d, f["depth_figures"])        # reference's fp32 pairwise mean
+
+
+def _train_fixture(golden_dir):
+    f = np.load(os.path.join(golden_dir, "train_step.npz"))
+    batch = S.synthetic_batch(2, 240, 320, 1234, frame0=int(f["frame0"]))
+    gt = S.synthetic_ground_truth_depth(batch["image"], 1234)
+    din = torch.zeros(2, 240, 320)
+    rc = torch.from_numpy(f["depth_in_rc"]).long()
+    din[rc[:, 0], rc[:, 1], rc[:, 2]] = torch.from_numpy(f["depth_in_val"])
+    return f, batch["image"], torch.from_numpy(f["normal"]), din[:, None], gt
+
+
+def check_probe(f, tag, name, t, rtol, atol):
+    """A tensor against its stored summary (whole tensor if small, else sum / |sum| / 64 probe elements)."""
+    t = t.detach().float().reshape(-1)
+    key = "%s|%s|" % (tag, name)
+    if key + "full" in f.files:
+        ref = f[key + "full"]
+        assert np.abs(t.numpy() - ref).max() <= atol + rtol * np.abs(ref).max(), (tag, name, np.abs(t.numpy() - ref).max(), np.abs(ref).max())
+    else:
+        ref = f[key + "val"]
+        got = t[torch.from_numpy(f[key + "idx"])].numpy()
+        scale = float(f[key + "abs"]) / t.numel()
+        assert np.abs(got - ref).max() <= atol + rtol * max(np.abs(ref).max(), scale), (tag, name, np.abs(got - ref).max(), scale)
+        assert abs(float(t.double().abs().sum()) - float(f[key + "abs"])) <= (atol * t.numel() + rtol * float(f[key + "abs"])), (tag, name)
+
+
+def test_train_oracle_matches_reference_training_iteration(golden_dir, seeded_weights):
+    """oracle/train_oracle.py against ONE `_run_training_iteration` of the reference itself (oracle/tools/make_golden_train.py;
+    network_run.py:231-254, 158-191, 228-229): the loss, the gradient of 29 parameters spread over the network (stems, BatchNorm
+    affines, Bottleneck convs of every stage, decoder, head), their values after the Adam step and updated running statistics.
+    Same torch-CPU kernels on both sides -> agreement to float rounding (the autograd graphs differ: functional vs nn.Module)."""
+    from oracle import train_oracle as T
+    f, image, normal, depth_in, gt = _train_fixture(golden_dir)
+    sd = seeded_weights["dc"]
+    loss, pred, grads, bufs = T.forward_backward(sd, image, normal, depth_in, gt)
+    assert abs(float(loss) - float(f["loss"])) < 1e-6 and abs(round(float(loss), 4) - float(f["loss_logged"])) < 1e-9
+    assert np.abs(pred[:, 0, ::16, ::16].numpy() - f["pred_probe"]).max() < 1e-5
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
+    assert abs(gn - float(f["grad_global_norm"])) < 1e-5 * gn
+    names = sorted({k.split("|")[1] for k in f.files if k.startswith("grad|")})
+    assert len(names) == 29
+    for k in names:
+        check_probe(f, "grad", k, grads[k], 2e-4, 1e-9)
+    new = T.adam_step({k: sd[k] for k in grads}, grads, {}, float(f["lr"]))
+    for k in names:
+        # The first Adam step moves a weight by lr * g / (|g| + 1e-8): ~lr = 1e-4 wherever |g| >> 1e-8, and ill-conditioned where the
+        # gradient is ~1e-8 (a rounding-level difference in g moves the update by a fraction of lr).  3e-5 still separates "stepped"
+        # from "did not step" (1e-4).
+        check_probe(f, "new", k, new[k], 1e-6, 3e-5)
+        check_probe(f, "old", k, sd[k], 0.0, 0.0)
+    for k in [k[4:] for k in f.files if k.startswith("buf|")]:
+        assert np.abs(bufs[k].numpy() - f["buf|" + k]).max() < 1e-6 * max(1.0, np.abs(f["buf|" + k]).max())

@@ -191,6 +191,15 @@ def synthetic_batch(batch, height=240, width=320, seed=1234, n_sparse=200, frame
     }
 
 
+def synthetic_ground_truth_depth(image, seed=1234):
+    """Dense synthetic ground-truth depth (metres) for the training configuration (BASELINE configs[4]): a smooth function of the
+    frame content plus noise, ~20 % invalid (0) pixels like a real sensor map.  image: (B,3,H,W) -> (B,1,H,W)."""
+    B, _, H, W = image.shape
+    base = 1.0 + 3.0 * image.mean(dim=1, keepdim=True) + 0.5 * uniform01(seed, "gt.noise", (B, 1, H, W))
+    hole = uniform01(seed, "gt.hole", (B, 1, H, W)) < 0.2
+    return torch.where(hole, torch.zeros_like(base), base).float()
+
+
 def synthetic_camera_batch(batch, src_height=480, src_width=640, seed=1234, n_sparse=200, frame0=0, out_hw=(240, 320)):
     """Raw camera-side inputs of a stream (BASELINE configs[2], [3]: "640x480 stream", "1280x720"), i.e. what DemoDataset reads from
     disk before its own pre-processing (dataset.py:461-510): uint8 RGB frames (B,H,W,3), the raw gravity file values (B,3) (the loader
