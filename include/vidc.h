@@ -383,6 +383,62 @@ int vidc_instance_map(const uint8_t* pasted, const float* det_scores, const int3
  * ---------------------------------------------------------------------------------------------- */
 
 /* ------------------------------------------------------------------------------------------------
+ * Training step of the depth-completion network (network_run.py:158-191, 228-254): what
+ * `_run_training_iteration` needs beyond the inference kernels.  Activations NHWC fp32 rows [M][ld] with C channels used.
+ * `scratch`: vidc_train_scratch_bytes(M, C) bytes unless stated.  Per-channel reductions: fp64, fixed order.
+ * ---------------------------------------------------------------------------------------------- */
+size_t vidc_train_scratch_bytes(long long M, int C);
+
+/* nn.BatchNorm2d in train() mode (+ the ReLU that follows it when relu != 0): batch mean / biased variance over the M rows,
+ * y = (x - mean) * invstd * gamma + beta; running_mean/var (may be NULL) <- (1 - momentum) * old + momentum * (mean, unbiased var);
+ * save_mean / save_rstd [C] are kept for the backward. */
+int vidc_bn_train_forward(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
+                          void* scratch, vidc_stream_t stream);
+/* Its backward.  y_relu: the forward output when a ReLU followed (its mask is applied to dy), else NULL.  dx may alias dy. */
+int vidc_bn_train_backward(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
+                           int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                           void* scratch, vidc_stream_t stream);
+/* out[c] = sum over rows of dy[.][c]: the bias gradient of a convolution. */
+int vidc_colsum(const float* dy, long long M, int C, int ld, float* out, void* scratch, vidc_stream_t stream);
+/* y = a + b, ReLU optional (Bottleneck: relu(bn3(conv3(.)) + identity); decoder: z1 + z2 + z3 + z4). */
+int vidc_add_rows(const float* a, const float* b, float* y, long long M, int C, int lda, int ldb, int ldy, int relu, vidc_stream_t stream);
+/* dx (accumulate ? += : =) dy * (y > 0); y == NULL: plain copy / accumulate. */
+int vidc_relu_backward(const float* dy, const float* y, float* dx, long long M, int C, int lddy, int ldy, int lddx, int accumulate,
+                       vidc_stream_t stream);
+/* Backward of vidc_maxpool3x3s2 (first maximum of a window in scan order takes the gradient, like torch). x: the pool's input. */
+int vidc_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int ldx, int lddy, int lddx,
+                               vidc_stream_t stream);
+/* Backward of vidc_upsample_bilinear_ac: dy [B][H][W] rows -> dx [B][h][w] rows (gather form, deterministic). */
+int vidc_upsample_bilinear_ac_backward(const float* dy, float* dx, int B, int h, int w, int C, int lddy, int lddx, int H, int W,
+                                       vidc_stream_t stream);
+/* Backward of the padded 1x1 head conv (depth_completion.py:145: Conv2d(192, 1, 1, padding=1)): g_low [B][h+2][w+2] -> dx NHWC
+ * [B][h][w][C], dw [C], dbias [1].  scratch: vidc_head_backward_scratch_bytes. */
+size_t vidc_head_backward_scratch_bytes(int B, int h, int w, int C);
+int vidc_head_backward(const float* g_low, const float* x, const float* wgt, float* dx, float* dw, float* dbias, int B, int h, int w, int C,
+                       int ldx, int lddx, void* scratch, vidc_stream_t stream);
+/* `_network_loss` (network_run.py:163-173): *loss = sum over gt > 0 of |pred - gt| / hw (hw = H*W of one image), dpred = its
+ * gradient, terms = the per-pixel terms (n floats of scratch the caller owns); scratch: n / 512 + 8 doubles. */
+int vidc_masked_l1_loss(const float* pred, const float* gt, long long n, int hw, double* loss, float* dpred, float* terms, void* scratch,
+                        vidc_stream_t stream);
+/* torch.optim.Adam.step (defaults: no weight decay, no amsgrad) over a flat buffer; step = 1, 2, ... */
+int vidc_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,
+                   vidc_stream_t stream);
+/* dgrad: the gradient w.r.t. a conv's input is vidc_conv2d_bn_act of dY (stride 1, pad KH-1-pad) with these weights
+ * ([Cin][Cout/32][KH][KW][32], kernel flipped); a stride-s conv first spreads dY over the input grid with vidc_zero_stuff. */
+int vidc_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, vidc_stream_t stream);
+int vidc_zero_stuff(const float* dy, float* z, int B, int Ho, int Wo, int C, int lddy, int stride, int H, int W, vidc_stream_t stream);
+/* wgrad: dw_oihw[co][ci][kh][kw] = sum over output pixels of dy[m][co] * x[pixel(m) at the tap][ci], on v_mfma_f32_32x32x2_f32 with the
+ * pixels as the reduction index.  scratch: vidc_conv_wgrad_scratch_bytes. */
+size_t vidc_conv_wgrad_scratch_bytes(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW);
+int vidc_conv_wgrad(const float* dy, const float* x, float* dw_oihw, int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int lddy,
+                    int KH, int KW, int stride, int pad, void* scratch, vidc_stream_t stream);
+/* wgrad of the 3x3 / stride-2 stem conv on the NCHW network input (Cin = 1 or 3). */
+size_t vidc_stem_wgrad_scratch_bytes(int B, int Cin, int H, int W, int Cout);
+int vidc_stem_wgrad(const float* dy, const float* x_nchw, float* dw_oihw, int B, int Cin, int H, int W, int Cout, int lddy, void* scratch,
+                    vidc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Persistent conv chains.  A run of consecutive small fused convs (vidc_conv_desc, same `groups` <= 8 and precision; e.g. the 22
  * identical Bottlenecks of torchvision ResNet-101 layer3, networks/surface_normal.py:27-35) as ONE launch: group g runs entirely on
  * XCD g, layers hand over through that XCD's L2 with per-XCD item counters (no grid barrier), and the weights of the next item

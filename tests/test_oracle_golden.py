@@ -132,19 +132,7 @@ def _train_fixture(golden_dir):
     return f, batch["image"], torch.from_numpy(f["normal"]), din[:, None], gt
 
 
-def check_probe(f, tag, name, t, rtol, atol):
-    """A tensor against its stored summary (whole tensor if small, else sum / |sum| / 64 probe elements)."""
-    t = t.detach().float().reshape(-1)
-    key = "%s|%s|" % (tag, name)
-    if key + "full" in f.files:
-        ref = f[key + "full"]
-        assert np.abs(t.numpy() - ref).max() <= atol + rtol * np.abs(ref).max(), (tag, name, np.abs(t.numpy() - ref).max(), np.abs(ref).max())
-    else:
-        ref = f[key + "val"]
-        got = t[torch.from_numpy(f[key + "idx"])].numpy()
-        scale = float(f[key + "abs"]) / t.numel()
-        assert np.abs(got - ref).max() <= atol + rtol * max(np.abs(ref).max(), scale), (tag, name, np.abs(got - ref).max(), scale)
-        assert abs(float(t.double().abs().sum()) - float(f[key + "abs"])) <= (atol * t.numel() + rtol * float(f[key + "abs"])), (tag, name)
+from _probe import check_probe  # noqa: E402
 
 
 def test_train_oracle_matches_reference_training_iteration(golden_dir, seeded_weights):

@@ -75,6 +75,24 @@ SIGNATURES = {
     "vidc_conv2d_bn_act": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "vidc_conv2d_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "vidc_conv2d_plan": (C.c_int, [C.POINTER(ConvDesc)]),
+    "vidc_train_scratch_bytes": (C.c_size_t, [C.c_longlong, _i]),
+    "vidc_bn_train_forward": (C.c_int, [_vp, _vp, C.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "vidc_bn_train_backward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vidc_colsum": (C.c_int, [_vp, C.c_longlong, _i, _i, _vp, _vp, _vp]),
+    "vidc_add_rows": (C.c_int, [_vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp]),
+    "vidc_relu_backward": (C.c_int, [_vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp]),
+    "vidc_maxpool3x3s2_backward": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vidc_upsample_bilinear_ac_backward": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vidc_head_backward_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "vidc_head_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "vidc_masked_l1_loss": (C.c_int, [_vp, _vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vidc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, _f, _f, _f, _f, _i, _vp]),
+    "vidc_pack_conv_weight_dgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vidc_zero_stuff": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vidc_conv_wgrad_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i]),
+    "vidc_conv_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "vidc_stem_wgrad_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "vidc_stem_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vidc_chain_create": (C.c_int, [C.POINTER(ConvDesc), _i, C.POINTER(_vp)]),
     "vidc_chain_run": (C.c_int, [_vp, _vp]),
     "vidc_chain_status": (C.c_int, [_vp, C.POINTER(C.c_int)]),

@@ -1,0 +1,697 @@
+// Training step of the depth-completion network on the device: what `_run_training_iteration` (network_run.py:231-254)
+// needs beyond the inference kernels -- BatchNorm in train() mode (batch statistics + running-statistic update) and its backward, the
+// backward of ReLU / residual add / max-pool / bilinear upsampling / the padded 1x1 head, the weight gradients of the convolutions
+// (wgrad: an fp32-MFMA GEMM whose reduction runs over the pixels), the masked L1 loss of `_network_loss` (network_run.py:158-173)
+// and torch.optim.Adam's update (network_run.py:228-229).  The data gradients of the convolutions (dgrad) are the forward conv kernel
+// (conv_mfma.hip) on flipped / transposed weights (pack_weight_dgrad_kernel here), with stride-2 layers going through a zero-stuffed
+// copy of the incoming gradient.
+//
+// Layout: activations NHWC fp32, `ld` = channel stride of a row (a tensor may be a channel slice of a concat buffer).  Per-channel
+// reductions accumulate in fp64 with a fixed two-level order (bit-reproducible), like torch's CPU kernels accumulate float in double.
+#include "common.h"
+#include <cstdint>
+
+namespace {
+
+constexpr int TT = 256;
+
+// ---- per-channel sums over rows: partial[chunk][q][C] (fp64) -------------------------------------------------------------------------
+// block = 256 threads = 64 channels x 4 row-lanes; grid = (C/64 rounded up, n_chunks).  MODE 0: sum x, sum x^2.  MODE 1 (BN backward):
+// sum dy', sum dy' * xhat with dy' = dy * (y > 0) when y != NULL (the ReLU that followed the BatchNorm).
+template <int MODE>
+__global__ void __launch_bounds__(TT)
+chan_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ y, long long M, int C, int lda, int ldb,
+                    int ldy, const float* __restrict__ mean, const float* __restrict__ rstd, int rows_per_chunk, double* __restrict__ partial) {
+    __shared__ double red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    double s0 = 0.0, s1 = 0.0;
+    if (c < C) {
+        const float mu = MODE ? mean[c] : 0.f, rs = MODE ? rstd[c] : 0.f;
+        for (long long r = r0 + rl; r < r1; r += 4) {
+            if (MODE == 0) {
+                const double v = (double)a[r * lda + c];
+                s0 += v; s1 += v * v;
+            } else {
+                float g = a[r * lda + c];
+                if (y && !(y[r * ldy + c] > 0.f)) g = 0.f;
+                const float xh = (b[r * ldb + c] - mu) * rs;
+                s0 += (double)g; s1 += (double)g * (double)xh;
+            }
+        }
+    }
+    red[0][rl][threadIdx.x & 63] = s0; red[1][rl][threadIdx.x & 63] = s1;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const int l = threadIdx.x & 63;
+        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    }
+}
+
+// sums[q][C] = sum over chunks, in chunk order
+__global__ void __launch_bounds__(TT) chan_final_kernel(const double* __restrict__ partial, int n_chunks, int C, double* __restrict__ sums) {
+    const int c = blockIdx.x * TT + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < n_chunks; ++k) { s0 += partial[((size_t)k * 2 + 0) * C + c]; s1 += partial[((size_t)k * 2 + 1) * C + c]; }
+    sums[c] = s0; sums[C + c] = s1;
+}
+
+// nn.BatchNorm2d.forward in train(): batch mean, biased variance, invstd = 1/sqrt(var + eps); running_mean/var <- (1 - momentum) * old
+// + momentum * (mean, unbiased var)
+__global__ void __launch_bounds__(TT)
+bn_stats_final_kernel(const double* __restrict__ sums, long long M, int C, float eps, float momentum, float* __restrict__ mean,
+                      float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * TT + threadIdx.x;
+    if (c >= C) return;
+    const double mu = sums[c] / (double)M;
+    double var = sums[C + c] / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mu);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+}
+
+// y = x * alpha + beta' with alpha = invstd * gamma, beta' = beta - mean * alpha (torch's batch_norm_cpu_transform_input), ReLU optional
+__global__ void __launch_bounds__(TT)
+bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long long M, int C, int ldx, int ldy, const float* __restrict__ mean,
+                const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta, int relu) {
+    const int c4 = C >> 2;
+    const long long i = (long long)blockIdx.x * TT + threadIdx.x;
+    if (i >= M * c4) return;
+    const long long r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float alpha = rstd[c + k] * gamma[c + k];
+        const float bb = beta[c + k] - mean[c + k] * alpha;
+        const float o = in[k] * alpha + bb;
+        out[k] = relu ? fmaxf(o, 0.f) : o;
+    }
+    *reinterpret_cast<float4*>(y + r * ldy + c) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// dx = gamma * invstd * (dy' - sum(dy')/M - xhat * sum(dy' * xhat)/M); dgamma = sum(dy' * xhat); dbeta = sum(dy')
+__global__ void __launch_bounds__(TT)
+bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ dx, long long M, int C,
+                    int lddy, int ldx, int ldy, int lddx, const float* __restrict__ mean, const float* __restrict__ rstd,
+                    const float* __restrict__ gamma, const double* __restrict__ sums) {
+    const int c4 = C >> 2;
+    const long long i = (long long)blockIdx.x * TT + threadIdx.x;
+    if (i >= M * c4) return;
+    const long long r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    const float4 g4 = *reinterpret_cast<const float4*>(dy + r * lddy + c), x4 = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    float g[4] = {g4.x, g4.y, g4.z, g4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w}, o[4];
+    if (y) {
+        const float4 y4 = *reinterpret_cast<const float4*>(y + r * ldy + c);
+        const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (!(yv[k] > 0.f)) g[k] = 0.f;
+    }
+    const double invM = 1.0 / (double)M;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float xh = (xv[k] - mean[c + k]) * rstd[c + k];
+        const float m1 = (float)(sums[c + k] * invM), m2 = (float)(sums[C + c + k] * invM);
+        o[k] = gamma[c + k] * rstd[c + k] * (g[k] - m1 - xh * m2);
+    }
+    *reinterpret_cast<float4*>(dx + r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ void __launch_bounds__(TT) bn_param_grad_kernel(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * TT + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = (float)sums[c];
+    dgamma[c] = (float)sums[C + c];
+}
+
+// bias gradient of a conv: column sums of dY (MODE-0 partials, first sum only)
+__global__ void __launch_bounds__(TT) colsum_out_kernel(const double* __restrict__ sums, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * TT + threadIdx.x;
+    if (c < C) out[c] = (float)sums[c];
+}
+
+// ---- elementwise ---------------------------------------------------------------------------------------------------------------
+// y = relu?(a + b)  (Bottleneck: out = relu(bn3(conv3) + identity); decoder: z1 + z2 + z3 + z4 without ReLU)
+__global__ void __launch_bounds__(TT)
+add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long long M, int C, int lda, int ldb, int ldy, int relu) {
+    const int c4 = C >> 2;
+    const long long i = (long long)blockIdx.x * TT + threadIdx.x;
+    if (i >= M * c4) return;
+    const long long r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    const float4 u = *reinterpret_cast<const float4*>(a + r * lda + c), v = *reinterpret_cast<const float4*>(b + r * ldb + c);
+    float4 o = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    *reinterpret_cast<float4*>(y + r * ldy + c) = o;
+}
+
+// dx (=|+=) dy * (y > 0)   (y NULL: plain copy / accumulate)
+__global__ void __launch_bounds__(TT)
+relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long long M, int C, int lddy, int ldy, int lddx, int accumulate) {
+    const int c4 = C >> 2;
+    const long long i = (long long)blockIdx.x * TT + threadIdx.x;
+    if (i >= M * c4) return;
+    const long long r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+    if (y) {
+        const float4 v = *reinterpret_cast<const float4*>(y + r * ldy + c);
+        if (!(v.x > 0.f)) g.x = 0.f;
+        if (!(v.y > 0.f)) g.y = 0.f;
+        if (!(v.z > 0.f)) g.z = 0.f;
+        if (!(v.w > 0.f)) g.w = 0.f;
+    }
+    float4* d = reinterpret_cast<float4*>(dx + r * lddx + c);
+    if (accumulate) { const float4 o = *d; g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
+    *d = g;
+}
+
+// ---- max-pool 3x3 / stride 2 / pad 1 backward (gather, deterministic) -------------------------------------------------------------
+// An input pixel receives dy of every window whose FIRST maximum (scan order kh, kw like torch's CPU kernel) it is.
+__global__ void __launch_bounds__(TT)
+maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W, int C, int ldx, int lddy, int lddx) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long i = (long long)blockIdx.x * TT + threadIdx.x;
+    const long long total = (long long)B * H * W * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long long p = i / C;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc = 0.f;
+    for (int oy = h / 2; oy <= (h + 1) / 2; ++oy) {       // the windows with 2*oy-1 <= h <= 2*oy+1: one for even h, two for odd h
+        if (oy >= Ho) continue;
+        for (int ox = w / 2; ox <= (w + 1) / 2; ++ox) {
+            if (ox >= Wo) continue;
+            float best = -INFINITY;
+            int bh = -1, bw = -1;
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = 2 * oy - 1 + kh;
+                if (ih < 0 || ih >= H) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iw = 2 * ox - 1 + kw;
+                    if (iw < 0 || iw >= W) continue;
+                    const float v = x[(((long long)b * H + ih) * W + iw) * ldx + c];
+                    if (v > best || bh < 0) { best = v; bh = ih; bw = iw; }
+                }
+            }
+            if (bh == h && bw == w) acc += dy[(((long long)b * Ho + oy) * Wo + ox) * lddy + c];
+        }
+    }
+    dx[(((long long)b * H + h) * W + w) * lddx + c] = acc;
+}
+
+// ---- bilinear upsampling (align_corners = True) backward, gather form ------------------------------------------------------------
+// Forward (pointwise.hip / F.interpolate): src = dst * (in - 1) / (out - 1) in fp32, i0 = floor(src), i1 = min(i0 + 1, in - 1),
+// lambda = src - i0.  The input pixel (i, j) collects every output pixel that interpolated from it.
+__device__ inline void up_src(int d, int in, int out, int& i0, int& i1, float& lam) {
+    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float s = scale * (float)d;
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    lam = s - (float)i0;
+}
+__global__ void __launch_bounds__(TT)
+upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int h, int w, int C, int lddy, int lddx, int H, int W) {
+    const long long i = (long long)blockIdx.x * TT + threadIdx.x;
+    const long long total = (long long)B * h * w * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long long p = i / C;
+    const int jj = (int)(p % w); p /= w;
+    const int ii = (int)(p % h);
+    const int b = (int)(p / h);
+    // candidate output rows: src in (ii - 1, ii + 1)  ->  dst in ((ii-1)/scale, (ii+1)/scale); scanned with a margin of one
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    int Y0 = 0, Y1 = H - 1, X0 = 0, X1 = W - 1;
+    if (sy > 0.f) { Y0 = max(0, (int)floorf((float)(ii - 1) / sy) - 1); Y1 = min(H - 1, (int)ceilf((float)(ii + 1) / sy) + 1); }
+    if (sx > 0.f) { X0 = max(0, (int)floorf((float)(jj - 1) / sx) - 1); X1 = min(W - 1, (int)ceilf((float)(jj + 1) / sx) + 1); }
+    float acc = 0.f;
+    for (int Y = Y0; Y <= Y1; ++Y) {
+        int a0, a1; float ly;
+        up_src(Y, h, H, a0, a1, ly);
+        const float wy = (a0 == ii ? 1.f - ly : 0.f) + (a1 == ii ? ly : 0.f);
+        if (wy == 0.f) continue;
+        for (int X = X0; X <= X1; ++X) {
+            int b0, b1; float lx;
+            up_src(X, w, W, b0, b1, lx);
+            const float wx = (b0 == jj ? 1.f - lx : 0.f) + (b1 == jj ? lx : 0.f);
+            if (wx == 0.f) continue;
+            acc += wy * wx * dy[(((long long)b * H + Y) * W + X) * lddy + c];
+        }
+    }
+    dx[(((long long)b * h + ii) * w + jj) * lddx + c] = acc;
+}
+
+// ---- padded 1x1 head (depth_completion.py:141-147: Conv2d(192, 1, 1, padding=1)) backward -----------------------------------------
+// g_low: [B][h+2][w+2] gradient at the 62x82 map; x: NHWC [B][h][w][C].  dx[b,y,x,c] = g_low[b,y+1,x+1] * w[c]
+__global__ void __launch_bounds__(TT)
+head_dgrad_kernel(const float* __restrict__ g_low, const float* __restrict__ wgt, float* __restrict__ dx, int B, int h, int w, int C, int lddx) {
+    const long long i = (long long)blockIdx.x * TT + threadIdx.x;
+    const long long total = (long long)B * h * w * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long long p = i / C;
+    const int xx = (int)(p % w); p /= w;
+    const int yy = (int)(p % h);
+    const int b = (int)(p / h);
+    dx[(((long long)b * h + yy) * w + xx) * lddx + c] = g_low[((long long)b * (h + 2) + yy + 1) * (w + 2) + xx + 1] * wgt[c];
+}
+// dw[c] = sum g_low_interior * x[...,c]; one block per channel chunk would re-read g: here one thread per (chunk, c), partials in fp64
+__global__ void __launch_bounds__(TT)
+head_wgrad_partial_kernel(const float* __restrict__ g_low, const float* __restrict__ x, int B, int h, int w, int C, int ldx, int rows_per_chunk,
+                          double* __restrict__ partial) {
+    const int c = blockIdx.x * TT + threadIdx.x;
+    if (c >= C) return;
+    const long long M = (long long)B * h * w;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    double s = 0.0;
+    for (long long r = r0; r < r1; ++r) {
+        const int xx = (int)(r % w);
+        const long long q = r / w;
+        const int yy = (int)(q % h), b = (int)(q / h);
+        s += (double)g_low[((long long)b * (h + 2) + yy + 1) * (w + 2) + xx + 1] * (double)x[r * ldx + c];
+    }
+    partial[(size_t)blockIdx.y * C + c] = s;
+}
+__global__ void __launch_bounds__(TT) head_wgrad_final_kernel(const double* __restrict__ partial, int n_chunks, int C, float* __restrict__ dw) {
+    const int c = blockIdx.x * TT + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < n_chunks; ++k) s += partial[(size_t)k * C + c];
+    dw[c] = (float)s;
+}
+
+// ---- generic fixed-order sum of n floats (fp64): head bias gradient, loss ----------------------------------------------------------
+__global__ void __launch_bounds__(TT) sum_partial_kernel(const float* __restrict__ v, long long n, int per, double* __restrict__ partial) {
+    __shared__ double red[TT];
+    const long long base = (long long)blockIdx.x * TT * per;
+    double s = 0.0;
+    for (int k = 0; k < per; ++k) {
+        const long long i = base + (long long)k * TT + threadIdx.x;
+        if (i < n) s += (double)v[i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = TT / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(TT) sum_final_kernel(const double* __restrict__ partial, int n, double* __restrict__ out_d, float* __restrict__ out_f) {
+    __shared__ double red[TT];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += TT) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = TT / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { if (out_d) *out_d = red[0]; if (out_f) *out_f = (float)red[0]; }
+}
+
+// ---- masked L1 loss (network_run.py:163-173): terms |pred - gt| / (H*W) on gt > 0, and d loss / d pred ----------------------------
+__global__ void __launch_bounds__(TT)
+l1_loss_kernel(const float* __restrict__ pred, const float* __restrict__ gt, long long n, float inv_hw, float* __restrict__ terms, float* __restrict__ dpred) {
+    const long long i = (long long)blockIdx.x * TT + threadIdx.x;
+    if (i >= n) return;
+    const float g = gt[i], d = pred[i] - g;
+    const bool on = g > 0.f;
+    terms[i] = on ? fabsf(d) : 0.f;
+    dpred[i] = on ? (d > 0.f ? inv_hw : (d < 0.f ? -inv_hw : 0.f)) : 0.f;
+}
+
+// ---- Adam (torch.optim.Adam defaults: no weight decay, no amsgrad) on a flat parameter buffer -------------------------------------
+__global__ void __launch_bounds__(TT)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n, float lr, float b1, float b2,
+            float eps, float bc1, float bc2_sqrt) {
+    const long long i = (long long)blockIdx.x * TT + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = m[i] * b1 + gi * (1.f - b1);
+    const float vi = v[i] * b2 + gi * gi * (1.f - b2);
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+// ---- dgrad helpers -------------------------------------------------------------------------------------------------------------
+// Weights of the dgrad convolution, packed for conv_mfma.hip: the conv computing dX from dY has Cout' = Cin, Cin' = Cout and the
+// kernel flipped: wp[ci][co/32][KH-1-kh][KW-1-kw][co%32] = w[co][ci][kh][kw]  (wp is [Cout'][Cin'/32][KH][KW][32]).
+__global__ void __launch_bounds__(TT)
+pack_weight_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KH, int KW) {
+    const long long total = (long long)Cout * Cin * KH * KW;
+    const long long idx = (long long)blockIdx.x * TT + threadIdx.x;
+    if (idx >= total) return;
+    const int Kp = Cout * KH * KW;                     // K of the dgrad conv
+    const int ci = (int)(idx / Kp), k = (int)(idx - (long long)ci * Kp);
+    const int lane = k & 31, u = k >> 5, taps = KH * KW;
+    const int cu = u / taps, tap = u - cu * taps, kh = tap / KW, kw = tap - kh * KW, co = cu * 32 + lane;
+    wp[idx] = w[(((long long)co * Cin + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+}
+// z[b, oy*s, ox*s, :] = dy[b, oy, ox, :], zero elsewhere (z is B x H x W x C, dense)
+__global__ void __launch_bounds__(TT)
+zero_stuff_kernel(const float* __restrict__ dy, float* __restrict__ z, int B, int Ho, int Wo, int C, int lddy, int s, int H, int W) {
+    const int c4 = C >> 2;
+    const long long i = (long long)blockIdx.x * TT + threadIdx.x;
+    const long long total = (long long)B * H * W * c4;
+    if (i >= total) return;
+    const int c = (int)(i % c4) * 4;
+    long long p = i / c4;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y % s == 0 && x % s == 0 && y / s < Ho && x / s < Wo)
+        v = *reinterpret_cast<const float4*>(dy + (((long long)b * Ho + y / s) * Wo + x / s) * lddy + c);
+    *reinterpret_cast<float4*>(z + (((long long)b * H + y) * W + x) * C + c) = v;
+}
+
+// ---- wgrad: dW[co][ci][kh][kw] = sum_m dY[m][co] * X[pixel(m) shifted by the tap][ci] on the fp32 matrix cores ---------------------
+// v_mfma_f32_32x32x2_f32 with the reduction index = pixel: lane l supplies A[i = l & 31][k = l >> 5] = dY[m0 + (l >> 5)][co0 + (l & 31)]
+// and B[k][j] = X[.. m0 + (l >> 5) ..][ci0 + (l & 31)]: both are 32 consecutive channels of an NHWC row, i.e. coalesced 128-byte
+// loads straight from global memory, no transposition, no LDS.  One wave = one 32x32 (co, ci) tile of one tap over a range of pixels;
+// a workgroup = 4 waves = 2x2 tiles (64 co x 64 ci); grid = (co tiles, ci tiles * taps, pixel chunks).  Partials of the pixel chunks
+// are summed in chunk order by wgrad_final_kernel (deterministic), which also writes the OIHW layout of the parameter.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256)
+wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int lddy,
+             int KH, int KW, int stride, int pad, int rows_per_chunk, float* __restrict__ partial /* [chunk][tap][Cout][Cin] */) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int taps = KH * KW;
+    const int ci_tiles = (Cin + 63) / 64;
+    const int tap = blockIdx.y / ci_tiles, cit = blockIdx.y - tap * ci_tiles;
+    const int kh = tap / KW, kw = tap - kh * KW;
+    const int co = blockIdx.x * 64 + (wave >> 1) * 32 + li, ci = cit * 64 + (wave & 1) * 32 + li;
+    const bool co_ok = co < Cout, ci_ok = ci < Cin;
+    const long long M = (long long)B * Ho * Wo;
+    const long long m_begin = (long long)blockIdx.z * rows_per_chunk, m_end = min(M, m_begin + rows_per_chunk);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (long long m0 = m_begin; m0 < m_end; m0 += 16) {          // 8 MFMAs (2 pixels each) per iteration, 16 loads in flight per lane
+        float a[8], bv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const long long m = m0 + 2 * t + lh;
+            a[t] = 0.f; bv[t] = 0.f;
+            if (m < m_end) {
+                const int ox = (int)(m % Wo);
+                const long long q = m / Wo;
+                const int oy = (int)(q % Ho), b = (int)(q / Ho);
+                const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+                if (co_ok) a[t] = dy[m * lddy + co];
+                if (ci_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) bv[t] = x[(((long long)b * H + iy) * W + ix) * ldx + ci];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bv[t], acc, 0, 0, 0);
+    }
+    // C/D layout: col j = lane & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float* out = partial + ((size_t)blockIdx.z * taps + tap) * (size_t)Cout * Cin;
+    const int cj = cit * 64 + (wave & 1) * 32 + li;
+    if (cj < Cin) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = blockIdx.x * 64 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (ro < Cout) out[(size_t)ro * Cin + cj] = acc[r];
+        }
+    }
+}
+__global__ void __launch_bounds__(TT)
+wgrad_final_kernel(const float* __restrict__ partial, int n_chunks, int taps, int Cout, int Cin, float* __restrict__ dw /* OIHW */) {
+    const long long i = (long long)blockIdx.x * TT + threadIdx.x;            // index into [tap][Cout][Cin]
+    const long long per = (long long)taps * Cout * Cin;
+    if (i >= per) return;
+    float s = 0.f;
+    for (int k = 0; k < n_chunks; ++k) s += partial[(size_t)k * per + i];
+    const int ci = (int)(i % Cin);
+    const long long q = i / Cin;
+    const int co = (int)(q % Cout), tap = (int)(q / Cout);
+    dw[((long long)co * Cin + ci) * taps + tap] = s;
+}
+
+// stem conv (3x3, stride 2, pad 1, Cin = 1 or 3, NCHW input, no bias): dW[co][ci][kh][kw] = sum dY[m][co] * x[b][ci][2oy+kh-1][2ox+kw-1]
+__global__ void __launch_bounds__(TT)
+stem_wgrad_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x, int B, int Cin, int H, int W, int Ho, int Wo, int Cout, int lddy,
+                          int rows_per_chunk, double* __restrict__ partial /* [chunk][Cout*Cin*9] */) {
+    const int n = Cout * Cin * 9;
+    const int idx = blockIdx.x * TT + threadIdx.x;
+    if (idx >= n) return;
+    const int kw = idx % 3, kh = (idx / 3) % 3, ci = (idx / 9) % Cin, co = idx / (9 * Cin);
+    const long long M = (long long)B * Ho * Wo;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    double s = 0.0;
+    for (long long m = r0; m < r1; ++m) {
+        const int ox = (int)(m % Wo);
+        const long long q = m / Wo;
+        const int oy = (int)(q % Ho), b = (int)(q / Ho);
+        const int iy = 2 * oy - 1 + kh, ix = 2 * ox - 1 + kw;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            s += (double)dy[m * lddy + co] * (double)x[(((long long)b * Cin + ci) * H + iy) * W + ix];
+    }
+    partial[(size_t)blockIdx.y * n + idx] = s;
+}
+
+}  // namespace
+
+// ---- C ABI ----------------------------------------------------------------------------------------------------------------------
+namespace {
+inline int chunks_for(long long M) { return (int)((M + 2047) / 2048); }          // 2048 rows per chunk
+inline unsigned blocks(long long n) { return (unsigned)((n + TT - 1) / TT); }
+}
+
+extern "C" size_t vidc_train_scratch_bytes(long long M, int C) {
+    return ((size_t)chunks_for(M) * 2 * (size_t)C + 2 * (size_t)C) * sizeof(double) + 256;
+}
+
+extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
+                                     void* scratch, vidc_stream_t stream) {
+    VIDC_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && scratch, VIDC_ERR_NULL, "vidc_bn_train_forward: null pointer");
+    VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0, VIDC_ERR_SHAPE, "vidc_bn_train_forward: bad shape");
+    hipStream_t st = vidc::as_stream(stream);
+    const int nch = chunks_for(M);
+    double* partial = reinterpret_cast<double*>(scratch);
+    double* sums = partial + (size_t)nch * 2 * C;
+    hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, x, (const float*)nullptr, (const float*)nullptr, M, C, ldx, 0, 0,
+                       (const float*)nullptr, (const float*)nullptr, 2048, partial);
+    hipLaunchKernelGGL(chan_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, partial, nch, C, sums);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, sums, M, C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, x, y, M, C, ldx, ldy, save_mean, save_rstd, gamma, beta, relu);
+    VIDC_CHECK_LAUNCH("bn_train_forward");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_bn_train_backward(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
+                                      int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                                      void* scratch, vidc_stream_t stream) {
+    VIDC_REQUIRE(dy && x && dx && gamma && save_mean && save_rstd && dgamma && dbeta && scratch, VIDC_ERR_NULL, "vidc_bn_train_backward: null pointer");
+    VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!y_relu || ldy % 4 == 0), VIDC_ERR_SHAPE,
+                 "vidc_bn_train_backward: bad shape");
+    hipStream_t st = vidc::as_stream(stream);
+    const int nch = chunks_for(M);
+    double* partial = reinterpret_cast<double*>(scratch);
+    double* sums = partial + (size_t)nch * 2 * C;
+    hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean, save_rstd, 2048, partial);
+    hipLaunchKernelGGL(chan_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, partial, nch, C, sums);
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(blocks(C)), dim3(TT), 0, st, sums, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, save_mean, save_rstd,
+                       gamma, sums);
+    VIDC_CHECK_LAUNCH("bn_train_backward");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_colsum(const float* dy, long long M, int C, int ld, float* out, void* scratch, vidc_stream_t stream) {
+    VIDC_REQUIRE(dy && out && scratch, VIDC_ERR_NULL, "vidc_colsum: null pointer");
+    VIDC_REQUIRE(M > 0 && C > 0 && ld >= C, VIDC_ERR_SHAPE, "vidc_colsum: bad shape");
+    hipStream_t st = vidc::as_stream(stream);
+    const int nch = chunks_for(M);
+    double* partial = reinterpret_cast<double*>(scratch);
+    double* sums = partial + (size_t)nch * 2 * C;
+    hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, (const float*)nullptr, (const float*)nullptr, M, C, ld, 0, 0,
+                       (const float*)nullptr, (const float*)nullptr, 2048, partial);
+    hipLaunchKernelGGL(chan_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, partial, nch, C, sums);
+    hipLaunchKernelGGL(colsum_out_kernel, dim3(blocks(C)), dim3(TT), 0, st, sums, C, out);
+    VIDC_CHECK_LAUNCH("colsum");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_add_rows(const float* a, const float* b, float* y, long long M, int C, int lda, int ldb, int ldy, int relu, vidc_stream_t stream) {
+    VIDC_REQUIRE(a && b && y, VIDC_ERR_NULL, "vidc_add_rows: null pointer");
+    VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldy % 4 == 0, VIDC_ERR_SHAPE, "vidc_add_rows: bad shape");
+    hipLaunchKernelGGL(add_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, vidc::as_stream(stream), a, b, y, M, C, lda, ldb, ldy, relu);
+    VIDC_CHECK_LAUNCH("add_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_relu_backward(const float* dy, const float* y, float* dx, long long M, int C, int lddy, int ldy, int lddx, int accumulate,
+                                  vidc_stream_t stream) {
+    VIDC_REQUIRE(dy && dx, VIDC_ERR_NULL, "vidc_relu_backward: null pointer");
+    VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (!y || ldy % 4 == 0), VIDC_ERR_SHAPE, "vidc_relu_backward: bad shape");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, vidc::as_stream(stream), dy, y, dx, M, C, lddy, ldy, lddx, accumulate);
+    VIDC_CHECK_LAUNCH("relu_bwd_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int ldx, int lddy, int lddx,
+                                          vidc_stream_t stream) {
+    VIDC_REQUIRE(x && dy && dx, VIDC_ERR_NULL, "vidc_maxpool3x3s2_backward: null pointer");
+    VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, VIDC_ERR_SHAPE, "vidc_maxpool3x3s2_backward: bad shape");
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks((long long)B * H * W * C)), dim3(TT), 0, vidc::as_stream(stream), x, dy, dx, B, H, W, C, ldx, lddy, lddx);
+    VIDC_CHECK_LAUNCH("maxpool_bwd_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_upsample_bilinear_ac_backward(const float* dy, float* dx, int B, int h, int w, int C, int lddy, int lddx, int H, int W,
+                                                  vidc_stream_t stream) {
+    VIDC_REQUIRE(dy && dx, VIDC_ERR_NULL, "vidc_upsample_bilinear_ac_backward: null pointer");
+    VIDC_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0 && H > 0 && W > 0, VIDC_ERR_SHAPE, "vidc_upsample_bilinear_ac_backward: bad shape");
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(blocks((long long)B * h * w * C)), dim3(TT), 0, vidc::as_stream(stream), dy, dx, B, h, w, C, lddy, lddx, H, W);
+    VIDC_CHECK_LAUNCH("upsample_bwd_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_head_backward(const float* g_low, const float* x, const float* wgt, float* dx, float* dw, float* dbias, int B, int h, int w, int C,
+                                  int ldx, int lddx, void* scratch, vidc_stream_t stream) {
+    VIDC_REQUIRE(g_low && x && wgt && dx && dw && dbias && scratch, VIDC_ERR_NULL, "vidc_head_backward: null pointer");
+    VIDC_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0, VIDC_ERR_SHAPE, "vidc_head_backward: bad shape");
+    hipStream_t st = vidc::as_stream(stream);
+    const long long M = (long long)B * h * w;
+    const int nch = chunks_for(M);
+    double* partial = reinterpret_cast<double*>(scratch);
+    hipLaunchKernelGGL(head_dgrad_kernel, dim3(blocks(M * C)), dim3(TT), 0, st, g_low, wgt, dx, B, h, w, C, lddx);
+    hipLaunchKernelGGL(head_wgrad_partial_kernel, dim3(blocks(C), nch), dim3(TT), 0, st, g_low, x, B, h, w, C, ldx, 2048, partial);
+    hipLaunchKernelGGL(head_wgrad_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, partial, nch, C, dw);
+    const long long n = (long long)B * (h + 2) * (w + 2);
+    const int nb = (int)((n + (long long)TT * 16 - 1) / ((long long)TT * 16));
+    double* p2 = partial + (size_t)nch * C;
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(nb), dim3(TT), 0, st, g_low, n, 16, p2);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(TT), 0, st, p2, nb, (double*)nullptr, dbias);
+    VIDC_CHECK_LAUNCH("head_backward");
+    return VIDC_OK;
+}
+
+extern "C" size_t vidc_head_backward_scratch_bytes(int B, int h, int w, int C) {
+    const long long M = (long long)B * h * w;
+    const long long n = (long long)B * (h + 2) * (w + 2);
+    return ((size_t)chunks_for(M) * C + (size_t)((n + (long long)TT * 16 - 1) / ((long long)TT * 16)) + 8) * sizeof(double);
+}
+
+extern "C" int vidc_masked_l1_loss(const float* pred, const float* gt, long long n, int hw, double* loss, float* dpred, float* terms, void* scratch,
+                                   vidc_stream_t stream) {
+    VIDC_REQUIRE(pred && gt && loss && dpred && terms && scratch, VIDC_ERR_NULL, "vidc_masked_l1_loss: null pointer");
+    VIDC_REQUIRE(n > 0 && hw > 0, VIDC_ERR_SHAPE, "vidc_masked_l1_loss: bad shape");
+    hipStream_t st = vidc::as_stream(stream);
+    hipLaunchKernelGGL(l1_loss_kernel, dim3(blocks(n)), dim3(TT), 0, st, pred, gt, n, 1.0f / (float)hw, terms, dpred);
+    const int nb = (int)((n + (long long)TT * 16 - 1) / ((long long)TT * 16));
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(nb), dim3(TT), 0, st, terms, n, 16, reinterpret_cast<double*>(scratch));
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(TT), 0, st, reinterpret_cast<const double*>(scratch), nb, loss, (float*)nullptr);
+    VIDC_CHECK_LAUNCH("masked_l1_loss");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,
+                              vidc_stream_t stream) {
+    VIDC_REQUIRE(p && g && m && v, VIDC_ERR_NULL, "vidc_adam_step: null pointer");
+    VIDC_REQUIRE(n > 0 && step >= 1, VIDC_ERR_SHAPE, "vidc_adam_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks(n)), dim3(TT), 0, vidc::as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1,
+                       (float)sqrt(bc2));
+    VIDC_CHECK_LAUNCH("adam_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, vidc_stream_t stream) {
+    VIDC_REQUIRE(w_oihw && w_packed, VIDC_ERR_NULL, "vidc_pack_conv_weight_dgrad: null pointer");
+    VIDC_REQUIRE(Cout > 0 && Cout % 32 == 0 && Cin > 0 && KH > 0 && KW > 0, VIDC_ERR_SHAPE, "vidc_pack_conv_weight_dgrad: Cout must be a multiple of 32");
+    const long long total = (long long)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(pack_weight_dgrad_kernel, dim3(blocks(total)), dim3(TT), 0, vidc::as_stream(stream), w_oihw, w_packed, Cout, Cin, KH, KW);
+    VIDC_CHECK_LAUNCH("pack_weight_dgrad_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_zero_stuff(const float* dy, float* z, int B, int Ho, int Wo, int C, int lddy, int stride, int H, int W, vidc_stream_t stream) {
+    VIDC_REQUIRE(dy && z, VIDC_ERR_NULL, "vidc_zero_stuff: null pointer");
+    VIDC_REQUIRE(B > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && stride >= 1 && (Ho - 1) * stride < H && (Wo - 1) * stride < W,
+                 VIDC_ERR_SHAPE, "vidc_zero_stuff: bad shape");
+    hipLaunchKernelGGL(zero_stuff_kernel, dim3(blocks((long long)B * H * W * (C / 4))), dim3(TT), 0, vidc::as_stream(stream), dy, z, B, Ho, Wo, C, lddy,
+                       stride, H, W);
+    VIDC_CHECK_LAUNCH("zero_stuff_kernel");
+    return VIDC_OK;
+}
+
+namespace {
+inline int wgrad_rows_per_chunk(long long M, int Cout, int Cin, int taps) {
+    // enough workgroups to fill 256 CUs, chunks of at least 256 pixels (a multiple of 16)
+    const long long tiles = (long long)((Cout + 63) / 64) * ((Cin + 63) / 64) * taps;
+    long long chunks = (1024 + tiles - 1) / tiles;
+    if (chunks < 1) chunks = 1;
+    long long rows = (M + chunks - 1) / chunks;
+    if (rows < 256) rows = 256;
+    rows = (rows + 15) / 16 * 16;
+    return (int)rows;
+}
+}
+
+extern "C" size_t vidc_conv_wgrad_scratch_bytes(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW) {
+    const long long M = (long long)B * Ho * Wo;
+    const int rows = wgrad_rows_per_chunk(M, Cout, Cin, KH * KW);
+    const long long chunks = (M + rows - 1) / rows;
+    return (size_t)chunks * KH * KW * (size_t)Cout * Cin * sizeof(float);
+}
+
+extern "C" int vidc_conv_wgrad(const float* dy, const float* x, float* dw_oihw, int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int lddy,
+                               int KH, int KW, int stride, int pad, void* scratch, vidc_stream_t stream) {
+    VIDC_REQUIRE(dy && x && dw_oihw && scratch, VIDC_ERR_NULL, "vidc_conv_wgrad: null pointer");
+    VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0 && ldx >= Cin && lddy >= Cout,
+                 VIDC_ERR_SHAPE, "vidc_conv_wgrad: bad shape");
+    VIDC_REQUIRE(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1, VIDC_ERR_SHAPE, "vidc_conv_wgrad: Ho/Wo inconsistent");
+    hipStream_t st = vidc::as_stream(stream);
+    const long long M = (long long)B * Ho * Wo;
+    const int taps = KH * KW;
+    const int rows = wgrad_rows_per_chunk(M, Cout, Cin, taps);
+    const int chunks = (int)((M + rows - 1) / rows);
+    float* partial = reinterpret_cast<float*>(scratch);
+    hipLaunchKernelGGL(wgrad_kernel, dim3((Cout + 63) / 64, ((Cin + 63) / 64) * taps, chunks), dim3(256), 0, st, dy, x, B, H, W, Cin, ldx, Ho, Wo, Cout, lddy,
+                       KH, KW, stride, pad, rows, partial);
+    hipLaunchKernelGGL(wgrad_final_kernel, dim3(blocks((long long)taps * Cout * Cin)), dim3(TT), 0, st, partial, chunks, taps, Cout, Cin, dw_oihw);
+    VIDC_CHECK_LAUNCH("conv_wgrad");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_stem_wgrad(const float* dy, const float* x_nchw, float* dw_oihw, int B, int Cin, int H, int W, int Cout, int lddy, void* scratch,
+                               vidc_stream_t stream) {
+    VIDC_REQUIRE(dy && x_nchw && dw_oihw && scratch, VIDC_ERR_NULL, "vidc_stem_wgrad: null pointer");
+    VIDC_REQUIRE(B > 0 && Cin > 0 && Cin <= 4 && H > 0 && W > 0 && Cout > 0 && lddy >= Cout, VIDC_ERR_SHAPE, "vidc_stem_wgrad: bad shape");
+    hipStream_t st = vidc::as_stream(stream);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long M = (long long)B * Ho * Wo;
+    const int n = Cout * Cin * 9;
+    const int rows = 1024;
+    const int chunks = (int)((M + rows - 1) / rows);
+    double* partial = reinterpret_cast<double*>(scratch);
+    hipLaunchKernelGGL(stem_wgrad_partial_kernel, dim3(blocks(n), chunks), dim3(TT), 0, st, dy, x_nchw, B, Cin, H, W, Ho, Wo, Cout, lddy, rows, partial);
+    hipLaunchKernelGGL(head_wgrad_final_kernel, dim3(blocks(n)), dim3(TT), 0, st, partial, chunks, n, dw_oihw);
+    VIDC_CHECK_LAUNCH("stem_wgrad");
+    return VIDC_OK;
+}
+
+extern "C" size_t vidc_stem_wgrad_scratch_bytes(int B, int Cin, int H, int W, int Cout) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long M = (long long)B * Ho * Wo;
+    return (size_t)((M + 1023) / 1024) * (size_t)Cout * Cin * 9 * sizeof(double);
+}

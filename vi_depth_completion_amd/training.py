@@ -1,0 +1,404 @@
+"""Training step of the depth-completion network on the GPU (BASELINE configs[4]).
+
+`DepthCompletionTrainer(cnn, learning_rate).step(image, normal, depth_in, depth_gt)` is the body of the reference's
+`ImageNetworkRunInterface._run_training_iteration` (network_run.py:231-254) for `self.cnn = ModifiedFPN`:
+
+    cnn.train()                       BatchNorm on batch statistics, running statistics updated (momentum 0.1)
+    outputs = cnn(image, normals, depth_enriched)          (the three inputs are what `_call_cnn`, main.py:261-298, feeds the network;
+                                                            they do not depend on the trained parameters)
+    loss = L1Loss(sum)(pred[gt > 0], gt[gt > 0]) / (H*W)   network_run.py:163-173
+    loss.backward(); Adam(cnn.parameters(), lr).step()      network_run.py:228-229, 249-250
+
+Everything numeric is a libvidc.so kernel: forward convs = the inference MFMA kernel (csrc/conv_mfma.hip) with the raw bias instead of a
+folded BatchNorm, data gradients = the same kernel on flipped/transposed weights, weight gradients / BatchNorm / pooling / upsampling /
+head / loss / Adam = csrc/train.hip.  PyTorch provides device memory, the parameter containers (the module keeps its reference
+state_dict layout; parameters and their .grad become views of two flat buffers) and, across GPUs, `torch.distributed.all_reduce` of
+the flat gradient buffer (RCCL): frames shard over ranks, every rank normalises BatchNorm over ITS frames (what the reference's
+DataParallel replicas do as well) and gradients are SUMMED, which equals the reference's single loss over the whole batch.
+There is no CPU path.  Arithmetic: exact fp32 MFMA products (VIDC_PREC_FP32) for all three conv passes."""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .networks.fpn_decoder import _BRANCH_PLAN
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+class Act:
+    """An activation: NHWC rows `t` (B,H,W,C view, possibly a channel slice of a wider buffer) + its gradient (same geometry)."""
+    __slots__ = ("t", "grad")
+
+    def __init__(self, t):
+        self.t, self.grad = t, None
+
+    @property
+    def ld(self):
+        return self.t.stride(2)
+
+    @property
+    def rows(self):
+        return self.t.shape[0] * self.t.shape[1] * self.t.shape[2]
+
+
+def _ld(t):
+    return t.stride(2)
+
+
+class GradientBuckets:
+    """The flat gradient buffer cut into buckets for the cross-rank SUM (one collective per bucket, ~64 MB each: large enough that a
+    ring all-reduce over xGMI runs at link speed, small enough to start before the whole backward has finished if overlapped)."""
+
+    def __init__(self, n_elements, bucket_elements=16 * 1024 * 1024):
+        self.ranges = [(a, min(n_elements, a + bucket_elements)) for a in range(0, n_elements, bucket_elements)]
+
+    def all_reduce(self, flat):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return flat
+        for a, b in self.ranges:
+            dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM)
+        return flat
+
+
+class DepthCompletionTrainer:
+    def __init__(self, cnn, learning_rate=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DepthCompletionTrainer needs a GPU: the HIP path has no CPU fallback")
+        self.cnn = cnn
+        self.lr, self.betas, self.eps = float(learning_rate), betas, float(eps)
+        self.named = [(k, p) for k, p in cnn.named_parameters()]
+        dev = self.named[0][1].device
+        if dev.type != "cuda":
+            raise RuntimeError("move the network to the GPU before building the trainer")
+        self.device = dev
+        n = sum(p.numel() for _, p in self.named)
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.param, self.grad = {}, {}
+        o = 0
+        for k, p in self.named:            # parameters and gradients become views of the flat buffers (one Adam launch, bucketed all-reduce)
+            k_n = p.numel()
+            self.flat_p[o:o + k_n].copy_(p.detach().reshape(-1))
+            p.data = self.flat_p[o:o + k_n].view(p.shape)
+            p.grad = self.flat_g[o:o + k_n].view(p.shape)
+            self.param[k], self.grad[k] = p.data, p.grad
+            o += k_n
+        self.buf = {k: b for k, b in cnn.named_buffers()}
+        self.buckets = GradientBuckets(n)
+        self.step_count = 0
+        self._ones, self._zeros, self._packed, self._scratch = {}, {}, {}, None
+        self.last_loss = None
+
+    # ---- small helpers ------------------------------------------------------------------------------------------------------
+    def _const(self, store, n, value):
+        if n not in store:
+            store[n] = torch.full((n,), value, dtype=torch.float32, device=self.device)
+        return store[n]
+
+    def _scratch_bytes(self, nbytes):
+        if self._scratch is None or self._scratch.numel() < nbytes:
+            self._scratch = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
+        return self._scratch
+
+    def _train_scratch(self, M, Cc):
+        return self._scratch_bytes(L.lib().vidc_train_scratch_bytes(M, Cc))
+
+    def _empty(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    # ---- conv: forward, dgrad, wgrad --------------------------------------------------------------------------------------------
+    def _conv_call(self, x_t, w_packed, shift, y_t, kh, kw, stride, pad, relu, accumulate):
+        B, H, W, cin = x_t.shape
+        _, Ho, Wo, cout = y_t.shape
+        d = L.ConvDesc()
+        d.x, d.w, d.y = L.ptr(x_t), L.ptr(w_packed), L.ptr(y_t)
+        d.scale1, d.shift1 = L.ptr(self._const(self._ones, cout, 1.0)), L.ptr(shift)
+        d.B, d.H, d.W, d.Cin, d.ldx = B, H, W, cin, _ld(x_t)
+        d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, cout, _ld(y_t)
+        d.KH, d.KW, d.stride, d.pad = kh, kw, stride, pad
+        d.flags = (L.RELU1 if relu else 0) | (L.ACCUM if accumulate else 0)
+        d.groups, d.splitk, d.precision, d.tile = 1, 1, L.PREC_FP32, 0
+        d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, cout * kh * kw * cin, cout, cout
+        L.check(L.lib().vidc_conv2d_plan(C.byref(d)), "conv plan")
+        d.splitk = 1
+        L.check(L.lib().vidc_conv2d_bn_act(C.byref(d), L.current_stream()), "conv")
+
+    def conv(self, x, key, stride=1, pad=0, relu=False, out=None):
+        """nn.Conv2d (+ReLU when no BatchNorm sits in between, depth_completion.py:141-142).  Records its backward."""
+        w = self.param[key + ".weight"]
+        bias = self.param.get(key + ".bias")
+        co, ci, kh, kw = w.shape
+        B, H, W, _ = x.t.shape
+        Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        wp = self._packed.setdefault((key, "f"), self._empty(co, kh * kw * ci))
+        L.check(L.lib().vidc_pack_conv_weight(L.ptr(w), L.ptr(wp), co, ci, kh, kw, L.current_stream()), "pack")
+        y = Act(out if out is not None else self._empty(B, Ho, Wo, co))
+        self._conv_call(x.t, wp, bias if bias is not None else self._const(self._zeros, co, 0.0), y.t, kh, kw, stride, pad, relu, False)
+
+        def backward():
+            g = y.grad
+            if relu:                                         # y = relu(conv): mask first
+                gm = self._empty(B, Ho, Wo, co)
+                L.check(L.lib().vidc_relu_backward(L.ptr(g), L.ptr(y.t), L.ptr(gm), y.rows, co, _ld(g), y.ld, co, 0, L.current_stream()), "relu_bwd")
+                g = gm
+            lib = L.lib()
+            # weight gradient (fp32 MFMA over the pixels) and bias gradient (column sums)
+            sc = self._scratch_bytes(lib.vidc_conv_wgrad_scratch_bytes(B, Ho, Wo, co, ci, kh, kw))
+            L.check(lib.vidc_conv_wgrad(L.ptr(g), L.ptr(x.t), L.ptr(self.grad[key + ".weight"]), B, H, W, ci, x.ld, Ho, Wo, co, _ld(g), kh, kw, stride, pad,
+                                        L.ptr(sc), L.current_stream()), "wgrad")
+            if bias is not None:
+                L.check(lib.vidc_colsum(L.ptr(g), y.rows, co, _ld(g), L.ptr(self.grad[key + ".bias"]), L.ptr(self._train_scratch(y.rows, co)),
+                                        L.current_stream()), "colsum")
+            if x.grad is False:                              # network input: no data gradient wanted
+                return
+            # data gradient: the conv kernel on flipped / transposed weights; a strided conv spreads dY over the input grid first
+            wd = self._packed.setdefault((key, "d"), self._empty(ci, kh * kw * co))
+            L.check(lib.vidc_pack_conv_weight_dgrad(L.ptr(w), L.ptr(wd), co, ci, kh, kw, L.current_stream()), "pack_dgrad")
+            gz = g
+            if stride > 1:
+                gz = self._empty(B, H, W, co)
+                L.check(lib.vidc_zero_stuff(L.ptr(g), L.ptr(gz), B, Ho, Wo, co, _ld(g), stride, H, W, L.current_stream()), "zero_stuff")
+            acc = x.grad is not None
+            if not acc:
+                x.grad = self._empty(B, H, W, ci)
+            self._conv_call(gz, wd, self._const(self._zeros, ci, 0.0), x.grad, kh, kw, 1, kh - 1 - pad, False, acc)
+
+        self.tape.append(backward)
+        return y
+
+    # ---- BatchNorm (train mode) + ReLU ---------------------------------------------------------------------------------------------
+    def bn(self, x, key, relu, out=None):
+        Cc = x.t.shape[-1]
+        y = Act(out if out is not None else torch.empty_like(x.t))
+        mean, rstd = self._empty(Cc), self._empty(Cc)
+        gamma, beta = self.param[key + ".weight"], self.param[key + ".bias"]
+        L.check(L.lib().vidc_bn_train_forward(L.ptr(x.t), L.ptr(y.t), x.rows, Cc, x.ld, y.ld, L.ptr(gamma), L.ptr(beta), L.ptr(self.buf[key + ".running_mean"]),
+                                              L.ptr(self.buf[key + ".running_var"]), BN_EPS, BN_MOMENTUM, int(relu), L.ptr(mean), L.ptr(rstd),
+                                              L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_forward")
+        self.buf[key + ".num_batches_tracked"] += 1
+
+        def backward():
+            acc = x.grad is not None
+            dx = self._empty(*x.t.shape) if acc else None
+            target = dx if acc else self._empty(*x.t.shape)
+            L.check(L.lib().vidc_bn_train_backward(L.ptr(y.grad), L.ptr(x.t), L.ptr(y.t) if relu else None, L.ptr(target), x.rows, Cc, _ld(y.grad), x.ld, y.ld,
+                                                   Cc, L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(self.grad[key + ".weight"]), L.ptr(self.grad[key + ".bias"]),
+                                                   L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_backward")
+            if acc:
+                self._accumulate(x, target)
+            else:
+                x.grad = target
+
+        self.tape.append(backward)
+        return y
+
+    def _accumulate(self, x, g):
+        """x.grad += g (or = g when none yet; g is then shared, not copied: nothing writes it afterwards)."""
+        if x.grad is None:
+            x.grad = g
+            return
+        Cc = x.t.shape[-1]
+        L.check(L.lib().vidc_relu_backward(L.ptr(g), None, L.ptr(x.grad), x.rows, Cc, _ld(g), 0, _ld(x.grad), 1, L.current_stream()), "accumulate")
+
+    def add(self, a, b, relu, out=None):
+        Cc = a.t.shape[-1]
+        y = Act(out if out is not None else self._empty(*a.t.shape))
+        L.check(L.lib().vidc_add_rows(L.ptr(a.t), L.ptr(b.t), L.ptr(y.t), a.rows, Cc, a.ld, b.ld, y.ld, int(relu), L.current_stream()), "add")
+
+        def backward():
+            g = y.grad
+            if relu:
+                gm = self._empty(*a.t.shape)
+                L.check(L.lib().vidc_relu_backward(L.ptr(g), L.ptr(y.t), L.ptr(gm), a.rows, Cc, _ld(g), y.ld, Cc, 0, L.current_stream()), "relu_bwd")
+                g = gm
+            self._accumulate(a, g)
+            self._accumulate(b, g)
+
+        self.tape.append(backward)
+        return y
+
+    def maxpool(self, x):
+        B, H, W, Cc = x.t.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = Act(self._empty(B, Ho, Wo, Cc))
+        L.check(L.lib().vidc_maxpool3x3s2(L.ptr(x.t), L.ptr(y.t), B, H, W, Cc, x.ld, Cc, None, L.current_stream()), "maxpool")
+
+        def backward():
+            dx = self._empty(B, H, W, Cc)
+            L.check(L.lib().vidc_maxpool3x3s2_backward(L.ptr(x.t), L.ptr(y.grad), L.ptr(dx), B, H, W, Cc, x.ld, _ld(y.grad), Cc, L.current_stream()), "maxpool_bwd")
+            self._accumulate(x, dx)
+
+        self.tape.append(backward)
+        return y
+
+    def upsample(self, x, size):
+        B, h, w, Cc = x.t.shape
+        y = Act(self._empty(B, size[0], size[1], Cc))
+        L.check(L.lib().vidc_upsample_bilinear_ac(L.ptr(x.t), L.ptr(y.t), B, h, w, Cc, x.ld, size[0], size[1], Cc, 0, None, L.current_stream()), "upsample")
+
+        def backward():
+            dx = self._empty(B, h, w, Cc)
+            L.check(L.lib().vidc_upsample_bilinear_ac_backward(L.ptr(y.grad), L.ptr(dx), B, h, w, Cc, _ld(y.grad), Cc, size[0], size[1], L.current_stream()),
+                    "upsample_bwd")
+            self._accumulate(x, dx)
+
+        self.tape.append(backward)
+        return y
+
+    # ---- network walk (depth_completion.py:16-65, 154-165) ----------------------------------------------------------------------
+    def _stem(self, x_nchw, p, out_channels=64):
+        w = self.param[p + "conv1.conv1_1.weight"]
+        B, cin, H, W = x_nchw.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = Act(self._empty(B, Ho, Wo, out_channels))
+        L.check(L.lib().vidc_stem_conv3x3s2(L.ptr(x_nchw), L.ptr(w), L.ptr(y.t), B, cin, H, W, out_channels, out_channels, 1, None, 0, L.current_stream()), "stem")
+
+        def backward():
+            g = self._empty(B, Ho, Wo, out_channels)
+            L.check(L.lib().vidc_relu_backward(L.ptr(y.grad), L.ptr(y.t), L.ptr(g), y.rows, out_channels, _ld(y.grad), out_channels, out_channels, 0,
+                                               L.current_stream()), "relu_bwd")
+            sc = self._scratch_bytes(L.lib().vidc_stem_wgrad_scratch_bytes(B, cin, H, W, out_channels))
+            L.check(L.lib().vidc_stem_wgrad(L.ptr(g), L.ptr(x_nchw), L.ptr(self.grad[p + "conv1.conv1_1.weight"]), B, cin, H, W, out_channels, out_channels,
+                                            L.ptr(sc), L.current_stream()), "stem_wgrad")
+
+        self.tape.append(backward)
+        return y
+
+    def _bottleneck(self, x, p, stride, project, out=None):
+        t = self.bn(self.conv(x, p + "conv1"), p + "bn1", True)
+        t = self.bn(self.conv(t, p + "conv2", stride, 1), p + "bn2", True)
+        t = self.bn(self.conv(t, p + "conv3"), p + "bn3", False)
+        idn = self.bn(self.conv(x, p + "downsample.0", stride, 0), p + "downsample.1", False) if project else x
+        return self.add(t, idn, True, out=out)
+
+    def _pyramid(self, x_nchw, p, module, level_out):
+        """ResNetPyramids.forward (depth_completion.py:55-65) in train mode; level l's output goes to `level_out[l]` (a channel slice of
+        the concat buffer, depth_completion.py:151-152)."""
+        t = self._stem(x_nchw, p)
+        t = self.bn(self.conv(t, p + "conv1.conv1_2", 1, 1), p + "conv1.bn_2", True)
+        t = self.bn(self.conv(t, p + "conv1.conv1_3", 1, 1), p + "conv1.bn1_3", True)
+        t = self.bn(t, p + "bn1", True)
+        t = self.maxpool(t)
+        outs = []
+        for li in range(1, 5):
+            stage = getattr(module, "layer%d" % li)
+            for bi, blk in enumerate(stage):
+                last = bi == len(stage) - 1
+                t = self._bottleneck(t, "%slayer%d.%d." % (p, li, bi), blk.stride, blk.downsample is not None, out=level_out[li - 1] if last else None)
+            outs.append(t)
+        return outs
+
+    def forward(self, image, normal, depth_in):
+        """Train-mode forward; returns the predicted depth (B,1,H,W).  The tape of backward closures is left in self.tape."""
+        self.tape = []
+        B, _, H, W = image.shape
+        sizes = [((H - 1) // 2 + 1, (W - 1) // 2 + 1)]
+        sizes[0] = ((sizes[0][0] - 1) // 2 + 1, (sizes[0][1] - 1) // 2 + 1)
+        for _ in range(3):
+            sizes.append(((sizes[-1][0] - 1) // 2 + 1, (sizes[-1][1] - 1) // 2 + 1))
+        chans = [256, 512, 1024, 2048]
+        cat = [self._empty(B, sizes[l][0], sizes[l][1], 3 * chans[l]) for l in range(4)]
+        levels = [Act(c) for c in cat]
+        subs = []
+        for pi, (name, x) in enumerate((("resnet_rgb", image), ("resnet_normal", normal), ("resnet_depth", depth_in))):
+            outs = [cat[l][..., pi * chans[l]:(pi + 1) * chans[l]] for l in range(4)]
+            subs.append(self._pyramid(x.contiguous().float(), name + ".", getattr(self.cnn, name), outs))
+
+        def split_level_grads():                     # runs (in the backward) once the decoder has produced d(concat): slices become the
+            for l in range(4):                       # gradients of the three pyramids' level outputs
+                for pi in range(3):
+                    g = levels[l].grad[..., pi * chans[l]:(pi + 1) * chans[l]]
+                    subs[pi][l].grad = g if subs[pi][l].grad is None else subs[pi][l].grad
+        # NB: appended BEFORE the decoder ops, so it runs after all of them in the reversed tape; a level's slice is also fed by the next
+        # stage of its pyramid, whose backward (later in the reversed order) accumulates into the same slice.
+        self.tape.append(split_level_grads)
+
+        zs = []
+        for b in (1, 2, 3, 4):
+            t = levels[b - 1]
+            idx, target = 0, b
+            for step in _BRANCH_PLAN[b]:
+                q = "feature%d_upsamping.%d" % (b, idx)
+                if step == "u":
+                    target -= 1
+                    t = self.upsample(t, sizes[target - 1])
+                    idx += 1
+                else:
+                    k = step[0]
+                    t = self.bn(self.conv(t, q, 1, k // 2), "feature%d_upsamping.%d" % (b, idx + 1), True)
+                    idx += 3
+            zs.append(t)
+        z = self.add(self.add(self.add(zs[0], zs[1], False), zs[2], False), zs[3], False)
+        h = self.conv(z, "feature_concat.0", 1, 1, relu=True)
+        # padded 1x1 head -> bilinear to (H, W) -> ReLU (depth_completion.py:143-147)
+        w2, b2 = self.param["feature_concat.2.weight"], self.param["feature_concat.2.bias"]
+        hh, hw_ = h.t.shape[1], h.t.shape[2]
+        low = self._empty(B, 1, hh + 2, hw_ + 2)
+        pred = self._empty(B, 1, H, W)
+        L.check(L.lib().vidc_head_conv1x1_upsample(L.ptr(h.t), L.ptr(w2), L.ptr(b2), L.ptr(low), L.ptr(pred), B, hh, hw_, 192, h.ld, 1, 1, H, W, 1,
+                                                   L.current_stream()), "head")
+        self._pred_grad = None
+
+        def head_backward():
+            lib = L.lib()
+            n = B * H * W
+            g = self._empty(n)
+            L.check(lib.vidc_relu_backward(L.ptr(self._pred_grad), L.ptr(pred), L.ptr(g), n // 4, 4, 4, 4, 4, 0, L.current_stream()), "relu_bwd")
+            g_low = self._empty(B, hh + 2, hw_ + 2)
+            L.check(lib.vidc_upsample_bilinear_ac_backward(L.ptr(g), L.ptr(g_low), B, hh + 2, hw_ + 2, 1, 1, 1, H, W, L.current_stream()), "upsample_bwd")
+            h.grad = self._empty(B, hh, hw_, 192)
+            sc = self._scratch_bytes(lib.vidc_head_backward_scratch_bytes(B, hh, hw_, 192))
+            L.check(lib.vidc_head_backward(L.ptr(g_low), L.ptr(h.t), L.ptr(w2), L.ptr(h.grad), L.ptr(self.grad["feature_concat.2.weight"]),
+                                           L.ptr(self.grad["feature_concat.2.bias"]), B, hh, hw_, 192, h.ld, 192, L.ptr(sc), L.current_stream()), "head_bwd")
+
+        self.tape.append(head_backward)
+        self._pred = pred
+        return pred
+
+    def loss_and_backward(self, pred, depth_gt):
+        """network_run.py:163-173 + `total_loss.backward()`: fills the flat gradient buffer; returns the loss (0-dim fp64 GPU tensor)."""
+        B, _, H, W = pred.shape
+        n = pred.numel()
+        gt = depth_gt.contiguous().float()
+        loss = torch.zeros((), dtype=torch.float64, device=self.device)
+        self._pred_grad = self._empty(n)
+        terms = self._empty(n)
+        sc = self._scratch_bytes((n // 512 + 64) * 8)
+        L.check(L.lib().vidc_masked_l1_loss(L.ptr(pred), L.ptr(gt), n, H * W, L.ptr(loss), L.ptr(self._pred_grad), L.ptr(terms), L.ptr(sc), L.current_stream()),
+                "loss")
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+        return loss
+
+    @torch.no_grad()
+    def forward_backward(self, image, normal, depth_in, depth_gt):
+        for t in (image, normal, depth_in, depth_gt):
+            if not t.is_cuda:
+                raise RuntimeError("DepthCompletionTrainer takes GPU tensors only (no CPU fallback)")
+        if not self.cnn.training:
+            raise RuntimeError("call cnn.train() first (network_run.py:232): the trainer implements BatchNorm's train() mode")
+        pred = self.forward(image.float(), normal.float(), depth_in.float())
+        loss = self.loss_and_backward(pred, depth_gt)
+        return loss, pred
+
+    @torch.no_grad()
+    def optimizer_step(self):
+        """torch.optim.Adam.step over the flat buffers; gradients are summed over ranks first (frame-sharded batch)."""
+        self.buckets.all_reduce(self.flat_g)
+        self.step_count += 1
+        L.check(L.lib().vidc_adam_step(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.m), L.ptr(self.v), self.flat_p.numel(), self.lr, self.betas[0],
+                                       self.betas[1], self.eps, self.step_count, L.current_stream()), "adam")
+        self.cnn._invalidate()          # the inference programs' packed / BN-folded copies are stale now
+
+    def step(self, image, normal, depth_in, depth_gt):
+        """One `_run_training_iteration`: returns the loss (0-dim fp64 GPU tensor, this rank's frames)."""
+        loss, _ = self.forward_backward(image, normal, depth_in, depth_gt)
+        self.optimizer_step()
+        self.last_loss = loss
+        return loss
