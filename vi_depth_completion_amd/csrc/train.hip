@@ -330,7 +330,7 @@ l1_loss_kernel(const float* __restrict__ pred, const float* __restrict__ gt, lon
     if (i >= n) return;
     const float g = gt[i], d = pred[i] - g;
     const bool on = g > 0.f;
-    terms[i] = on ? fabsf(d) : 0.f;
+    terms[i] = on ? fabsf(d) * inv_hw : 0.f;
     dpred[i] = on ? (d > 0.f ? inv_hw : (d < 0.f ? -inv_hw : 0.f)) : 0.f;
 }
 
@@ -436,12 +436,12 @@ wgrad_final_kernel(const float* __restrict__ partial, int n_chunks, int taps, in
     const long long i = (long long)blockIdx.x * TT + threadIdx.x;            // index into [tap][Cout][Cin]
     const long long per = (long long)taps * Cout * Cin;
     if (i >= per) return;
-    float s = 0.f;
-    for (int k = 0; k < n_chunks; ++k) s += partial[(size_t)k * per + i];
+    double s = 0.0;
+    for (int k = 0; k < n_chunks; ++k) s += (double)partial[(size_t)k * per + i];
     const int ci = (int)(i % Cin);
     const long long q = i / Cin;
     const int co = (int)(q % Cout), tap = (int)(q / Cout);
-    dw[((long long)co * Cin + ci) * taps + tap] = s;
+    dw[((long long)co * Cin + ci) * taps + tap] = (float)s;
 }
 
 // stem conv (3x3, stride 2, pad 1, Cin = 1 or 3, NCHW input, no bias): dW[co][ci][kh][kw] = sum dY[m][co] * x[b][ci][2oy+kh-1][2ox+kw-1]
@@ -642,7 +642,8 @@ inline int wgrad_rows_per_chunk(long long M, int Cout, int Cin, int taps) {
     if (chunks < 1) chunks = 1;
     long long rows = (M + chunks - 1) / chunks;
     if (rows < 256) rows = 256;
-    rows = (rows + 15) / 16 * 16;
+    if (rows > 1024) rows = 1024;       // short fp32 accumulation chains (the partials are then summed in fp64): keeps dW within ~1e-4 of an
+    rows = (rows + 15) / 16 * 16;       // fp64 evaluation even where the sum over 10^4..10^5 pixels cancels heavily
     return (int)rows;
 }
 }
