@@ -266,8 +266,26 @@ def test_training_iteration_vs_reference(golden_dir, seeded_weights):
         check_probe(f, "grad", k, tr.grad[k].cpu(), 5e-4 if tight else 2e-2, 1e-7)
     tr.optimizer_step()
     torch.cuda.synchronize()
+    # First Adam step: every weight moves by lr * g / (|g| + 1e-8) ~ lr * sign(g).  Where the gradient is well above its noise floor
+    # (> 5 % of the tensor's largest entry) the sign is certain and the stepped value must match to 1e-6; elsewhere a sign flip of a
+    # near-zero gradient moves the value by up to 2 * lr = 2e-4 on either side, which is all that can be asserted there.
+    lr = float(f["lr"])
+    n_certain = 0
     for k in names:
-        check_probe(f, "new", k, tr.param[k].cpu(), 1e-6, 3e-5)      # (see tests/test_oracle_golden.py on the first Adam step's conditioning)
+        key, t = "|%s|" % k, tr.param[k].cpu().reshape(-1)
+        if "new" + key + "full" in f.files:
+            new, gref, got = f["new" + key + "full"], f["grad" + key + "full"], t.numpy()
+        else:
+            new, gref, got = f["new" + key + "val"], f["grad" + key + "val"], t[torch.from_numpy(f["new" + key + "idx"])].numpy()
+        assert np.abs(got - new).max() < 2.1 * lr, (k, np.abs(got - new).max())
+        if np.abs(gref).max() < 1e-7:          # bias in front of a BatchNorm: the whole gradient is rounding noise around 0
+            continue
+        certain = np.abs(gref) > 0.05 * np.abs(gref).max()
+        n_certain += int(certain.sum())
+        assert np.abs(got - new)[certain].max() < 1e-6, (k, np.abs(got - new)[certain].max())
+        old = f["old" + key + ("full" if "old" + key + "full" in f.files else "val")]
+        assert np.abs(np.abs(got - old)[certain] - lr).max() < 2e-6, k                    # ... and it did move by lr
+    assert n_certain > 1000
     sd = cnn.state_dict()
     for k in [k[4:] for k in f.files if k.startswith("buf|")]:
         assert np.abs(sd[k].cpu().numpy() - f["buf|" + k]).max() < 1e-4 * max(1.0, np.abs(f["buf|" + k]).max()), k
