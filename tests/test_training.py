@@ -110,6 +110,7 @@ def test_conv_bn_relu_block_gradients(cin, cout, k, stride, pad, H, W):
     with torch.no_grad():
         xa = Act(_nhwc(x).to(DEV))
         y = tr.bn(tr.conv(xa, "0", stride, pad), "1", True)
+        tr.flush_counters()
         y.grad = _nhwc(gw).to(DEV)
         _run_tape(tr)
     _close(_nchw(y.t), yr, 2e-5, "forward")

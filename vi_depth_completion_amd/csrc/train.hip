@@ -470,7 +470,8 @@ stem_wgrad_partial_kernel(const float* __restrict__ dy, const float* __restrict_
 
 // ---- C ABI ----------------------------------------------------------------------------------------------------------------------
 namespace {
-inline int chunks_for(long long M) { return (int)((M + 2047) / 2048); }          // 2048 rows per chunk
+constexpr int kRowsPerChunk = 256;        // rows per workgroup of the per-channel reductions: M = 10^4..10^5 rows -> hundreds of workgroups per 64 channels
+inline int chunks_for(long long M) { return (int)((M + kRowsPerChunk - 1) / kRowsPerChunk); }
 inline unsigned blocks(long long n) { return (unsigned)((n + TT - 1) / TT); }
 }
 
@@ -488,7 +489,7 @@ extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int 
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, x, (const float*)nullptr, (const float*)nullptr, M, C, ldx, 0, 0,
-                       (const float*)nullptr, (const float*)nullptr, 2048, partial);
+                       (const float*)nullptr, (const float*)nullptr, kRowsPerChunk, partial);
     hipLaunchKernelGGL(chan_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, partial, nch, C, sums);
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, sums, M, C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, x, y, M, C, ldx, ldy, save_mean, save_rstd, gamma, beta, relu);
@@ -506,7 +507,7 @@ extern "C" int vidc_bn_train_backward(const float* dy, const float* x, const flo
     const int nch = chunks_for(M);
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
-    hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean, save_rstd, 2048, partial);
+    hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean, save_rstd, kRowsPerChunk, partial);
     hipLaunchKernelGGL(chan_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, partial, nch, C, sums);
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3(blocks(C)), dim3(TT), 0, st, sums, C, dgamma, dbeta);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, save_mean, save_rstd,
@@ -523,7 +524,7 @@ extern "C" int vidc_colsum(const float* dy, long long M, int C, int ld, float* o
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, (const float*)nullptr, (const float*)nullptr, M, C, ld, 0, 0,
-                       (const float*)nullptr, (const float*)nullptr, 2048, partial);
+                       (const float*)nullptr, (const float*)nullptr, kRowsPerChunk, partial);
     hipLaunchKernelGGL(chan_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, partial, nch, C, sums);
     hipLaunchKernelGGL(colsum_out_kernel, dim3(blocks(C)), dim3(TT), 0, st, sums, C, out);
     VIDC_CHECK_LAUNCH("colsum");
@@ -574,7 +575,7 @@ extern "C" int vidc_head_backward(const float* g_low, const float* x, const floa
     const int nch = chunks_for(M);
     double* partial = reinterpret_cast<double*>(scratch);
     hipLaunchKernelGGL(head_dgrad_kernel, dim3(blocks(M * C)), dim3(TT), 0, st, g_low, wgt, dx, B, h, w, C, lddx);
-    hipLaunchKernelGGL(head_wgrad_partial_kernel, dim3(blocks(C), nch), dim3(TT), 0, st, g_low, x, B, h, w, C, ldx, 2048, partial);
+    hipLaunchKernelGGL(head_wgrad_partial_kernel, dim3(blocks(C), nch), dim3(TT), 0, st, g_low, x, B, h, w, C, ldx, kRowsPerChunk, partial);
     hipLaunchKernelGGL(head_wgrad_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, partial, nch, C, dw);
     const long long n = (long long)B * (h + 2) * (w + 2);
     const int nb = (int)((n + (long long)TT * 16 - 1) / ((long long)TT * 16));

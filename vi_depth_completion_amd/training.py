@@ -91,7 +91,7 @@ class DepthCompletionTrainer:
         self.buf = {k: b for k, b in cnn.named_buffers()}
         self.buckets = GradientBuckets(n)
         self.step_count = 0
-        self._ones, self._zeros, self._packed, self._scratch = {}, {}, {}, None
+        self._ones, self._zeros, self._packed, self._scratch, self._nbt = {}, {}, {}, None, []
         self.last_loss = None
 
     # ---- small helpers ------------------------------------------------------------------------------------------------------
@@ -180,7 +180,7 @@ class DepthCompletionTrainer:
         L.check(L.lib().vidc_bn_train_forward(L.ptr(x.t), L.ptr(y.t), x.rows, Cc, x.ld, y.ld, L.ptr(gamma), L.ptr(beta), L.ptr(self.buf[key + ".running_mean"]),
                                               L.ptr(self.buf[key + ".running_var"]), BN_EPS, BN_MOMENTUM, int(relu), L.ptr(mean), L.ptr(rstd),
                                               L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_forward")
-        self.buf[key + ".num_batches_tracked"] += 1
+        self._nbt.append(self.buf[key + ".num_batches_tracked"])
 
         def backward():
             acc = x.grad is not None
@@ -196,6 +196,12 @@ class DepthCompletionTrainer:
 
         self.tape.append(backward)
         return y
+
+    def flush_counters(self):
+        """Every BatchNorm's num_batches_tracked += 1 for the forward just recorded, in one launch (bookkeeping, not arithmetic)."""
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)
+        self._nbt = []
 
     def _accumulate(self, x, g):
         """x.grad += g (or = g when none yet; g is then shared, not copied: nothing writes it afterwards)."""
@@ -295,7 +301,7 @@ class DepthCompletionTrainer:
 
     def forward(self, image, normal, depth_in):
         """Train-mode forward; returns the predicted depth (B,1,H,W).  The tape of backward closures is left in self.tape."""
-        self.tape = []
+        self.tape, self._nbt = [], []
         B, _, H, W = image.shape
         sizes = [((H - 1) // 2 + 1, (W - 1) // 2 + 1)]
         sizes[0] = ((sizes[0][0] - 1) // 2 + 1, (sizes[0][1] - 1) // 2 + 1)
@@ -358,6 +364,7 @@ class DepthCompletionTrainer:
 
         self.tape.append(head_backward)
         self._pred = pred
+        self.flush_counters()
         return pred
 
     def loss_and_backward(self, pred, depth_gt):
