@@ -611,13 +611,17 @@ def test_dense_depth_input_in_the_pipeline(pipeline, seeded_weights):
     masks = [S.plane_id_map(240, 320)]
     intr = _intr()
     ref = O.call_cnn(seeded_weights["sn"], seeded_weights["dc"], batch, masks, intr, 200, rng=np.random.RandomState(8))
-    pipeline.rng = np.random.RandomState(8)
-    got = pipeline._call_cnn(batch).cpu()
-    assert float((got - ref).pow(2).mean().sqrt()) < 1e-3
-    pipeline.rng = np.random.RandomState(8)
-    dev_batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
-    outs = [o.cpu() for o in pipeline.run_interleaved(iter([dev_batch]))]
-    assert float((outs[0] - ref).pow(2).mean().sqrt()) < 1e-3
+    saved = pipeline.rng
+    try:
+        pipeline.rng = np.random.RandomState(8)
+        got = pipeline._call_cnn(batch).cpu()
+        assert float((got - ref).pow(2).mean().sqrt()) < 1e-3
+        pipeline.rng = np.random.RandomState(8)
+        dev_batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        outs = [o.cpu() for o in pipeline.run_interleaved(iter([dev_batch]))]
+        assert float((outs[0] - ref).pow(2).mean().sqrt()) < 1e-3
+    finally:
+        pipeline.rng = saved          # the module-scoped pipeline draws from np.random in the golden tests
 
 
 def test_enriched_samples_zero_skips_the_plane_block(pipeline, seeded_weights):
