@@ -43,7 +43,40 @@ def test_roi_align_oracle_basics():
     assert np.all(D.roi_align_forward(x, np.array([[0, 100.0, 100.0, 120.0, 120.0]], np.float32), 1.0, 2, 2, 2) == 0)
 
 
+# Hand-computed known answers for the bilinear edge cases of the reference's kernel (csrc/cpu/ROIAlign_cpu.cpp:20-110; the reference has
+# no ROIAlign test of its own and its C++ does not build against this PyTorch): feature f[y][x] = 10*y + x on a 4x4 map, ONE sample per
+# ROI (pooled 1x1, sampling_ratio 1) at the ROI's centre.  (sample x, sample y) -> expected value:
+ROI_KAT = [((1.25, 2.5), 26.25),      # interior: plain bilinear (a linear image is reproduced exactly)
+           ((-0.5, -0.5), 0.0),       # -1 <= coordinate <= 0: clamped to 0 (:62-67)  -> f[0][0]
+           ((1.5, 3.6), 31.5),        # y_low >= height-1: y_high = y_low = last row, y = 3 (:74-79)  -> 30 + 1.5
+           ((3.0, 3.0), 33.0),        # exactly on the last pixel -> f[3][3]
+           ((3.7, 3.9), 33.0),        # both coordinates beyond the last pixel centre but inside the map -> f[3][3]
+           ((1.5, 4.5), 0.0),         # y > height: the sample contributes nothing (:45-59)
+           ((-1.5, 2.0), 0.0)]        # x < -1: nothing
+
+
+def _kat_inputs():
+    f = (10.0 * np.arange(4, dtype=np.float32)[:, None] + np.arange(4, dtype=np.float32)[None, :]).reshape(1, 1, 4, 4)
+    rois = np.array([[0, cx - 0.5, cy - 0.5, cx + 0.5, cy + 0.5] for (cx, cy), _ in ROI_KAT], np.float32)      # width = height = 1 -> centre sample
+    return f, rois, np.array([v for _, v in ROI_KAT], np.float32)
+
+
+def test_roi_align_oracle_known_answers():
+    f, rois, want = _kat_inputs()
+    got = D.roi_align_forward(f, rois, 1.0, 1, 1, 1).reshape(-1)
+    assert np.abs(got - want).max() < 1e-5, (got, want)
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_roi_align_known_answers():
+    from vi_depth_completion_amd import detector
+    f, rois, want = _kat_inputs()
+    x = np.repeat(f, 32, axis=1)                    # the kernel puts lanes along channels: 32 identical channels
+    got = detector.roi_align(torch.from_numpy(x).cuda(), torch.from_numpy(rois).cuda(), (1, 1), 1.0, 1).cpu().numpy()
+    assert got.shape == (len(want), 32, 1, 1)
+    assert np.abs(got[:, :, 0, 0] - want[:, None]).max() < 1e-5
+
 @gpu
 def test_hip_nms_reference_vectors():
     from vi_depth_completion_amd import detector

@@ -295,3 +295,32 @@ def test_training_iteration_vs_reference(golden_dir, seeded_weights):
     cnn.eval()
     out = cnn(image[:1].to(DEV), normal[:1].to(DEV), depth_in[:1].to(DEV))
     assert torch.isfinite(out).all()
+
+
+@gpu
+def test_training_loop_on_pipeline_inputs(seeded_weights):
+    """The binding INTEGRATION.md shows: the pipeline produces what `_call_cnn` feeds the depth network (image, predicted normals,
+    enriched depth), the trainer runs `_run_training_iteration` on it; four iterations on one batch bring the loss down, the parameters
+    stay views of the flat buffer, and the stepped network serves inference again (BatchNorm running statistics included)."""
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    from vi_depth_completion_amd.training import DepthCompletionTrainer
+    pipe = DepthCompletionPipeline(enriched_samples=200, rng=np.random.RandomState(3))
+    pipe.load_state_dicts(seeded_weights["sn"], seeded_weights["dc"])
+    pipe.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(240, 320))
+    batch = S.synthetic_batch(2, 240, 320, 1234, frame0=50)
+    gt = S.synthetic_ground_truth_depth(batch["image"], 1234).to(DEV)
+    rgb, normals, depth_in = pipe.network_inputs(batch)
+    assert rgb.shape == (2, 3, 240, 320) and normals.shape == (2, 3, 240, 320) and depth_in.shape == (2, 1, 240, 320)
+    assert int((depth_in > 0).sum()) > int((batch["sparse_depth"] > 0).sum())          # enriched
+    before = pipe._call_cnn(batch).clone()
+    pipe.cnn.train()
+    tr = DepthCompletionTrainer(pipe.cnn, 1e-4)
+    losses = [float(tr.step(rgb, normals, depth_in, gt)) for _ in range(4)]
+    print("losses", losses)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    p = dict(pipe.cnn.named_parameters())["feature_concat.0.weight"]
+    assert p.data_ptr() == tr.param["feature_concat.0.weight"].data_ptr() and p.grad.data_ptr() == tr.grad["feature_concat.0.weight"].data_ptr()
+    pipe.cnn.eval()
+    pipe.rng = np.random.RandomState(3)
+    after = pipe._call_cnn(batch)
+    assert torch.isfinite(after).all() and float((after - before).abs().mean()) > 1e-4      # the trained weights are the ones that run

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["VIDC_CHAIN"] = "1"          # the chain is opt-in
 sys.path.insert(0, ROOT)
 from vi_depth_completion_amd import _lib as L, synthetic as S  # noqa: E402
 from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN  # noqa: E402

@@ -170,6 +170,17 @@ class DepthCompletionPipeline:
         return self.cnn.enqueue(st["rgb"], st["normals"], depth_in, slot)
 
     @torch.no_grad()
+    def network_inputs(self, input_batch):
+        """(image, predicted normals, enriched sparse depth): exactly what `_call_cnn` hands to `self.cnn` (main.py:262-296), as fresh
+        tensors -- the inputs of a training iteration (`training.DepthCompletionTrainer.step`; network_run.py:236 calls `_call_cnn`,
+        whose only trained part is that last network).  The surface-normal network runs in eval mode here."""
+        st = self._stage1(input_batch)
+        depth_in = st["ds"]
+        if st["di"] is not None:
+            depth_in = self.planes.enrich(st["ds"], st["di"], st["nnz"], self.args.enriched_samples, rng=st["rng"])
+        return st["rgb"], st["normals"].clone(), depth_in.clone()
+
+    @torch.no_grad()
     def _call_cnn(self, input_batch, taps=None):
         st = self._stage1(input_batch)
         out = self._stage2(st).clone()
