@@ -387,49 +387,75 @@ zero_stuff_kernel(const float* __restrict__ dy, float* __restrict__ z, int B, in
 // a workgroup = 4 waves = 2x2 tiles (64 co x 64 ci); grid = (co tiles, ci tiles * taps, pixel chunks).  Partials of the pixel chunks
 // are summed in chunk order by wgrad_final_kernel (deterministic), which also writes the OIHW layout of the parameter.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// One wave = a 64 x 64 (co, ci) register tile (2 x 2 MFMA tiles: 4 loads feed 4 MFMAs); a workgroup = 4 waves = 128 co x 128 ci.
 __global__ void __launch_bounds__(256)
 wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int B, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int lddy,
              int KH, int KW, int stride, int pad, int rows_per_chunk, float* __restrict__ partial /* [chunk][tap][Cout][Cin] */) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     const int taps = KH * KW;
-    const int ci_tiles = (Cin + 63) / 64;
+    const int ci_tiles = (Cin + 127) / 128;
     const int tap = blockIdx.y / ci_tiles, cit = blockIdx.y - tap * ci_tiles;
     const int kh = tap / KW, kw = tap - kh * KW;
-    const int co = blockIdx.x * 64 + (wave >> 1) * 32 + li, ci = cit * 64 + (wave & 1) * 32 + li;
-    const bool co_ok = co < Cout, ci_ok = ci < Cin;
+    const int co0 = blockIdx.x * 128 + (wave >> 1) * 64, ci0 = cit * 128 + (wave & 1) * 64;
+    const int co[2] = {co0 + li, co0 + 32 + li}, ci[2] = {ci0 + li, ci0 + 32 + li};
     const long long M = (long long)B * Ho * Wo;
     const long long m_begin = (long long)blockIdx.z * rows_per_chunk, m_end = min(M, m_begin + rows_per_chunk);
-    f32x16 acc;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (long long m0 = m_begin; m0 < m_end; m0 += 16) {          // 8 MFMAs (2 pixels each) per iteration, 16 loads in flight per lane
-        float a[8], bv[8];
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const long long m = m0 + 2 * t + lh;
-            a[t] = 0.f; bv[t] = 0.f;
-            if (m < m_end) {
-                const int ox = (int)(m % Wo);
-                const long long q = m / Wo;
-                const int oy = (int)(q % Ho), b = (int)(q / Ho);
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
+    // The pixel index of a lane advances by fixed steps, so (b, oy, ox) of the chunk's first pixel is decoded ONCE (wave-uniform: scalar
+    // unit) and every lane walks from there with compares -- the first version divided twice per lane and pixel in 64-bit arithmetic,
+    // ~10x the instructions of the MFMAs they fed.  Offsets are 32-bit (the host checks that both tensors stay below 2^31 elements).
+    const int m_lo = (int)m_begin, m_hi = (int)m_end;
+    int ox0 = m_lo % Wo, oy0 = (m_lo / Wo) % Ho, b0 = m_lo / (Wo * Ho);
+    for (int m0 = m_lo; m0 < m_hi; m0 += 8) {           // 4 pixel pairs x (2 x 2) MFMAs per iteration, 16 loads in flight per lane
+        float a[4][2], bv[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int m = m0 + 2 * t + lh;
+            int ox = ox0 + 2 * t + lh, oy = oy0, b = b0;
+            while (ox >= Wo) { ox -= Wo; ++oy; }
+            while (oy >= Ho) { oy -= Ho; ++b; }
+            a[t][0] = a[t][1] = bv[t][0] = bv[t][1] = 0.f;
+            if (m < m_hi) {
                 const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
-                if (co_ok) a[t] = dy[m * lddy + co];
-                if (ci_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) bv[t] = x[(((long long)b * H + iy) * W + ix) * ldx + ci];
+                const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const int xo = ((b * H + iy) * W + ix) * ldx;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    if (co[p] < Cout) a[t][p] = dy[m * lddy + co[p]];
+                    if (inside && ci[p] < Cin) bv[t][p] = x[xo + ci[p]];
+                }
             }
         }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bv[t], acc, 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][p], bv[t][q], acc[p][q], 0, 0, 0);
+        ox0 += 8;
+        while (ox0 >= Wo) { ox0 -= Wo; ++oy0; }
+        while (oy0 >= Ho) { oy0 -= Ho; ++b0; }
     }
     // C/D layout: col j = lane & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     float* out = partial + ((size_t)blockIdx.z * taps + tap) * (size_t)Cout * Cin;
-    const int cj = cit * 64 + (wave & 1) * 32 + li;
-    if (cj < Cin) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ro = blockIdx.x * 64 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (ro < Cout) out[(size_t)ro * Cin + cj] = acc[r];
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int cj = ci0 + q * 32 + li;
+            if (cj >= Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = co0 + p * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ro < Cout) out[(size_t)ro * Cin + cj] = acc[p][q][r];
+            }
         }
-    }
 }
 __global__ void __launch_bounds__(TT)
 wgrad_final_kernel(const float* __restrict__ partial, int n_chunks, int taps, int Cout, int Cin, float* __restrict__ dw /* OIHW */) {
@@ -638,13 +664,13 @@ extern "C" int vidc_zero_stuff(const float* dy, float* z, int B, int Ho, int Wo,
 namespace {
 inline int wgrad_rows_per_chunk(long long M, int Cout, int Cin, int taps) {
     // enough workgroups to fill 256 CUs, chunks of at least 256 pixels (a multiple of 16)
-    const long long tiles = (long long)((Cout + 63) / 64) * ((Cin + 63) / 64) * taps;
+    const long long tiles = (long long)((Cout + 127) / 128) * ((Cin + 127) / 128) * taps;
     long long chunks = (1024 + tiles - 1) / tiles;
     if (chunks < 1) chunks = 1;
     long long rows = (M + chunks - 1) / chunks;
     if (rows < 256) rows = 256;
     if (rows > 1024) rows = 1024;       // short fp32 accumulation chains (the partials are then summed in fp64): keeps dW within ~1e-4 of an
-    rows = (rows + 15) / 16 * 16;       // fp64 evaluation even where the sum over 10^4..10^5 pixels cancels heavily
+    rows = (rows + 7) / 8 * 8;          // fp64 evaluation even where the sum over 10^4..10^5 pixels cancels heavily
     return (int)rows;
 }
 }
@@ -662,13 +688,15 @@ extern "C" int vidc_conv_wgrad(const float* dy, const float* x, float* dw_oihw, 
     VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0 && ldx >= Cin && lddy >= Cout,
                  VIDC_ERR_SHAPE, "vidc_conv_wgrad: bad shape");
     VIDC_REQUIRE(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1, VIDC_ERR_SHAPE, "vidc_conv_wgrad: Ho/Wo inconsistent");
+    VIDC_REQUIRE((long long)B * H * W * ldx < (1ll << 31) && (long long)B * Ho * Wo * lddy < (1ll << 31), VIDC_ERR_SHAPE,
+                 "vidc_conv_wgrad: tensors must stay below 2^31 elements (32-bit offsets)");
     hipStream_t st = vidc::as_stream(stream);
     const long long M = (long long)B * Ho * Wo;
     const int taps = KH * KW;
     const int rows = wgrad_rows_per_chunk(M, Cout, Cin, taps);
     const int chunks = (int)((M + rows - 1) / rows);
     float* partial = reinterpret_cast<float*>(scratch);
-    hipLaunchKernelGGL(wgrad_kernel, dim3((Cout + 63) / 64, ((Cin + 63) / 64) * taps, chunks), dim3(256), 0, st, dy, x, B, H, W, Cin, ldx, Ho, Wo, Cout, lddy,
+    hipLaunchKernelGGL(wgrad_kernel, dim3((Cout + 127) / 128, ((Cin + 127) / 128) * taps, chunks), dim3(256), 0, st, dy, x, B, H, W, Cin, ldx, Ho, Wo, Cout, lddy,
                        KH, KW, stride, pad, rows, partial);
     hipLaunchKernelGGL(wgrad_final_kernel, dim3(blocks((long long)taps * Cout * Cin)), dim3(TT), 0, st, partial, chunks, taps, Cout, Cin, dw_oihw);
     VIDC_CHECK_LAUNCH("conv_wgrad");
