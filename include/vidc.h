@@ -335,6 +335,11 @@ int vidc_det_stem_im2col(const float* image01_nchw, float* cols, int B, int H, i
                          float mean_r, vidc_stream_t stream);
 /* F.interpolate(x, scale_factor=2, mode="nearest") of the FPN top-down path (modeling/backbone/fpn.py:66-72), NHWC. */
 int vidc_upsample_nearest2x(const float* x, float* y, int B, int h, int w, int C, int ldx, int ldy, vidc_stream_t stream);
+
+/* The `use_mask=True` branch of SurfaceNormalPrediction.forward (networks/surface_normal.py:150-162): y = x * mask, where mask =
+ * (r + g + b > 1e-2) of the warped image (NCHW [B][3][H][W]) nearest-resized to the h x w feature map x (NHWC); the mask is not stored. */
+int vidc_mask_scale(const float* x, const float* image_nchw, float* y, int B, int h, int w, int C, int ldx, int ldy, int H, int W,
+                    vidc_stream_t stream);
 /* RPNPostProcessor.forward_for_single_feature_map up to NMS (modeling/rpn/inference.py:74-100): rpn_map [B][h][w][ld] holds A objectness
  * logits then 4A box deltas per pixel; sigmoid, the k = min(pre_nms_top_n, A*h*w) best in descending order (ties: lower (h,w,a) index
  * first), anchors (cell_anchors_host [A][4], host memory, + the pixel's stride offset), BoxCoder(1,1,1,1).decode, clip to the image.
@@ -460,7 +465,7 @@ int vidc_chain_destroy(vidc_chain* chain);
 enum vidc_op_kind { VIDC_OP_CONV = 1, VIDC_OP_STEM = 2, VIDC_OP_MAXPOOL = 3, VIDC_OP_UPSAMPLE = 4, VIDC_OP_HEAD = 5,
                     VIDC_OP_WARP_PARAMS = 6, VIDC_OP_WARP_FWD = 7, VIDC_OP_WARP_INV = 8, VIDC_OP_COPY = 9, VIDC_OP_SPLIT = 10,
                     VIDC_OP_AVGPOOL = 11, VIDC_OP_NORMALIZE = 12, VIDC_OP_DET_IM2COL = 13, VIDC_OP_NEAREST2X = 14,
-                    VIDC_OP_CHAIN = 15 /* g.p[0] = vidc_chain* */ };
+                    VIDC_OP_CHAIN = 15 /* g.p[0] = vidc_chain* */, VIDC_OP_MASK = 16 /* vidc_mask_scale: p = x, image, y; i = B,h,w,C,ldx,ldy,H,W */ };
 
 typedef struct vidc_generic_args {   /* arguments of the non-conv launchers, in declaration order */
     const void* p[6];

@@ -208,8 +208,8 @@ _BRANCHES = {
 }
 
 
-def fpn_decoder(levels, sd, p, final_size, head_pad, final_relu, taps=None):
-    """levels: [x1..x4].  Returns the full-resolution head output."""
+def fpn_decoder(levels, sd, p, final_size, head_pad, final_relu, taps=None, sum_mask=None):
+    """levels: [x1..x4].  Returns the full-resolution head output.  sum_mask: multiplied into z1+z2+z3+z4 (use_mask branch)."""
     sizes = {i + 1: tuple(t.shape[-2:]) for i, t in enumerate(levels)}
     zsum = None
     for b in (1, 2, 3, 4):
@@ -227,6 +227,8 @@ def fpn_decoder(levels, sd, p, final_size, head_pad, final_relu, taps=None):
         if taps is not None:
             taps["z%d" % b] = t
         zsum = t if zsum is None else zsum + t
+    if sum_mask is not None:
+        zsum = zsum * sum_mask
     h = F.relu(_conv(zsum, sd, p + "feature_concat.0", 1, 1))
     h = _conv(h, sd, p + "feature_concat.2", 1, head_pad)
     if taps is not None:
@@ -235,10 +237,16 @@ def fpn_decoder(levels, sd, p, final_size, head_pad, final_relu, taps=None):
     return F.relu(h) if final_relu else h
 
 
-def surface_normal_forward(sd, x, g, a, intr, align_corners=False, taps=None):
+def surface_normal_forward(sd, x, g, a, intr, align_corners=False, taps=None, use_mask=False):
     _, xw = warp_forward(x, g, a, intr, align_corners)
     levels = resnet_pyramids(xw, sd, "resnet_pyramids.")
-    y = fpn_decoder(levels, sd, "", (intr.H, intr.W), 0, False, taps)
+    sum_mask = None
+    if use_mask:          # networks/surface_normal.py:150-162
+        fm = (xw[:, 0:1] + xw[:, 1:2] + xw[:, 2:3] > 1e-2).float()
+        masks = [F.interpolate(fm, size=tuple(t.shape[-2:]), mode="nearest") for t in levels]
+        levels = [t * m for t, m in zip(levels, masks)]
+        sum_mask = masks[0]
+    y = fpn_decoder(levels, sd, "", (intr.H, intr.W), 0, False, taps, sum_mask=sum_mask)
     _, z = warp_inverse_normals(y, g, a, intr, align_corners)
     if taps is not None:
         taps.update(warped=xw, x1=levels[0], x2=levels[1], x3=levels[2], x4=levels[3], normal_raw=y)

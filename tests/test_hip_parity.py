@@ -783,3 +783,27 @@ def test_modules_refuse_cpu_and_training(pipeline):
     with pytest.raises(RuntimeError, match="inference-only"):
         pipeline.cnn(torch.zeros(1, 3, 240, 320, device=DEV), torch.zeros(1, 3, 240, 320, device=DEV), torch.zeros(1, 1, 240, 320, device=DEV))
     pipeline.cnn.eval()
+
+
+def test_use_mask_branch(golden_dir, seeded_weights):
+    """`SurfaceNormalPrediction(use_mask=True)` (networks/surface_normal.py:150-162): features of the four pyramid levels and their
+    sum are zeroed where the warped image is empty (vidc_mask_scale).  HIP vs the reference's golden output and vs the oracle, in the
+    module's own program and in the software-pipelined frame program.  Tolerances as for the unmasked network."""
+    from vi_depth_completion_amd.networks.surface_normal import SurfaceNormalPrediction
+    f = np.load(os.path.join(golden_dir, "sn_use_mask.npz"))
+    b = S.synthetic_batch(1, 240, 320, 1234, frame0=int(f["frame0"]))
+    g, a = torch.from_numpy(f["gravity"]), torch.from_numpy(f["aligned"])
+    sn = SurfaceNormalPrediction(fc_img=np.array([202.0, 202.0]), use_mask=True).to(DEV).eval()
+    st = sn.state_dict()
+    st.update({k: v.to(DEV) for k, v in seeded_weights["sn"].items()})
+    sn.load_state_dict(st)
+    n = sn(b["image"].to(DEV), g.to(DEV), a.to(DEV)).cpu()
+    assert any(name == "mask_scale" for name in sn.program(1, torch.device(DEV)).op_names)
+    d = np.abs(n[0, :, ::4, ::4].numpy() - f["normals_sub"])
+    assert d.max() < 2e-3 and d.mean() < 5e-5, (d.max(), d.mean())
+    ref = O.surface_normal_forward(seeded_weights["sn"], b["image"], g, a, _intr(), use_mask=True)
+    e = (n - ref).abs()
+    assert e.max() < 2e-3 and e.mean() < 5e-5
+    sn.use_mask = False
+    sn._invalidate()
+    assert float((sn(b["image"].to(DEV), g.to(DEV), a.to(DEV)).cpu() - n).abs().max()) > 0.5      # the branch matters on this frame

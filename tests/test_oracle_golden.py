@@ -161,3 +161,14 @@ def test_train_oracle_matches_reference_training_iteration(golden_dir, seeded_we
         check_probe(f, "old", k, sd[k], 0.0, 0.0)
     for k in [k[4:] for k in f.files if k.startswith("buf|")]:
         assert np.abs(bufs[k].numpy() - f["buf|" + k]).max() < 1e-6 * max(1.0, np.abs(f["buf|" + k]).max())
+
+
+def test_use_mask_branch_oracle_vs_reference(golden_dir, seeded_weights):
+    """`SurfaceNormalPrediction(use_mask=True)` (networks/surface_normal.py:150-162; off in the shipped pipeline): the restatement
+    against the reference module's own output on a strongly tilted frame (oracle/tools/make_golden_usemask.py)."""
+    f = np.load(os.path.join(golden_dir, "sn_use_mask.npz"))
+    b = S.synthetic_batch(1, 240, 320, 1234, frame0=int(f["frame0"]))
+    intr = O.Intrinsics(202.0, 202.0, 0.5 * 319.87654, 0.5 * 239.87603)
+    n = O.surface_normal_forward(seeded_weights["sn"], b["image"], torch.from_numpy(f["gravity"]), torch.from_numpy(f["aligned"]), intr, use_mask=True)
+    assert np.abs(n[0, :, ::4, ::4].numpy() - f["normals_sub"]).max() < 2e-4      # (the warp grids differ by fp32 rounding, DESIGN §2)
+    assert float(f["diff_vs_unmasked"]) > 0.5

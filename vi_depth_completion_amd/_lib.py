@@ -20,7 +20,7 @@ MAX_SEGMENTS = 4
 # vidc_conv_flags / vidc_up_flags / vidc_op_kind / vidc_conv_tile
 RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM, SPLIT_OUT, NO_F32_OUT = 1, 2, 4, 8, 16, 32, 64, 128
 UP_RELU, UP_ACCUM, UP_NO_F32_OUT = 1, 2, 4
-OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY, OP_SPLIT, OP_AVGPOOL, OP_NORMALIZE, OP_DET_IM2COL, OP_NEAREST2X, OP_CHAIN = range(1, 16)
+OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY, OP_SPLIT, OP_AVGPOOL, OP_NORMALIZE, OP_DET_IM2COL, OP_NEAREST2X, OP_CHAIN, OP_MASK = range(1, 17)
 TILE_AUTO = 0
 TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "64x64k2", 6: "32x64k2", 7: "32x32k4", 8: "32x128",
               9: "32x32k8", 10: "32x64k2d5", 11: "32x32k4d4", 12: "32x128d6", 13: "64x64k2d4", 14: "32x64k2L", 15: "32x64k2d5L", 16: "32x32k4d4L", 17: "64x64L", 18: "64x64k2d4L",
@@ -129,6 +129,7 @@ SIGNATURES = {
     "vidc_roi_align_forward": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "vidc_det_stem_im2col": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
     "vidc_upsample_nearest2x": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "vidc_mask_scale": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_rpn_topk_decode": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, C.c_longlong, _vp]),
     "vidc_rpn_topk_decode_levels": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, C.c_longlong, _vp]),
     "vidc_rpn_select": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),

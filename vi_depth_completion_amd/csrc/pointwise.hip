@@ -304,3 +304,41 @@ extern "C" int vidc_head_conv1x1_upsample(const float* x, const float* w, const 
     VIDC_CHECK_LAUNCH("head_upsample_kernel");
     return VIDC_OK;
 }
+
+// ---- use_mask branch of SurfaceNormalPrediction.forward (networks/surface_normal.py:150-162) ---------------------------------------
+// feature_mask = (r + g + b > 1e-2) of the WARPED image, nearest-resized to the feature map (F.interpolate(mode='nearest'):
+// src = min(floor(dst * in / out), in - 1) with the scale in fp32), multiplied into the features.  One launch: the mask is never stored.
+namespace {
+__global__ void __launch_bounds__(256)
+mask_scale_kernel(const float* __restrict__ x, const float* __restrict__ img, float* __restrict__ y, int B, int h, int w, int C, int ldx, int ldy,
+                  int H, int W) {
+    const int c4 = C >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * h * w * c4;
+    if (i >= total) return;
+    const int c = (int)(i % c4) * 4;
+    long long p = i / c4;
+    const int xx = (int)(p % w); p /= w;
+    const int yy = (int)(p % h);
+    const int b = (int)(p / h);
+    const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+    const int iy = min((int)floorf((float)yy * sy), H - 1), ix = min((int)floorf((float)xx * sx), W - 1);
+    const float* ib = img + (size_t)b * 3 * H * W + (size_t)iy * W + ix;
+    const float m = (ib[0] + ib[(size_t)H * W] + ib[2 * (size_t)H * W] > 1e-2f) ? 1.f : 0.f;
+    const size_t row = ((size_t)b * h + yy) * w + xx;
+    const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+    *reinterpret_cast<float4*>(y + row * ldy + c) = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
+}
+}  // namespace
+
+extern "C" int vidc_mask_scale(const float* x, const float* image_nchw, float* y, int B, int h, int w, int C, int ldx, int ldy, int H, int W,
+                               vidc_stream_t stream) {
+    VIDC_REQUIRE(x && image_nchw && y, VIDC_ERR_NULL, "vidc_mask_scale: null pointer");
+    VIDC_REQUIRE(B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0, VIDC_ERR_SHAPE,
+                 "vidc_mask_scale: bad shape");
+    const long long total = (long long)B * h * w * (C / 4);
+    hipLaunchKernelGGL(mask_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vidc::as_stream(stream), x, image_nchw, y, B, h, w, C, ldx, ldy,
+                       H, W);
+    VIDC_CHECK_LAUNCH("mask_scale_kernel");
+    return VIDC_OK;
+}

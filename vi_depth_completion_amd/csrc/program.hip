@@ -59,6 +59,8 @@ int launch_op(const vidc_op& op, hipStream_t st) {
             return vidc_det_stem_im2col((const float*)g.p[0], (float*)g.p[1], g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.f[0], g.f[1], g.f[2], s);
         case VIDC_OP_NEAREST2X:    // i = B, h, w, C, ldx, ldy
             return vidc_upsample_nearest2x((const float*)g.p[0], (float*)g.p[1], g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.i[5], s);
+        case VIDC_OP_MASK:
+            return vidc_mask_scale((const float*)g.p[0], (const float*)g.p[1], (float*)g.p[2], g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.i[5], g.i[6], g.i[7], s);
         case VIDC_OP_CHAIN:
             return vidc_chain_run(reinterpret_cast<vidc_chain*>(const_cast<void*>(g.p[0])), s);
         case VIDC_OP_COPY: {   // p[0] -> p[1], i[0..1] = byte count (lo, hi)

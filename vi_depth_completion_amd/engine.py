@@ -330,6 +330,13 @@ class Program:
         self._emit("nearest2x", [x], [y], x=x, y=y)
         return y
 
+    def mask_scale(self, x, image):
+        """x * (r+g+b > 1e-2 of `image`, nearest-resized to x): the use_mask branch of surface_normal.py:150-162.  `image`: NCHW."""
+        assert image.nchw and image.C == 3 and not x.nchw
+        y = self.nhwc(x.H, x.W, x.C, x.G)
+        self._emit("mask", [x, image], [y], x=x, y=y, image=image)
+        return y
+
     def maxpool(self, x):
         Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
         y = self.nhwc(Ho, Wo, x.C, x.G)
@@ -723,6 +730,13 @@ class Program:
                     g.i[j] = v
                 g.f[0], g.f[1], g.f[2] = kw["mean"]
                 self.op_names.append("det_im2col")
+            elif kind == "mask":
+                x, y, im = kw["x"], kw["y"], kw["image"]
+                op.kind = L.OP_MASK
+                g.p[0], g.p[1], g.p[2] = addr(x), addr(im), addr(y)
+                for j, v in enumerate((x.B, x.H, x.W, x.C * x.G, x.ld, y.ld, im.H, im.W)):
+                    g.i[j] = v
+                self.op_names.append("mask_scale")
             elif kind == "nearest2x":
                 x, y = kw["x"], kw["y"]
                 op.kind = L.OP_NEAREST2X

@@ -63,8 +63,6 @@ class SurfaceNormalPrediction(_HipModule):
                  fc_img=np.array([0.5 * 577.87061, 0.5 * 580.25851]),
                  cc_img=np.array([0.5 * 319.87654, 0.5 * 239.87603]), use_mask=False, align_corners=False):
         super().__init__()
-        if use_mask:
-            raise NotImplementedError("use_mask=True (surface_normal.py:150-162) is off in the reference pipeline")
         self.output_size, self.mode, self.use_mask = output_size, training_mode, use_mask
         self.warp_2dof_alignment = Warping2DOFAlignment(fx=fc_img[0], fy=fc_img[1], cx=cc_img[0], cy=cc_img[1],
                                                         align_corners=align_corners)
@@ -85,7 +83,10 @@ class SurfaceNormalPrediction(_HipModule):
         params = prog.warp_params(g, a, wp, kinv)
         xw = prog.warp_fwd(x, params, wp, wp.align_corners)
         levels = self.resnet_pyramids.emit(prog, xw, engine.K("resnet_pyramids."))
-        zsum = emit_decoder(prog, self, levels)
+        if self.use_mask:               # surface_normal.py:150-162: features and their sum are zeroed where the warp left no image
+            zsum = prog.mask_scale(emit_decoder(prog, self, [prog.mask_scale(t, xw) for t in levels]), xw)
+        else:
+            zsum = emit_decoder(prog, self, levels)
         h = prog.conv(zsum, "feature_concat.0", relu=True, padding=1)
         y, low = prog.head(h, "feature_concat.2", 0, (wp.H, wp.W), relu=False)
         z = prog.warp_inv(y, params, wp, wp.align_corners, normalize=True)

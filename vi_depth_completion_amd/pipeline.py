@@ -56,7 +56,10 @@ def build_frame_program(sn, dc, B, H, W, device, dry_run=False, weights=None):
             prog.split(t)            # stage and both decoders read (channel slices of) it
     sn_levels = [T(t.buf, t.B, t.H, t.W, t.C, 1, t.ld, t.ch_off) for t in levels]
     dc_levels = [T(t.buf, t.B, t.H, t.W, 3 * t.C, 1, t.ld, t.ch_off + t.C) for t in levels]
-    zs = emit_decoder(prog, sn, sn_levels, "sn/")
+    if sn.use_mask:                  # surface_normal.py:150-162
+        zs = prog.mask_scale(emit_decoder(prog, sn, [prog.mask_scale(t, xw) for t in sn_levels], "sn/"), xw)
+    else:
+        zs = emit_decoder(prog, sn, sn_levels, "sn/")
     h = prog.conv(zs, "sn/feature_concat.0", relu=True, padding=1)
     y, _low = prog.head(h, "sn/feature_concat.2", 0, (H, W), relu=False)
     # The normals of frame t are written straight into the buffer the normal pyramid of the depth network reads them from one
