@@ -324,3 +324,36 @@ def test_training_loop_on_pipeline_inputs(seeded_weights):
     pipe.rng = np.random.RandomState(3)
     after = pipe._call_cnn(batch)
     assert torch.isfinite(after).all() and float((after - before).abs().mean()) > 1e-4      # the trained weights are the ones that run
+
+
+@gpu
+def test_two_training_iterations_vs_oracle(golden_dir, seeded_weights):
+    """Two consecutive iterations against oracle/train_oracle.py (itself pinned by the reference's first iteration): the second loss
+    depends on the first Adam step, the second step on the moment estimates and bias corrections (step = 2), and the second forward on
+    nothing stale (packed weights are rebuilt every step)."""
+    from oracle import train_oracle as T
+    from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
+    from vi_depth_completion_amd.training import DepthCompletionTrainer
+    f, image, normal, depth_in, gt = _train_fixture(golden_dir)
+    image, normal, depth_in, gt = image[:1], normal[:1], depth_in[:1], gt[:1]             # one frame keeps the CPU side short
+    lr = 1e-3
+    sd, state, ref_losses = dict(seeded_weights["dc"]), {}, []
+    for _ in range(2):
+        loss, sd = T.training_iteration(sd, image, normal, depth_in, gt, lr, state)
+        ref_losses.append(float(loss))
+    cnn = ModifiedFPN().to(DEV)
+    st = cnn.state_dict()
+    st.update({k: v.to(DEV) for k, v in seeded_weights["dc"].items()})
+    cnn.load_state_dict(st)
+    cnn.train()
+    tr = DepthCompletionTrainer(cnn, lr)
+    got = [float(tr.step(image.to(DEV), normal.to(DEV), depth_in.to(DEV), gt.to(DEV))) for _ in range(2)]
+    print("losses", got, ref_losses)
+    assert abs(got[0] - ref_losses[0]) < 1e-5 * ref_losses[0]
+    assert abs(got[1] - ref_losses[1]) < 2e-3 * ref_losses[1]          # one lr = 1e-3 step through 310 M weights, signs of ~0 gradients free
+    assert ref_losses[1] != ref_losses[0]
+    new = cnn.state_dict()
+    for k in ("feature_concat.2.weight", "feature_concat.0.bias", "resnet_rgb.conv1.bn_2.running_var", "feature4_upsamping.1.running_mean"):
+        ref = sd[k].numpy()
+        assert np.abs(new[k].cpu().numpy() - ref).max() < 2.1 * 2 * lr + 1e-4 * np.abs(ref).max(), k
+    assert int(new["resnet_rgb.bn1.num_batches_tracked"]) == 2
