@@ -15,8 +15,10 @@ head / loss / Adam = csrc/train.hip.  PyTorch provides device memory, the parame
 state_dict layout; parameters and their .grad become views of two flat buffers) and, across GPUs, `torch.distributed.all_reduce` of
 the flat gradient buffer (RCCL): frames shard over ranks, every rank normalises BatchNorm over ITS frames (what the reference's
 DataParallel replicas do as well) and gradients are SUMMED, which equals the reference's single loss over the whole batch.
-There is no CPU path.  Arithmetic: exact fp32 MFMA products (VIDC_PREC_FP32) for all three conv passes."""
+There is no CPU path.  Arithmetic: wgrad on exact fp32 MFMA products; forward and dgrad convs in the split-bf16 3-pass mode of the
+inference path (VIDC_PREC_BF16X3: ~2^-16 relative error per product, fp32 accumulation) unless VIDC_TRAIN_PRECISION=fp32."""
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -92,6 +94,7 @@ class DepthCompletionTrainer:
         self.buckets = GradientBuckets(n)
         self.step_count = 0
         self._ones, self._zeros, self._packed, self._scratch, self._nbt = {}, {}, {}, None, []
+        self.precision = L.PREC_FP32 if os.environ.get("VIDC_TRAIN_PRECISION", "bf16x3") == "fp32" else L.PREC_BF16X3
         self.last_loss = None
 
     # ---- small helpers ------------------------------------------------------------------------------------------------------
@@ -113,20 +116,45 @@ class DepthCompletionTrainer:
 
     # ---- conv: forward, dgrad, wgrad --------------------------------------------------------------------------------------------
     def _conv_call(self, x_t, w_packed, shift, y_t, kh, kw, stride, pad, relu, accumulate):
+        """One launch of the inference conv kernel.  In bf16x3 mode the activations are split here (one extra pass over x); `w_packed`
+        must already be in the matching format (`_pack`)."""
         B, H, W, cin = x_t.shape
         _, Ho, Wo, cout = y_t.shape
+        ldx = _ld(x_t)
+        if self.precision == L.PREC_BF16X3:
+            xs = self._empty(B, H, W, cin)
+            L.check(L.lib().vidc_split_bf16x3(L.ptr(x_t), L.ptr(xs), B * H * W, cin, ldx, L.current_stream()), "split")
+            x_t, ldx = xs, cin
         d = L.ConvDesc()
         d.x, d.w, d.y = L.ptr(x_t), L.ptr(w_packed), L.ptr(y_t)
         d.scale1, d.shift1 = L.ptr(self._const(self._ones, cout, 1.0)), L.ptr(shift)
-        d.B, d.H, d.W, d.Cin, d.ldx = B, H, W, cin, _ld(x_t)
+        d.B, d.H, d.W, d.Cin, d.ldx = B, H, W, cin, ldx
         d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, cout, _ld(y_t)
         d.KH, d.KW, d.stride, d.pad = kh, kw, stride, pad
         d.flags = (L.RELU1 if relu else 0) | (L.ACCUM if accumulate else 0)
-        d.groups, d.splitk, d.precision, d.tile = 1, 1, L.PREC_FP32, 0
+        d.groups, d.splitk, d.precision, d.tile = 1, 1, self.precision, 0
         d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, cout * kh * kw * cin, cout, cout
         L.check(L.lib().vidc_conv2d_plan(C.byref(d)), "conv plan")
         d.splitk = 1
         L.check(L.lib().vidc_conv2d_bn_act(C.byref(d), L.current_stream()), "conv")
+
+    def _pack(self, key, kind, w):
+        """Packed weights of conv `key` for the forward ('f') or the dgrad ('d': kernel flipped, channels transposed) launch, in the
+        trainer's arithmetic mode; rebuilt every step (the parameters move)."""
+        co, ci, kh, kw = w.shape
+        rows, K = (co, kh * kw * ci) if kind == "f" else (ci, kh * kw * co)
+        out = self._packed.setdefault((key, kind), self._empty(rows, K))
+        lib, st = L.lib(), L.current_stream()
+        if kind == "f" and self.precision == L.PREC_BF16X3:
+            L.check(lib.vidc_pack_conv_weight_bf16x3(L.ptr(w), L.ptr(out), co, ci, kh, kw, st), "pack")
+        elif kind == "f":
+            L.check(lib.vidc_pack_conv_weight(L.ptr(w), L.ptr(out), co, ci, kh, kw, st), "pack")
+        else:
+            tmp = out if self.precision == L.PREC_FP32 else self._packed.setdefault((key, "d32"), self._empty(rows, K))
+            L.check(lib.vidc_pack_conv_weight_dgrad(L.ptr(w), L.ptr(tmp), co, ci, kh, kw, st), "pack_dgrad")
+            if self.precision == L.PREC_BF16X3:          # split the packed rows: every 32-wide K unit becomes [32 x hi | 32 x lo]
+                L.check(lib.vidc_split_bf16x3(L.ptr(tmp), L.ptr(out), rows, K, K, st), "split_w")
+        return out
 
     def conv(self, x, key, stride=1, pad=0, relu=False, out=None):
         """nn.Conv2d (+ReLU when no BatchNorm sits in between, depth_completion.py:141-142).  Records its backward."""
@@ -135,8 +163,7 @@ class DepthCompletionTrainer:
         co, ci, kh, kw = w.shape
         B, H, W, _ = x.t.shape
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
-        wp = self._packed.setdefault((key, "f"), self._empty(co, kh * kw * ci))
-        L.check(L.lib().vidc_pack_conv_weight(L.ptr(w), L.ptr(wp), co, ci, kh, kw, L.current_stream()), "pack")
+        wp = self._pack(key, "f", w)
         y = Act(out if out is not None else self._empty(B, Ho, Wo, co))
         self._conv_call(x.t, wp, bias if bias is not None else self._const(self._zeros, co, 0.0), y.t, kh, kw, stride, pad, relu, False)
 
@@ -157,8 +184,7 @@ class DepthCompletionTrainer:
             if x.grad is False:                              # network input: no data gradient wanted
                 return
             # data gradient: the conv kernel on flipped / transposed weights; a strided conv spreads dY over the input grid first
-            wd = self._packed.setdefault((key, "d"), self._empty(ci, kh * kw * co))
-            L.check(lib.vidc_pack_conv_weight_dgrad(L.ptr(w), L.ptr(wd), co, ci, kh, kw, L.current_stream()), "pack_dgrad")
+            wd = self._pack(key, "d", w)
             gz = g
             if stride > 1:
                 gz = self._empty(B, H, W, co)
