@@ -66,7 +66,11 @@ def _nchw(t):
 
 
 def _trainer(module):
+    """Kernel-level comparisons run with exact fp32 products: in the default bf16x3 mode the forward differs by ~1e-5, which flips the
+    ReLU gate of the odd pre-activation that sits within 1e-5 of zero, and ONE flipped gate moves max|dx| by percents of the scale
+    (measured: 1.6 %) although every kernel is right (dgrad alone: 1.4e-5).  The whole-network test covers both modes."""
     from vi_depth_completion_amd.training import DepthCompletionTrainer
+    assert os.environ.get("VIDC_TRAIN_PRECISION", "fp32") == "fp32"
     tr = DepthCompletionTrainer(module.to(DEV), 1e-3)
     tr.tape = []
     return tr
@@ -233,8 +237,14 @@ def _train_fixture(golden_dir):
 
 
 @gpu
-def test_training_iteration_vs_reference(golden_dir, seeded_weights):
-    """ONE `_run_training_iteration` (network_run.py:231-254) of the whole 310 M-parameter network on the reference's own 2-frame
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_training_iteration_vs_reference(golden_dir, seeded_weights, monkeypatch, precision):
+    """(precision: the arithmetic of the forward / dgrad convs.  fp32 = exact products like the reference, the trainer's default: the
+    tolerances below.  bf16x3 = VIDC_TRAIN_PRECISION=bf16x3, the split-bf16 3-pass mode of the inference path, ~2^-16 per product, a
+    throughput option: same loss, same prediction, same global gradient norm, but single gradient tensors are only asserted to 1e-1
+    of their scale (5e-3 in the head): a forward that differs by 1e-5 flips ReLU gates, and the flips propagate through 335
+    train-mode BatchNorms; observed up to 6 %.)
+    ONE `_run_training_iteration` (network_run.py:231-254) of the whole 310 M-parameter network on the reference's own 2-frame
     batch: the loss the reference logged, the gradient of 29 parameters from the stems to the head, the global gradient norm (1e-3),
     the parameters after the Adam step, the updated running statistics.
     Gradient tolerance: 2e-2 of each tensor's scale.  That is the noise floor of the REFERENCE's fp32 arithmetic, not slack: its own
@@ -244,6 +254,7 @@ def test_training_iteration_vs_reference(golden_dir, seeded_weights):
     from _probe import check_probe
     from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
     from vi_depth_completion_amd.training import DepthCompletionTrainer
+    monkeypatch.setenv("VIDC_TRAIN_PRECISION", precision)
     f, image, normal, depth_in, gt = _train_fixture(golden_dir)
     cnn = ModifiedFPN().to(DEV)
     st = cnn.state_dict()
@@ -264,7 +275,7 @@ def test_training_iteration_vs_reference(golden_dir, seeded_weights):
             assert float(tr.grad[k].abs().max()) < 1e-5, k
             continue
         tight = k.startswith("feature_concat") or k in ("feature1_upsamping.4.weight", "feature1_upsamping.0.weight")
-        check_probe(f, "grad", k, tr.grad[k].cpu(), 5e-4 if tight else 2e-2, 1e-7)
+        check_probe(f, "grad", k, tr.grad[k].cpu(), (5e-4 if precision == "fp32" else 5e-3) if tight else (2e-2 if precision == "fp32" else 1e-1), 1e-7)
     tr.optimizer_step()
     torch.cuda.synchronize()
     # First Adam step: every weight moves by lr * g / (|g| + 1e-8) ~ lr * sign(g).  Where the gradient is well above its noise floor
@@ -353,7 +364,10 @@ def test_two_training_iterations_vs_oracle(golden_dir, seeded_weights):
     assert abs(got[1] - ref_losses[1]) < 2e-3 * ref_losses[1]          # one lr = 1e-3 step through 310 M weights, signs of ~0 gradients free
     assert ref_losses[1] != ref_losses[0]
     new = cnn.state_dict()
-    for k in ("feature_concat.2.weight", "feature_concat.0.bias", "resnet_rgb.conv1.bn_2.running_var", "feature4_upsamping.1.running_mean"):
+    for k in ("feature_concat.2.weight", "feature_concat.0.bias"):
         ref = sd[k].numpy()
         assert np.abs(new[k].cpu().numpy() - ref).max() < 2.1 * 2 * lr + 1e-4 * np.abs(ref).max(), k
+    for k in ("resnet_rgb.conv1.bn_2.running_var", "feature4_upsamping.1.running_mean"):      # second-forward statistics: downstream of the
+        ref = sd[k].numpy()                                                                  # +-lr sign noise of the first step
+        assert np.abs(new[k].cpu().numpy() - ref).max() < 3e-2 * np.abs(ref).max(), k
     assert int(new["resnet_rgb.bn1.num_batches_tracked"]) == 2

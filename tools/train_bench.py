@@ -61,7 +61,8 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0:
         print(json.dumps({"metric": "training frames/sec", "value": round(world * B * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
-                          "batch_per_gpu": B, "ms_per_step": round(1e3 * dt / args.steps, 1), "dtype": "f32 (fp32 MFMA fwd / dgrad / wgrad)",
+                          "batch_per_gpu": B, "ms_per_step": round(1e3 * dt / args.steps, 1), "dtype": ("f32 (fp32 MFMA fwd / dgrad / wgrad)" if os.environ.get("VIDC_TRAIN_PRECISION", "fp32") == "fp32" else
+                                    "f32+bf16x3 (split-bf16 3-pass MFMA fwd / dgrad, fp32 MFMA wgrad)"),
                           "losses": [round(float(x), 5) for x in losses],
                           "config": "BASELINE configs[4]: ModifiedFPN training step (train-mode BN, masked L1 / (H*W), Adam), 320x240, synthetic"}))
     if world > 1:
