@@ -292,12 +292,12 @@ def test_training_iteration_vs_reference(golden_dir, seeded_weights, monkeypatch
         assert np.abs(got - new).max() < 2.1 * lr, (k, np.abs(got - new).max())
         if np.abs(gref).max() < 1e-7:          # bias in front of a BatchNorm: the whole gradient is rounding noise around 0
             continue
-        certain = np.abs(gref) > 0.05 * np.abs(gref).max()
+        certain = np.abs(gref) > (0.05 if precision == "fp32" else 0.3) * np.abs(gref).max()
         n_certain += int(certain.sum())
         assert np.abs(got - new)[certain].max() < 1e-6, (k, np.abs(got - new)[certain].max())
         old = f["old" + key + ("full" if "old" + key + "full" in f.files else "val")]
         assert np.abs(np.abs(got - old)[certain] - lr).max() < 2e-6, k                    # ... and it did move by lr
-    assert n_certain > 1000
+    assert n_certain > (1000 if precision == "fp32" else 200)
     sd = cnn.state_dict()
     for k in [k[4:] for k in f.files if k.startswith("buf|")]:
         assert np.abs(sd[k].cpu().numpy() - f["buf|" + k]).max() < 1e-4 * max(1.0, np.abs(f["buf|" + k]).max()), k
