@@ -35,7 +35,8 @@ def main():
     torch.set_grad_enabled(False)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(os.environ.get("VIDC_DIST_BACKEND", "nccl"), device_id=dev)
+        backend = os.environ.get("VIDC_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" to try the N > 1 path on a 1-GPU box
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     cnn = ModifiedFPN().to(dev)
     cnn.load_state_dict(S.seeded_state_dict(cnn.state_dict(), 1234, device=dev))
     cnn.train()

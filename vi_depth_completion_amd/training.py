@@ -62,8 +62,14 @@ class GradientBuckets:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return flat
+        stage = dist.get_backend() == "gloo" and flat.is_cuda       # (gloo = trying the N > 1 path without RCCL: through the host)
         for a, b in self.ranges:
-            dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM)
+            if stage:
+                h = flat[a:b].cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                flat[a:b].copy_(h)
+            else:
+                dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM)
         return flat
 
 
