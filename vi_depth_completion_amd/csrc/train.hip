@@ -22,40 +22,69 @@ template <int MODE>
 __global__ void __launch_bounds__(TT)
 chan_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ y, long long M, int C, int lda, int ldb,
                     int ldy, const float* __restrict__ mean, const float* __restrict__ rstd, int rows_per_chunk, double* __restrict__ partial) {
-    __shared__ double red[2][4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    // block = 16 channel quads (64 channels, one float4 per thread and row) x 16 row-lanes; C % 4 == 0 and the strides % 4 == 0 (host-checked)
+    __shared__ double red[2][16][64];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4;
     const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
-    double s0 = 0.0, s1 = 0.0;
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     if (c < C) {
-        const float mu = MODE ? mean[c] : 0.f, rs = MODE ? rstd[c] : 0.f;
-        for (long long r = r0 + rl; r < r1; r += 4) {
+        float mu[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0};
+        if (MODE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { mu[k] = mean[c + k]; rs[k] = rstd[c + k]; }
+        }
+        for (long long r = r0 + rl; r < r1; r += 16) {
+            const float4 av = *reinterpret_cast<const float4*>(a + r * lda + c);
+            float g[4] = {av.x, av.y, av.z, av.w};
             if (MODE == 0) {
-                const double v = (double)a[r * lda + c];
-                s0 += v; s1 += v * v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const double v = (double)g[k]; s0[k] += v; s1[k] += v * v; }
             } else {
-                float g = a[r * lda + c];
-                if (y && !(y[r * ldy + c] > 0.f)) g = 0.f;
-                const float xh = (b[r * ldb + c] - mu) * rs;
-                s0 += (double)g; s1 += (double)g * (double)xh;
+                const float4 bv = *reinterpret_cast<const float4*>(b + r * ldb + c);
+                const float xv[4] = {bv.x, bv.y, bv.z, bv.w};
+                if (y) {
+                    const float4 yv4 = *reinterpret_cast<const float4*>(y + r * ldy + c);
+                    const float yv[4] = {yv4.x, yv4.y, yv4.z, yv4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (!(yv[k] > 0.f)) g[k] = 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xh = (xv[k] - mu[k]) * rs[k];
+                    s0[k] += (double)g[k]; s1[k] += (double)g[k] * (double)xh;
+                }
             }
         }
     }
-    red[0][rl][threadIdx.x & 63] = s0; red[1][rl][threadIdx.x & 63] = s1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[0][rl][cq * 4 + k] = s0[k]; red[1][rl][cq * 4 + k] = s1[k]; }
     __syncthreads();
-    if (rl == 0 && c < C) {
-        const int l = threadIdx.x & 63;
-        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
-        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    if (threadIdx.x < 128) {                       // 64 channels x 2 sums; row-lanes added in order 0..15
+        const int q = threadIdx.x >> 6, l = threadIdx.x & 63, cc = blockIdx.x * 64 + l;
+        if (cc < C) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t += red[q][j][l];
+            partial[((size_t)blockIdx.y * 2 + q) * C + cc] = t;
+        }
     }
 }
 
-// sums[q][C] = sum over chunks, in chunk order
+// sums[q][C] = sum over chunks: block = 64 channels x 4 lanes, lane l adds chunks l, l+4, ... in order, then ((l0 + l1) + (l2 + l3)) -- fixed order
 __global__ void __launch_bounds__(TT) chan_final_kernel(const double* __restrict__ partial, int n_chunks, int C, double* __restrict__ sums) {
-    const int c = blockIdx.x * TT + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[2][4][64];
+    const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
     double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < n_chunks; ++k) { s0 += partial[((size_t)k * 2 + 0) * C + c]; s1 += partial[((size_t)k * 2 + 1) * C + c]; }
-    sums[c] = s0; sums[C + c] = s1;
+    if (c < C)
+        for (int k = rl; k < n_chunks; k += 4) { s0 += partial[((size_t)k * 2 + 0) * C + c]; s1 += partial[((size_t)k * 2 + 1) * C + c]; }
+    red[0][rl][l] = s0; red[1][rl][l] = s1;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        sums[c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        sums[C + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    }
 }
 
 // nn.BatchNorm2d.forward in train(): batch mean, biased variance, invstd = 1/sqrt(var + eps); running_mean/var <- (1 - momentum) * old
@@ -470,6 +499,48 @@ wgrad_final_kernel(const float* __restrict__ partial, int n_chunks, int taps, in
     dw[((long long)co * Cin + ci) * taps + tap] = (float)s;
 }
 
+// ---- wgrad as a GEMM on the conv kernel: transposed operands ---------------------------------------------------------------------------
+// dW[co][tap][ci] = sum_m dY^T[co][m] * Xt[tap*C + ci][m] is a plain "both operands K-contiguous" GEMM with K = the pixels -- exactly
+// the 1x1 case of conv_mfma.hip (activations = rows of dY^T, weights = rows of Xt), which runs at several times the rate of the
+// direct kernel above (LDS-tiled, split-K, fp32 or bf16x3).  This kernel builds the operands: xt[(tap*C + c)][m] = x[b, oy*s - p + kh,
+// ox*s - p + kw, c] (0 outside the image and for m >= M; rows are Mp = M rounded up to 32 long), through a 32x32 LDS transpose so that
+// both the NHWC reads and the row writes are 128-byte coalesced.  With KH = KW = 1, s = 1, p = 0 it is the transpose of dY.
+__global__ void __launch_bounds__(256)
+im2col_t_kernel(const float* __restrict__ x, float* __restrict__ xt, int B, int H, int W, int C, int ldx, int Ho, int Wo, int KH, int KW, int stride,
+                int pad, int M, int Mp) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tap = blockIdx.z;
+    const int kh = tap / KW, kw = tap - kh * KW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + ty + 8 * r, c = c0 + tx;
+        float v = 0.f;
+        if (m < M && c < C) {
+            const int ox = m % Wo, q = m / Wo, oy = q % Ho, b = q / Ho;
+            const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[((size_t)(b * H + iy) * W + ix) * ldx + c];
+        }
+        tile[ty + 8 * r][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = c0 + ty + 8 * r, m = m0 + tx;
+        if (c < C && m < Mp) xt[((size_t)tap * C + c) * Mp + m] = tile[tx][ty + 8 * r];
+    }
+}
+// dw_oihw[co][ci][tap] = tmp[co][tap * Cin + ci]
+__global__ void __launch_bounds__(TT) wgrad_permute_kernel(const float* __restrict__ tmp, float* __restrict__ dw, int Cout, int Cin, int taps) {
+    const long long i = (long long)blockIdx.x * TT + threadIdx.x;
+    const long long total = (long long)Cout * Cin * taps;
+    if (i >= total) return;
+    const int tap = (int)(i % taps);
+    const long long q = i / taps;
+    const int ci = (int)(q % Cin), co = (int)(q / Cin);
+    dw[i] = tmp[((long long)co * taps + tap) * Cin + ci];
+}
+
 // stem conv (3x3, stride 2, pad 1, Cin = 1 or 3, NCHW input, no bias): dW[co][ci][kh][kw] = sum dY[m][co] * x[b][ci][2oy+kh-1][2ox+kw-1]
 __global__ void __launch_bounds__(TT)
 stem_wgrad_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x, int B, int Cin, int H, int W, int Ho, int Wo, int Cout, int lddy,
@@ -516,7 +587,7 @@ extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int 
     double* sums = partial + (size_t)nch * 2 * C;
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, x, (const float*)nullptr, (const float*)nullptr, M, C, ldx, 0, 0,
                        (const float*)nullptr, (const float*)nullptr, kRowsPerChunk, partial);
-    hipLaunchKernelGGL(chan_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, partial, nch, C, sums);
+    hipLaunchKernelGGL(chan_final_kernel, dim3((C + 63) / 64), dim3(TT), 0, st, partial, nch, C, sums);
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, sums, M, C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, x, y, M, C, ldx, ldy, save_mean, save_rstd, gamma, beta, relu);
     VIDC_CHECK_LAUNCH("bn_train_forward");
@@ -534,7 +605,7 @@ extern "C" int vidc_bn_train_backward(const float* dy, const float* x, const flo
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
     hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean, save_rstd, kRowsPerChunk, partial);
-    hipLaunchKernelGGL(chan_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, partial, nch, C, sums);
+    hipLaunchKernelGGL(chan_final_kernel, dim3((C + 63) / 64), dim3(TT), 0, st, partial, nch, C, sums);
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3(blocks(C)), dim3(TT), 0, st, sums, C, dgamma, dbeta);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, save_mean, save_rstd,
                        gamma, sums);
@@ -544,14 +615,14 @@ extern "C" int vidc_bn_train_backward(const float* dy, const float* x, const flo
 
 extern "C" int vidc_colsum(const float* dy, long long M, int C, int ld, float* out, void* scratch, vidc_stream_t stream) {
     VIDC_REQUIRE(dy && out && scratch, VIDC_ERR_NULL, "vidc_colsum: null pointer");
-    VIDC_REQUIRE(M > 0 && C > 0 && ld >= C, VIDC_ERR_SHAPE, "vidc_colsum: bad shape");
+    VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0, VIDC_ERR_SHAPE, "vidc_colsum: bad shape (C and ld multiples of 4)");
     hipStream_t st = vidc::as_stream(stream);
     const int nch = chunks_for(M);
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, (const float*)nullptr, (const float*)nullptr, M, C, ld, 0, 0,
                        (const float*)nullptr, (const float*)nullptr, kRowsPerChunk, partial);
-    hipLaunchKernelGGL(chan_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, partial, nch, C, sums);
+    hipLaunchKernelGGL(chan_final_kernel, dim3((C + 63) / 64), dim3(TT), 0, st, partial, nch, C, sums);
     hipLaunchKernelGGL(colsum_out_kernel, dim3(blocks(C)), dim3(TT), 0, st, sums, C, out);
     VIDC_CHECK_LAUNCH("colsum");
     return VIDC_OK;
@@ -700,6 +771,26 @@ extern "C" int vidc_conv_wgrad(const float* dy, const float* x, float* dw_oihw, 
                        KH, KW, stride, pad, rows, partial);
     hipLaunchKernelGGL(wgrad_final_kernel, dim3(blocks((long long)taps * Cout * Cin)), dim3(TT), 0, st, partial, chunks, taps, Cout, Cin, dw_oihw);
     VIDC_CHECK_LAUNCH("conv_wgrad");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_im2col_transposed(const float* x, float* xt, int B, int H, int W, int C, int ldx, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                                      int Mp, vidc_stream_t stream) {
+    VIDC_REQUIRE(x && xt, VIDC_ERR_NULL, "vidc_im2col_transposed: null pointer");
+    const long long M = (long long)B * Ho * Wo;
+    VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0 && Mp >= M && Mp % 32 == 0 && M < (1ll << 31) &&
+                     (long long)KH * KW <= 65535, VIDC_ERR_SHAPE, "vidc_im2col_transposed: bad shape (Mp = M rounded up to a multiple of 32)");
+    hipLaunchKernelGGL(im2col_t_kernel, dim3(Mp / 32, (C + 31) / 32, KH * KW), dim3(256), 0, vidc::as_stream(stream), x, xt, B, H, W, C, ldx, Ho, Wo, KH, KW,
+                       stride, pad, (int)M, Mp);
+    VIDC_CHECK_LAUNCH("im2col_t_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_wgrad_permute(const float* tmp, float* dw_oihw, int Cout, int Cin, int taps, vidc_stream_t stream) {
+    VIDC_REQUIRE(tmp && dw_oihw, VIDC_ERR_NULL, "vidc_wgrad_permute: null pointer");
+    VIDC_REQUIRE(Cout > 0 && Cin > 0 && taps > 0, VIDC_ERR_SHAPE, "vidc_wgrad_permute: bad shape");
+    hipLaunchKernelGGL(wgrad_permute_kernel, dim3(blocks((long long)Cout * Cin * taps)), dim3(TT), 0, vidc::as_stream(stream), tmp, dw_oihw, Cout, Cin, taps);
+    VIDC_CHECK_LAUNCH("wgrad_permute_kernel");
     return VIDC_OK;
 }
 

@@ -102,6 +102,7 @@ class DepthCompletionTrainer:
         self.buckets = GradientBuckets(n)
         self.step_count = 0
         self._ones, self._zeros, self._packed, self._scratch, self._nbt = {}, {}, {}, None, []
+        self._gemm_ws = None
         self.precision = L.PREC_BF16X3 if os.environ.get("VIDC_TRAIN_PRECISION", "fp32") == "bf16x3" else L.PREC_FP32
         self.last_loss = None
 
@@ -164,6 +165,50 @@ class DepthCompletionTrainer:
                 L.check(lib.vidc_split_bf16x3(L.ptr(tmp), L.ptr(out), rows, K, K, st), "split_w")
         return out
 
+    def _wgrad_gemm(self, g, x, key, geom):
+        """dW through the conv kernel: dW[co][tap][ci] = sum over pixels of dY^T[co][m] * Xt[tap*Cin + ci][m] is the 1x1 case of
+        vidc_conv2d_bn_act with the rows of dY^T as activations and the rows of Xt (the transposed im2col of x) as weights -- LDS-tiled,
+        split-K, at several times the rate of the direct pixel-reduction kernel (vidc_conv_wgrad, kept for shapes beyond the 32-bit
+        limits of the conv kernel).  Returns False when the shape does not fit."""
+        B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad = geom
+        if os.environ.get("VIDC_WGRAD", "gemm") != "gemm":
+            return False
+        lib, st = L.lib(), L.current_stream()
+        taps, M = kh * kw, B * Ho * Wo
+        Mp = (M + 31) // 32 * 32
+        if taps * ci * Mp * 4 >= (1 << 31) or co * Mp >= (1 << 29) or ci % 32 or co % 4:
+            return False
+        gt, xt, tmp = self._empty(co, Mp), self._empty(taps * ci, Mp), self._empty(co, taps * ci)
+        L.check(lib.vidc_im2col_transposed(L.ptr(g), L.ptr(gt), B, Ho, Wo, co, _ld(g), Ho, Wo, 1, 1, 1, 0, Mp, st), "transpose dY")
+        L.check(lib.vidc_im2col_transposed(L.ptr(x.t), L.ptr(xt), B, H, W, ci, x.ld, Ho, Wo, kh, kw, stride, pad, Mp, st), "im2col^T")
+        if self.precision == L.PREC_BF16X3:
+            gs, xs = self._empty(co, Mp), self._empty(taps * ci, Mp)
+            L.check(lib.vidc_split_bf16x3(L.ptr(gt), L.ptr(gs), co, Mp, Mp, st), "split")
+            L.check(lib.vidc_split_bf16x3(L.ptr(xt), L.ptr(xs), taps * ci, Mp, Mp, st), "split")
+            gt, xt = gs, xs
+        n_out = taps * ci
+        d = L.ConvDesc()
+        d.x, d.w, d.y = L.ptr(gt), L.ptr(xt), L.ptr(tmp)
+        d.scale1, d.shift1 = L.ptr(self._const(self._ones, n_out, 1.0)), L.ptr(self._const(self._zeros, n_out, 0.0))
+        d.B, d.H, d.W, d.Cin, d.ldx = 1, 1, co, Mp, Mp
+        d.Ho, d.Wo, d.Cout, d.ldy = 1, co, n_out, n_out
+        d.KH, d.KW, d.stride, d.pad, d.flags = 1, 1, 1, 0, 0
+        d.groups, d.splitk, d.precision, d.tile = 1, 1, self.precision, 0
+        d.x_gs, d.w_gs, d.y_gs, d.p_gs = Mp, n_out * Mp, n_out, n_out
+        L.check(lib.vidc_conv2d_plan(C.byref(d)), "gemm plan")
+        need = lib.vidc_conv2d_workspace_bytes(C.byref(d))
+        if need:
+            if self._gemm_ws is None or self._gemm_ws.numel() * 4 < need:
+                self._gemm_ws = torch.zeros(int(need // 4 * 1.5) + 16, dtype=torch.float32, device=self.device)      # ticket counters at its head: zero once
+            d.workspace = L.ptr(self._gemm_ws)
+        L.check(lib.vidc_conv2d_bn_act(C.byref(d), st), "wgrad gemm")
+        gw = self.grad[key + ".weight"]
+        if taps == 1:
+            gw.view(co, ci).copy_(tmp)
+        else:
+            L.check(lib.vidc_wgrad_permute(L.ptr(tmp), L.ptr(gw), co, ci, taps, st), "wgrad permute")
+        return True
+
     def conv(self, x, key, stride=1, pad=0, relu=False, out=None):
         """nn.Conv2d (+ReLU when no BatchNorm sits in between, depth_completion.py:141-142).  Records its backward."""
         w = self.param[key + ".weight"]
@@ -182,10 +227,11 @@ class DepthCompletionTrainer:
                 L.check(L.lib().vidc_relu_backward(L.ptr(g), L.ptr(y.t), L.ptr(gm), y.rows, co, _ld(g), y.ld, co, 0, L.current_stream()), "relu_bwd")
                 g = gm
             lib = L.lib()
-            # weight gradient (fp32 MFMA over the pixels) and bias gradient (column sums)
-            sc = self._scratch_bytes(lib.vidc_conv_wgrad_scratch_bytes(B, Ho, Wo, co, ci, kh, kw))
-            L.check(lib.vidc_conv_wgrad(L.ptr(g), L.ptr(x.t), L.ptr(self.grad[key + ".weight"]), B, H, W, ci, x.ld, Ho, Wo, co, _ld(g), kh, kw, stride, pad,
-                                        L.ptr(sc), L.current_stream()), "wgrad")
+            # weight gradient and bias gradient (column sums)
+            if not self._wgrad_gemm(g, x, key, (B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad)):
+                sc = self._scratch_bytes(lib.vidc_conv_wgrad_scratch_bytes(B, Ho, Wo, co, ci, kh, kw))
+                L.check(lib.vidc_conv_wgrad(L.ptr(g), L.ptr(x.t), L.ptr(self.grad[key + ".weight"]), B, H, W, ci, x.ld, Ho, Wo, co, _ld(g), kh, kw, stride,
+                                            pad, L.ptr(sc), L.current_stream()), "wgrad")
             if bias is not None:
                 L.check(lib.vidc_colsum(L.ptr(g), y.rows, co, _ld(g), L.ptr(self.grad[key + ".bias"]), L.ptr(self._train_scratch(y.rows, co)),
                                         L.current_stream()), "colsum")
