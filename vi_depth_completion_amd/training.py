@@ -20,12 +20,14 @@ the reference's own fp32 noise floor).  VIDC_TRAIN_PRECISION=bf16x3 runs the for
 the inference path (~2^-16 per product): 12 % faster per step, loss identical to 6 digits, individual gradient tensors up to ~6 % of
 their scale away (flipped ReLU gates propagate through the train-mode BatchNorms) -- a throughput option, not the parity mode."""
 import ctypes as C
+import json
 import os
 
 import torch
 import torch.nn as nn
 
 from . import _lib as L
+from . import engine
 from .networks.fpn_decoder import _BRANCH_PLAN
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -45,6 +47,20 @@ class Act:
     @property
     def rows(self):
         return self.t.shape[0] * self.t.shape[1] * self.t.shape[2]
+
+
+_TRAIN_TUNING = None
+
+
+def training_table():
+    """Per-shape [tile_fp32, splitk_fp32, tile_bf16x3, splitk_bf16x3] of the training step's conv launches (forward, dgrad and the
+    wgrad GEMMs), measured on MI355X by tools/autotune_train.py.  VIDC_TRAIN_TUNING=0 ignores it (cost-model plan)."""
+    global _TRAIN_TUNING
+    if _TRAIN_TUNING is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_tuning.json")
+        use = os.environ.get("VIDC_TRAIN_TUNING", "1") != "0" and os.path.exists(path)
+        _TRAIN_TUNING = json.load(open(path)) if use else {}
+    return _TRAIN_TUNING
 
 
 def _ld(t):
@@ -103,6 +119,7 @@ class DepthCompletionTrainer:
         self.step_count = 0
         self._ones, self._zeros, self._packed, self._scratch, self._nbt = {}, {}, {}, None, []
         self._gemm_ws = None
+        self.tune_hook = None      # tools/autotune_train.py: called with every conv descriptor before it is planned
         self.precision = L.PREC_BF16X3 if os.environ.get("VIDC_TRAIN_PRECISION", "fp32") == "bf16x3" else L.PREC_FP32
         self.last_loss = None
 
@@ -143,9 +160,28 @@ class DepthCompletionTrainer:
         d.flags = (L.RELU1 if relu else 0) | (L.ACCUM if accumulate else 0)
         d.groups, d.splitk, d.precision, d.tile = 1, 1, self.precision, 0
         d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, cout * kh * kw * cin, cout, cout
-        L.check(L.lib().vidc_conv2d_plan(C.byref(d)), "conv plan")
-        d.splitk = 1
+        self._plan(d, "conv")
         L.check(L.lib().vidc_conv2d_bn_act(C.byref(d), L.current_stream()), "conv")
+
+    def _plan(self, d, role):
+        """Tile / split-K of one launch: the table measured on MI355X at the training shapes (train_tuning.json, tools/autotune_train.py:
+        [tile, splitk] per arithmetic mode), else the planner's cost model.  Split-K partial sums go through one persistent workspace
+        (ticket counters at its head, zeroed once; the last workgroup of a tile resets its ticket)."""
+        lib = L.lib()
+        if self.tune_hook is not None:
+            self.tune_hook(d, role)
+        ent = training_table().get(engine.conv_signature(d))
+        if ent is not None:
+            d.tile, d.splitk = ent[2 * d.precision], ent[2 * d.precision + 1]
+        else:
+            L.check(lib.vidc_conv2d_plan(C.byref(d)), "conv plan")
+            if role == "conv":
+                d.splitk = 1
+        need = lib.vidc_conv2d_workspace_bytes(C.byref(d))
+        if need:
+            if self._gemm_ws is None or self._gemm_ws.numel() * 4 < need:
+                self._gemm_ws = torch.zeros(int(need // 4 * 1.5) + 16, dtype=torch.float32, device=self.device)
+            d.workspace = L.ptr(self._gemm_ws)
 
     def _pack(self, key, kind, w):
         """Packed weights of conv `key` for the forward ('f') or the dgrad ('d': kernel flipped, channels transposed) launch, in the
@@ -195,12 +231,7 @@ class DepthCompletionTrainer:
         d.KH, d.KW, d.stride, d.pad, d.flags = 1, 1, 1, 0, 0
         d.groups, d.splitk, d.precision, d.tile = 1, 1, self.precision, 0
         d.x_gs, d.w_gs, d.y_gs, d.p_gs = Mp, n_out * Mp, n_out, n_out
-        L.check(lib.vidc_conv2d_plan(C.byref(d)), "gemm plan")
-        need = lib.vidc_conv2d_workspace_bytes(C.byref(d))
-        if need:
-            if self._gemm_ws is None or self._gemm_ws.numel() * 4 < need:
-                self._gemm_ws = torch.zeros(int(need // 4 * 1.5) + 16, dtype=torch.float32, device=self.device)      # ticket counters at its head: zero once
-            d.workspace = L.ptr(self._gemm_ws)
+        self._plan(d, "gemm")
         L.check(lib.vidc_conv2d_bn_act(C.byref(d), st), "wgrad gemm")
         gw = self.grad[key + ".weight"]
         if taps == 1:
