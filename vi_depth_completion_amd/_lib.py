@@ -32,6 +32,12 @@ SPLITK_COUNTERS = 16384            # VIDC_SPLITK_COUNTERS: ticket counters at th
 _f32p = C.POINTER(C.c_float)
 
 
+class PackItem(C.Structure):
+    """vidc_pack_item (include/vidc.h)."""
+    _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
+                ("kind", C.c_int32), ("reserved", C.c_int32), ("block_begin", C.c_int64)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p),
@@ -88,6 +94,7 @@ SIGNATURES = {
     "vidc_masked_l1_loss": (C.c_int, [_vp, _vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp]),
     "vidc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, _f, _f, _f, _f, _i, _vp]),
     "vidc_pack_conv_weight_dgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vidc_pack_conv_weights_batched": (C.c_int, [_vp, _i, C.c_longlong, _vp]),
     "vidc_zero_stuff": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_conv_wgrad_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i]),
     "vidc_conv_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

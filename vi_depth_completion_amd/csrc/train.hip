@@ -71,8 +71,37 @@ chan_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, co
     }
 }
 
-// sums[q][C] = sum over chunks: block = 64 channels x 4 lanes, lane l adds chunks l, l+4, ... in order, then ((l0 + l1) + (l2 + l3)) -- fixed order
-__global__ void __launch_bounds__(TT) chan_final_kernel(const double* __restrict__ partial, int n_chunks, int C, double* __restrict__ sums) {
+// What the per-channel sums become, applied by the thread that finishes a channel in chan_final_kernel (no extra launch).
+struct FinalStats {      // nn.BatchNorm2d.forward in train(): batch mean, biased variance, invstd = 1/sqrt(var + eps); running_mean/var <-
+    long long M;         // (1 - momentum) * old + momentum * (mean, unbiased var)
+    float eps, momentum;
+    float *mean, *rstd, *running_mean, *running_var;
+    __device__ void operator()(int c, double s0, double s1) const {
+        const double mu = s0 / (double)M;
+        double var = s1 / (double)M - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)mu;
+        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mu);
+            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+        }
+    }
+};
+struct FinalParamGrad {  // dbeta = sum dy, dgamma = sum dy * xhat
+    float *dgamma, *dbeta;
+    __device__ void operator()(int c, double s0, double s1) const { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
+};
+struct FinalColsum {     // bias gradient of a conv: column sums of dY (first sum only)
+    float* out;
+    __device__ void operator()(int c, double s0, double) const { out[c] = (float)s0; }
+};
+
+// sums[q][C] = sum over chunks: block = 64 channels x 4 lanes, lane l adds chunks l, l+4, ... in order, then ((l0 + l1) + (l2 + l3)) -- fixed
+// order; `fin` then turns the two sums of a channel into the op's per-channel outputs
+template <typename Final>
+__global__ void __launch_bounds__(TT) chan_final_kernel(const double* __restrict__ partial, int n_chunks, int C, double* __restrict__ sums, Final fin) {
     __shared__ double red[2][4][64];
     const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + l;
@@ -82,27 +111,11 @@ __global__ void __launch_bounds__(TT) chan_final_kernel(const double* __restrict
     red[0][rl][l] = s0; red[1][rl][l] = s1;
     __syncthreads();
     if (rl == 0 && c < C) {
-        sums[c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
-        sums[C + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
-    }
-}
-
-// nn.BatchNorm2d.forward in train(): batch mean, biased variance, invstd = 1/sqrt(var + eps); running_mean/var <- (1 - momentum) * old
-// + momentum * (mean, unbiased var)
-__global__ void __launch_bounds__(TT)
-bn_stats_final_kernel(const double* __restrict__ sums, long long M, int C, float eps, float momentum, float* __restrict__ mean,
-                      float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * TT + threadIdx.x;
-    if (c >= C) return;
-    const double mu = sums[c] / (double)M;
-    double var = sums[C + c] / (double)M - mu * mu;
-    if (var < 0.0) var = 0.0;
-    mean[c] = (float)mu;
-    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mu);
-        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+        s0 = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        s1 = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+        sums[c] = s0;
+        sums[C + c] = s1;
+        fin(c, s0, s1);
     }
 }
 
@@ -153,19 +166,6 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, c
         o[k] = gamma[c + k] * rstd[c + k] * (g[k] - m1 - xh * m2);
     }
     *reinterpret_cast<float4*>(dx + r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
-}
-
-__global__ void __launch_bounds__(TT) bn_param_grad_kernel(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * TT + threadIdx.x;
-    if (c >= C) return;
-    dbeta[c] = (float)sums[c];
-    dgamma[c] = (float)sums[C + c];
-}
-
-// bias gradient of a conv: column sums of dY (MODE-0 partials, first sum only)
-__global__ void __launch_bounds__(TT) colsum_out_kernel(const double* __restrict__ sums, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * TT + threadIdx.x;
-    if (c < C) out[c] = (float)sums[c];
 }
 
 // ---- elementwise ---------------------------------------------------------------------------------------------------------------
@@ -391,6 +391,38 @@ pack_weight_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, in
     const int cu = u / taps, tap = u - cu * taps, kh = tap / KW, kw = tap - kh * KW, co = cu * 32 + lane;
     wp[idx] = w[(((long long)co * Cin + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
 }
+// Every conv weight of a network re-packed in ONE launch (the parameters move every optimizer step): block -> item by binary search over
+// items[].block_begin (uniform per block: scalar loads), then the per-element maps of pack_weight_kernel / pack_weight_dgrad_kernel,
+// fp32 or split-bf16 ([row][K/32][32 x hi | 32 x lo]).
+__global__ void __launch_bounds__(TT) pack_batched_kernel(const vidc_pack_item* __restrict__ items, int n) {
+    int lo = 0, hi = n - 1;
+    const long long blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].block_begin <= blk) lo = mid; else hi = mid - 1;
+    }
+    const vidc_pack_item it = items[lo];
+    const long long total = (long long)it.Cout * it.Cin * it.KH * it.KW;
+    const long long idx = (blk - it.block_begin) * TT + threadIdx.x;
+    if (idx >= total) return;
+    const int taps = it.KH * it.KW, dgrad = it.kind & 1;
+    const int K = (dgrad ? it.Cout : it.Cin) * taps;
+    const int row = (int)(idx / K), k = (int)(idx - (long long)row * K);
+    const int lane = k & 31, u = k >> 5;
+    const int cu = u / taps, tap = u - cu * taps, kh = tap / it.KW, kw = tap - kh * it.KW, ch = cu * 32 + lane;
+    const float v = dgrad ? it.w[(((long long)ch * it.Cin + row) * it.KH + (it.KH - 1 - kh)) * it.KW + (it.KW - 1 - kw)]
+                          : it.w[(((long long)row * it.Cin + ch) * it.KH + kh) * it.KW + kw];
+    if (it.kind & 2) {
+        unsigned short h, l;
+        vidc::split_bf16(v, h, l);
+        unsigned short* base = reinterpret_cast<unsigned short*>(it.packed) + ((long long)row * (K / 32) + u) * 64 + lane;
+        base[0] = h;
+        base[32] = l;
+    } else {
+        it.packed[idx] = v;
+    }
+}
+
 // z[b, oy*s, ox*s, :] = dy[b, oy, ox, :], zero elsewhere (z is B x H x W x C, dense)
 __global__ void __launch_bounds__(TT)
 zero_stuff_kernel(const float* __restrict__ dy, float* __restrict__ z, int B, int Ho, int Wo, int C, int lddy, int s, int H, int W) {
@@ -587,8 +619,8 @@ extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int 
     double* sums = partial + (size_t)nch * 2 * C;
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, x, (const float*)nullptr, (const float*)nullptr, M, C, ldx, 0, 0,
                        (const float*)nullptr, (const float*)nullptr, kRowsPerChunk, partial);
-    hipLaunchKernelGGL(chan_final_kernel, dim3((C + 63) / 64), dim3(TT), 0, st, partial, nch, C, sums);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, sums, M, C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
+    hipLaunchKernelGGL(chan_final_kernel<FinalStats>, dim3((C + 63) / 64), dim3(TT), 0, st, partial, nch, C, sums,
+                       FinalStats{M, eps, momentum, save_mean, save_rstd, running_mean, running_var});
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, x, y, M, C, ldx, ldy, save_mean, save_rstd, gamma, beta, relu);
     VIDC_CHECK_LAUNCH("bn_train_forward");
     return VIDC_OK;
@@ -605,8 +637,7 @@ extern "C" int vidc_bn_train_backward(const float* dy, const float* x, const flo
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
     hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean, save_rstd, kRowsPerChunk, partial);
-    hipLaunchKernelGGL(chan_final_kernel, dim3((C + 63) / 64), dim3(TT), 0, st, partial, nch, C, sums);
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(blocks(C)), dim3(TT), 0, st, sums, C, dgamma, dbeta);
+    hipLaunchKernelGGL(chan_final_kernel<FinalParamGrad>, dim3((C + 63) / 64), dim3(TT), 0, st, partial, nch, C, sums, FinalParamGrad{dgamma, dbeta});
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, save_mean, save_rstd,
                        gamma, sums);
     VIDC_CHECK_LAUNCH("bn_train_backward");
@@ -622,8 +653,7 @@ extern "C" int vidc_colsum(const float* dy, long long M, int C, int ld, float* o
     double* sums = partial + (size_t)nch * 2 * C;
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, (const float*)nullptr, (const float*)nullptr, M, C, ld, 0, 0,
                        (const float*)nullptr, (const float*)nullptr, kRowsPerChunk, partial);
-    hipLaunchKernelGGL(chan_final_kernel, dim3((C + 63) / 64), dim3(TT), 0, st, partial, nch, C, sums);
-    hipLaunchKernelGGL(colsum_out_kernel, dim3(blocks(C)), dim3(TT), 0, st, sums, C, out);
+    hipLaunchKernelGGL(chan_final_kernel<FinalColsum>, dim3((C + 63) / 64), dim3(TT), 0, st, partial, nch, C, sums, FinalColsum{out});
     VIDC_CHECK_LAUNCH("colsum");
     return VIDC_OK;
 }
@@ -719,6 +749,14 @@ extern "C" int vidc_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed,
     const long long total = (long long)Cout * Cin * KH * KW;
     hipLaunchKernelGGL(pack_weight_dgrad_kernel, dim3(blocks(total)), dim3(TT), 0, vidc::as_stream(stream), w_oihw, w_packed, Cout, Cin, KH, KW);
     VIDC_CHECK_LAUNCH("pack_weight_dgrad_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_pack_conv_weights_batched(const vidc_pack_item* items_device, int n_items, long long total_blocks, vidc_stream_t stream) {
+    VIDC_REQUIRE(items_device, VIDC_ERR_NULL, "vidc_pack_conv_weights_batched: null pointer");
+    VIDC_REQUIRE(n_items > 0 && total_blocks > 0 && total_blocks < (1ll << 31), VIDC_ERR_SHAPE, "vidc_pack_conv_weights_batched: bad item / block count");
+    hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)total_blocks), dim3(TT), 0, vidc::as_stream(stream), items_device, n_items);
+    VIDC_CHECK_LAUNCH("pack_batched_kernel");
     return VIDC_OK;
 }
 

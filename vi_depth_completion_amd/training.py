@@ -119,6 +119,7 @@ class DepthCompletionTrainer:
         self.step_count = 0
         self._ones, self._zeros, self._packed, self._scratch, self._nbt = {}, {}, {}, None, []
         self._gemm_ws = None
+        self._pack_items, self._pack_table, self._packed_fresh = [], None, False
         self.tune_hook = None      # tools/autotune_train.py: called with every conv descriptor before it is planned
         self.precision = L.PREC_BF16X3 if os.environ.get("VIDC_TRAIN_PRECISION", "fp32") == "bf16x3" else L.PREC_FP32
         self.last_loss = None
@@ -185,21 +186,39 @@ class DepthCompletionTrainer:
 
     def _pack(self, key, kind, w):
         """Packed weights of conv `key` for the forward ('f') or the dgrad ('d': kernel flipped, channels transposed) launch, in the
-        trainer's arithmetic mode; rebuilt every step (the parameters move)."""
+        trainer's arithmetic mode.  The parameters move every step: `repack()` rebuilds every packed copy with one launch at the start of
+        a forward; a conv met for the first time is packed here and joins the table."""
+        ent = self._packed.get((key, kind))
+        if ent is not None and self._packed_fresh:
+            return ent
         co, ci, kh, kw = w.shape
-        rows, K = (co, kh * kw * ci) if kind == "f" else (ci, kh * kw * co)
-        out = self._packed.setdefault((key, kind), self._empty(rows, K))
-        lib, st = L.lib(), L.current_stream()
-        if kind == "f" and self.precision == L.PREC_BF16X3:
-            L.check(lib.vidc_pack_conv_weight_bf16x3(L.ptr(w), L.ptr(out), co, ci, kh, kw, st), "pack")
-        elif kind == "f":
-            L.check(lib.vidc_pack_conv_weight(L.ptr(w), L.ptr(out), co, ci, kh, kw, st), "pack")
-        else:
-            tmp = out if self.precision == L.PREC_FP32 else self._packed.setdefault((key, "d32"), self._empty(rows, K))
-            L.check(lib.vidc_pack_conv_weight_dgrad(L.ptr(w), L.ptr(tmp), co, ci, kh, kw, st), "pack_dgrad")
-            if self.precision == L.PREC_BF16X3:          # split the packed rows: every 32-wide K unit becomes [32 x hi | 32 x lo]
-                L.check(lib.vidc_split_bf16x3(L.ptr(tmp), L.ptr(out), rows, K, K, st), "split_w")
-        return out
+        if ent is None:
+            ent = self._packed[(key, kind)] = self._empty(co * ci * kh * kw)
+            self._pack_items.append((w, ent, co, ci, kh, kw, (1 if kind == "d" else 0) | (2 if self.precision == L.PREC_BF16X3 else 0)))
+            self._pack_table = None
+        self._launch_pack([it for it in self._pack_items if it[1] is ent])
+        return ent
+
+    def _launch_pack(self, items):
+        table = (L.PackItem * len(items))()
+        blocks = 0
+        for t, (w, out, co, ci, kh, kw, kind) in zip(table, items):
+            t.w, t.packed, t.Cout, t.Cin, t.KH, t.KW, t.kind, t.block_begin = L.ptr(w), L.ptr(out), co, ci, kh, kw, kind, blocks
+            blocks += (co * ci * kh * kw + 255) // 256
+        dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
+        L.check(L.lib().vidc_pack_conv_weights_batched(L.ptr(dev), len(items), blocks, L.current_stream()), "pack")
+        return dev, blocks
+
+    def repack(self):
+        """One launch re-packs every conv weight seen so far (forward and dgrad copies) from the current parameters."""
+        if self._pack_items:
+            if self._pack_table is None:
+                dev, blocks = self._launch_pack(self._pack_items)
+                self._pack_table = (dev, blocks, len(self._pack_items))
+            else:
+                dev, blocks, n = self._pack_table
+                L.check(L.lib().vidc_pack_conv_weights_batched(L.ptr(dev), n, blocks, L.current_stream()), "pack")
+        self._packed_fresh = True
 
     def _wgrad_gemm(self, g, x, key, geom):
         """dW through the conv kernel: dW[co][tap][ci] = sum over pixels of dY^T[co][m] * Xt[tap*Cin + ci][m] is the 1x1 case of
@@ -413,6 +432,7 @@ class DepthCompletionTrainer:
     def forward(self, image, normal, depth_in):
         """Train-mode forward; returns the predicted depth (B,1,H,W).  The tape of backward closures is left in self.tape."""
         self.tape, self._nbt = [], []
+        self.repack()
         B, _, H, W = image.shape
         sizes = [((H - 1) // 2 + 1, (W - 1) // 2 + 1)]
         sizes[0] = ((sizes[0][0] - 1) // 2 + 1, (sizes[0][1] - 1) // 2 + 1)
@@ -512,6 +532,7 @@ class DepthCompletionTrainer:
         self.step_count += 1
         L.check(L.lib().vidc_adam_step(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.m), L.ptr(self.v), self.flat_p.numel(), self.lr, self.betas[0],
                                        self.betas[1], self.eps, self.step_count, L.current_stream()), "adam")
+        self._packed_fresh = False      # so are the trainer's own packed copies (re-made by the next forward's repack())
         self.cnn._invalidate()          # the inference programs' packed / BN-folded copies are stale now
 
     def step(self, image, normal, depth_in, depth_gt):
