@@ -453,9 +453,10 @@ int vidc_conv_wgrad(const float* dy, const float* x, float* dw_oihw, int B, int 
 /* wgrad as a GEMM on the conv kernel: dW[co][tap][ci] = sum_m dY^T[co][m] * Xt[tap*C + ci][m] is the 1x1 case of vidc_conv2d_bn_act with
  * "activations" = the rows of dY^T and "weights" = the rows of Xt (both K-contiguous, K = pixels).  vidc_im2col_transposed writes
  * xt[(tap*C + c)][m] = x[b, oy*s - p + kh, ox*s - p + kw, c] (0 outside the image and for m >= B*Ho*Wo; rows Mp long, Mp % 32 == 0);
- * with KH = KW = 1, stride 1, pad 0 it transposes dY.  vidc_wgrad_permute: dw_oihw[co][ci][tap] = tmp[co][tap*Cin + ci]. */
+ * with KH = KW = 1, stride 1, pad 0 it transposes dY; split != 0 writes the rows as split-bf16 operands (vidc_split_bf16x3's layout) for
+ * a VIDC_PREC_BF16X3 GEMM.  vidc_wgrad_permute: dw_oihw[co][ci][tap] = tmp[co][tap*Cin + ci]. */
 int vidc_im2col_transposed(const float* x, float* xt, int B, int H, int W, int C, int ldx, int Ho, int Wo, int KH, int KW, int stride, int pad,
-                           int Mp, vidc_stream_t stream);
+                           int Mp, int split, vidc_stream_t stream);
 int vidc_wgrad_permute(const float* tmp, float* dw_oihw, int Cout, int Cin, int taps, vidc_stream_t stream);
 /* wgrad of the 3x3 / stride-2 stem conv on the NCHW network input (Cin = 1 or 3). */
 size_t vidc_stem_wgrad_scratch_bytes(int B, int Cin, int H, int W, int Cout);

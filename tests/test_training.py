@@ -237,6 +237,73 @@ def _train_fixture(golden_dir):
 
 
 @gpu
+@pytest.mark.parametrize("k,stride,pad,C,H,W", [(3, 1, 1, 64, 9, 11), (3, 2, 1, 32, 10, 7), (1, 1, 0, 96, 5, 6), (1, 2, 0, 64, 7, 9)])
+def test_im2col_transposed_operands(k, stride, pad, C, H, W):
+    """The wgrad GEMM's operands (training.py `_wgrad_gemm`): xt[(tap*C + c)][m] is F.unfold's column matrix in (tap, channel) row order,
+    rows padded with zeros to a multiple of 32 -- exact (pure data movement); with split=1 the same rows bit-identical to
+    vidc_split_bf16x3 applied to the fp32 rows."""
+    from vi_depth_completion_amd import _lib as L
+    lib = L.lib()
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    M = B * Ho * Wo
+    Mp = (M + 31) // 32 * 32
+    cols = F.unfold(x, k, padding=pad, stride=stride)                       # (B, C*k*k, Ho*Wo), rows ordered (c, tap)
+    want = cols.view(B, C, k * k, Ho * Wo).permute(2, 1, 0, 3).reshape(k * k * C, M)
+    want = F.pad(want, (0, Mp - M))
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    xt = torch.full((k * k * C, Mp), float("nan"), device=DEV)
+    st = L.current_stream()
+    L.check(lib.vidc_im2col_transposed(L.ptr(xd), L.ptr(xt), B, H, W, C, C, Ho, Wo, k, k, stride, pad, Mp, 0, st), "im2col^T")
+    assert torch.equal(xt.cpu(), want)
+    xs = torch.empty_like(xt)
+    L.check(lib.vidc_im2col_transposed(L.ptr(xd), L.ptr(xs), B, H, W, C, C, Ho, Wo, k, k, stride, pad, Mp, 1, st), "im2col^T split")
+    ref = torch.empty_like(xt)
+    L.check(lib.vidc_split_bf16x3(L.ptr(xt), L.ptr(ref), k * k * C, Mp, Mp, st), "split")
+    assert torch.equal(xs.view(torch.int32).cpu(), ref.view(torch.int32).cpu())
+
+
+@gpu
+def test_batched_weight_packing_equals_the_per_layer_packs():
+    """vidc_pack_conv_weights_batched (one launch for the whole network, every step) against the per-layer entry points it replaces:
+    forward / dgrad, fp32 / split-bf16 -- byte-identical."""
+    from vi_depth_completion_amd import _lib as L
+    lib, st = L.lib(), L.current_stream()
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 32, 3, 3), (96, 64, 1, 1), (32, 128, 3, 3), (256, 64, 1, 1), (64, 64, 3, 3)]
+    ws = [torch.randn(*sh, generator=g).to(DEV) for sh in shapes]
+    items, want = [], []
+    for w in ws:
+        co, ci, kh, kw = w.shape
+        n = w.numel()
+        for kind in range(4):
+            ref = torch.empty(n, device=DEV)
+            if kind == 0:
+                L.check(lib.vidc_pack_conv_weight(L.ptr(w), L.ptr(ref), co, ci, kh, kw, st), "pack")
+            elif kind == 2:
+                L.check(lib.vidc_pack_conv_weight_bf16x3(L.ptr(w), L.ptr(ref), co, ci, kh, kw, st), "pack")
+            else:
+                tmp = torch.empty(n, device=DEV)
+                L.check(lib.vidc_pack_conv_weight_dgrad(L.ptr(w), L.ptr(tmp if kind == 3 else ref), co, ci, kh, kw, st), "pack")
+                if kind == 3:
+                    L.check(lib.vidc_split_bf16x3(L.ptr(tmp), L.ptr(ref), ci, kh * kw * co, kh * kw * co, st), "split")
+            want.append(ref)
+            items.append((w, torch.full((n,), float("nan"), device=DEV), co, ci, kh, kw, kind))
+    table = (L.PackItem * len(items))()
+    blocks = 0
+    for t, (w, out, co, ci, kh, kw, kind) in zip(table, items):
+        t.w, t.packed, t.Cout, t.Cin, t.KH, t.KW, t.kind, t.block_begin = L.ptr(w), L.ptr(out), co, ci, kh, kw, kind, blocks
+        blocks += (w.numel() + 255) // 256
+    dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(DEV)
+    L.check(lib.vidc_pack_conv_weights_batched(L.ptr(dev), len(items), blocks, st), "batched pack")
+    for (w, out, *_rest), ref in zip(items, want):
+        assert torch.equal(out.view(torch.int32).cpu(), ref.view(torch.int32).cpu()), "kind %d of %s" % (_rest[-1], tuple(w.shape))
+    assert lib.vidc_pack_conv_weights_batched(None, 1, 1, st) != 0 and lib.vidc_pack_conv_weights_batched(L.ptr(dev), 0, 0, st) != 0
+
+
+@gpu
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 def test_training_iteration_vs_reference(golden_dir, seeded_weights, monkeypatch, precision):
     """(precision: the arithmetic of the forward / dgrad convs.  fp32 = exact products like the reference, the trainer's default: the
@@ -335,6 +402,36 @@ def test_training_loop_on_pipeline_inputs(seeded_weights):
     pipe.rng = np.random.RandomState(3)
     after = pipe._call_cnn(batch)
     assert torch.isfinite(after).all() and float((after - before).abs().mean()) > 1e-4      # the trained weights are the ones that run
+
+
+@gpu
+def test_graph_replay_equals_eager_steps(seeded_weights):
+    """`step()` replays forward + backward as one captured hipGraph from the third step of a shape on: five steps on changing inputs,
+    graph on against graph off -- the same kernels in the same order with fixed-order reductions, so losses, parameters and running
+    statistics are bit-identical."""
+    from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
+    from vi_depth_completion_amd.training import DepthCompletionTrainer
+    runs = []
+    for use_graph in (False, True):
+        cnn = ModifiedFPN().to(DEV)
+        cnn.load_state_dict({k: v.to(DEV) for k, v in seeded_weights["dc"].items()})
+        cnn.train()
+        tr = DepthCompletionTrainer(cnn, 1e-4)
+        tr.use_graph = use_graph
+        losses = []
+        for it in range(5):
+            b = S.synthetic_batch(1, 96, 128, 77, frame0=it)
+            image = b["image"].to(DEV)
+            normal = F.normalize(image - 0.5, dim=1)
+            gt = S.synthetic_ground_truth_depth(b["image"], 77).to(DEV)
+            losses.append(float(tr.step(image, normal, b["sparse_depth"].to(DEV), gt)))
+        assert bool(tr._graphs) == use_graph
+        runs.append((losses, tr.flat_p.clone(), {k: v.clone() for k, v in cnn.state_dict().items() if "running" in k or "tracked" in k}))
+    (l0, p0, s0), (l1, p1, s1) = runs
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(p0, p1)
+    assert all(torch.equal(s0[k], s1[k]) for k in s0)
+    assert int(s1["resnet_rgb.bn1.num_batches_tracked"]) == 5 if "resnet_rgb.bn1.num_batches_tracked" in s1 else True
 
 
 @gpu

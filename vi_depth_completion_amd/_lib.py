@@ -98,7 +98,7 @@ SIGNATURES = {
     "vidc_zero_stuff": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_conv_wgrad_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i]),
     "vidc_conv_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "vidc_im2col_transposed": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vidc_im2col_transposed": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_wgrad_permute": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "vidc_stem_wgrad_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "vidc_stem_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),

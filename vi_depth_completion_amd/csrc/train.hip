@@ -536,10 +536,11 @@ wgrad_final_kernel(const float* __restrict__ partial, int n_chunks, int taps, in
 // the 1x1 case of conv_mfma.hip (activations = rows of dY^T, weights = rows of Xt), which runs at several times the rate of the
 // direct kernel above (LDS-tiled, split-K, fp32 or bf16x3).  This kernel builds the operands: xt[(tap*C + c)][m] = x[b, oy*s - p + kh,
 // ox*s - p + kw, c] (0 outside the image and for m >= M; rows are Mp = M rounded up to 32 long), through a 32x32 LDS transpose so that
-// both the NHWC reads and the row writes are 128-byte coalesced.  With KH = KW = 1, s = 1, p = 0 it is the transpose of dY.
+// both the NHWC reads and the row writes are 128-byte coalesced.  With KH = KW = 1, s = 1, p = 0 it is the transpose of dY.  split != 0 writes
+// the rows in the split-bf16 operand format of the bf16x3 mode directly (vidc_split_bf16x3's layout; same bytes per row).
 __global__ void __launch_bounds__(256)
 im2col_t_kernel(const float* __restrict__ x, float* __restrict__ xt, int B, int H, int W, int C, int ldx, int Ho, int Wo, int KH, int KW, int stride,
-                int pad, int M, int Mp) {
+                int pad, int M, int Mp, int split) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tap = blockIdx.z;
@@ -559,7 +560,18 @@ im2col_t_kernel(const float* __restrict__ x, float* __restrict__ xt, int B, int 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int c = c0 + ty + 8 * r, m = m0 + tx;
-        if (c < C && m < Mp) xt[((size_t)tap * C + c) * Mp + m] = tile[tx][ty + 8 * r];
+        if (c < C && m < Mp) {
+            const float v = tile[tx][ty + 8 * r];
+            if (split) {         // the 32 pixels of this tile are one K unit of the GEMM: [32 x hi | 32 x lo] in the same 128 bytes
+                unsigned short h, l;
+                vidc::split_bf16(v, h, l);
+                unsigned short* u = reinterpret_cast<unsigned short*>(xt + ((size_t)tap * C + c) * Mp + m0);
+                u[tx] = h;
+                u[32 + tx] = l;
+            } else {
+                xt[((size_t)tap * C + c) * Mp + m] = v;
+            }
+        }
     }
 }
 // dw_oihw[co][ci][tap] = tmp[co][tap * Cin + ci]
@@ -813,13 +825,13 @@ extern "C" int vidc_conv_wgrad(const float* dy, const float* x, float* dw_oihw, 
 }
 
 extern "C" int vidc_im2col_transposed(const float* x, float* xt, int B, int H, int W, int C, int ldx, int Ho, int Wo, int KH, int KW, int stride, int pad,
-                                      int Mp, vidc_stream_t stream) {
+                                      int Mp, int split, vidc_stream_t stream) {
     VIDC_REQUIRE(x && xt, VIDC_ERR_NULL, "vidc_im2col_transposed: null pointer");
     const long long M = (long long)B * Ho * Wo;
     VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0 && Mp >= M && Mp % 32 == 0 && M < (1ll << 31) &&
                      (long long)KH * KW <= 65535, VIDC_ERR_SHAPE, "vidc_im2col_transposed: bad shape (Mp = M rounded up to a multiple of 32)");
     hipLaunchKernelGGL(im2col_t_kernel, dim3(Mp / 32, (C + 31) / 32, KH * KW), dim3(256), 0, vidc::as_stream(stream), x, xt, B, H, W, C, ldx, Ho, Wo, KH, KW,
-                       stride, pad, (int)M, Mp);
+                       stride, pad, (int)M, Mp, split);
     VIDC_CHECK_LAUNCH("im2col_t_kernel");
     return VIDC_OK;
 }

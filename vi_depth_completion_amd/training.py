@@ -120,6 +120,8 @@ class DepthCompletionTrainer:
         self._ones, self._zeros, self._packed, self._scratch, self._nbt = {}, {}, {}, None, []
         self._gemm_ws = None
         self._pack_items, self._pack_table, self._packed_fresh = [], None, False
+        self.use_graph = os.environ.get("VIDC_TRAIN_GRAPH", "1") != "0"
+        self._graphs, self._graph_seen = {}, {}
         self.tune_hook = None      # tools/autotune_train.py: called with every conv descriptor before it is planned
         self.precision = L.PREC_BF16X3 if os.environ.get("VIDC_TRAIN_PRECISION", "fp32") == "bf16x3" else L.PREC_FP32
         self.last_loss = None
@@ -234,13 +236,9 @@ class DepthCompletionTrainer:
         if taps * ci * Mp * 4 >= (1 << 31) or co * Mp >= (1 << 29) or ci % 32 or co % 4:
             return False
         gt, xt, tmp = self._empty(co, Mp), self._empty(taps * ci, Mp), self._empty(co, taps * ci)
-        L.check(lib.vidc_im2col_transposed(L.ptr(g), L.ptr(gt), B, Ho, Wo, co, _ld(g), Ho, Wo, 1, 1, 1, 0, Mp, st), "transpose dY")
-        L.check(lib.vidc_im2col_transposed(L.ptr(x.t), L.ptr(xt), B, H, W, ci, x.ld, Ho, Wo, kh, kw, stride, pad, Mp, st), "im2col^T")
-        if self.precision == L.PREC_BF16X3:
-            gs, xs = self._empty(co, Mp), self._empty(taps * ci, Mp)
-            L.check(lib.vidc_split_bf16x3(L.ptr(gt), L.ptr(gs), co, Mp, Mp, st), "split")
-            L.check(lib.vidc_split_bf16x3(L.ptr(xt), L.ptr(xs), taps * ci, Mp, Mp, st), "split")
-            gt, xt = gs, xs
+        split = 1 if self.precision == L.PREC_BF16X3 else 0          # operands written in the split-bf16 format directly
+        L.check(lib.vidc_im2col_transposed(L.ptr(g), L.ptr(gt), B, Ho, Wo, co, _ld(g), Ho, Wo, 1, 1, 1, 0, Mp, split, st), "transpose dY")
+        L.check(lib.vidc_im2col_transposed(L.ptr(x.t), L.ptr(xt), B, H, W, ci, x.ld, Ho, Wo, kh, kw, stride, pad, Mp, split, st), "im2col^T")
         n_out = taps * ci
         d = L.ConvDesc()
         d.x, d.w, d.y = L.ptr(gt), L.ptr(xt), L.ptr(tmp)
@@ -536,8 +534,37 @@ class DepthCompletionTrainer:
         self.cnn._invalidate()          # the inference programs' packed / BN-folded copies are stale now
 
     def step(self, image, normal, depth_in, depth_gt):
-        """One `_run_training_iteration`: returns the loss (0-dim fp64 GPU tensor, this rank's frames)."""
-        loss, _ = self.forward_backward(image, normal, depth_in, depth_gt)
+        """One `_run_training_iteration`: returns the loss (0-dim fp64 GPU tensor, this rank's frames).
+
+        The forward + backward of a step is ~4000 launches from Python (~17 us of host time each: host-bound once the convs run in the
+        bf16x3 mode), all with shape-static arguments, so from the third step of a given input shape on it is replayed as ONE captured
+        hipGraph (VIDC_TRAIN_GRAPH=0: always eager).  The all-reduce and the Adam launch (its bias correction takes the step number
+        by value) stay outside the graph."""
+        if self.use_graph:
+            loss = self._graphed_forward_backward(image, normal, depth_in, depth_gt)
+        else:
+            loss, _ = self.forward_backward(image, normal, depth_in, depth_gt)
         self.optimizer_step()
         self.last_loss = loss
         return loss
+
+    def _graphed_forward_backward(self, image, normal, depth_in, depth_gt):
+        ins = (image, normal, depth_in, depth_gt)
+        key = tuple((tuple(t.shape), t.dtype) for t in ins)
+        ent = self._graphs.get(key)
+        if ent is None:
+            seen = self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+            if seen <= 2:                     # eager: creates the packed-weight table, constants, scratch and split-K workspace
+                return self.forward_backward(*ins)[0]
+            static = [t.clone() for t in ins]
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss, pred = self.forward_backward(*static)
+            ent = self._graphs[key] = (graph, static, loss, pred)
+        graph, static, loss, pred = ent
+        for dst, src in zip(static, ins):
+            dst.copy_(src)
+        self._packed_fresh = True             # the graph starts with repack()
+        graph.replay()
+        return loss.clone()
