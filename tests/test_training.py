@@ -237,7 +237,7 @@ def _train_fixture(golden_dir):
 
 
 @gpu
-@pytest.mark.parametrize("k,stride,pad,C,H,W", [(3, 1, 1, 64, 9, 11), (3, 2, 1, 32, 10, 7), (1, 1, 0, 96, 5, 6), (1, 2, 0, 64, 7, 9)])
+@pytest.mark.parametrize("k,stride,pad,C,H,W", [(3, 1, 1, 64, 9, 11), (3, 2, 1, 32, 10, 7), (1, 1, 0, 96, 5, 6), (1, 2, 0, 64, 7, 9), (3, 1, 1, 30, 6, 7), (1, 1, 0, 132, 9, 13)])
 def test_im2col_transposed_operands(k, stride, pad, C, H, W):
     """The wgrad GEMM's operands (training.py `_wgrad_gemm`): xt[(tap*C + c)][m] is F.unfold's column matrix in (tap, channel) row order,
     rows padded with zeros to a multiple of 32 -- exact (pure data movement); with split=1 the same rows bit-identical to

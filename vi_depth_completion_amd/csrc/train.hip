@@ -98,21 +98,26 @@ struct FinalColsum {     // bias gradient of a conv: column sums of dY (first su
     __device__ void operator()(int c, double s0, double) const { out[c] = (float)s0; }
 };
 
-// sums[q][C] = sum over chunks: block = 64 channels x 4 lanes, lane l adds chunks l, l+4, ... in order, then ((l0 + l1) + (l2 + l3)) -- fixed
-// order; `fin` then turns the two sums of a channel into the op's per-channel outputs
+// sums[q][C] = sum over chunks: block = 8 channels x 32 lanes; lane l adds chunks l, l+32, ... in order, then the 32 lane sums are added
+// pairwise (a fixed tree) -- bit-reproducible; `fin` then turns the two sums of a channel into the op's per-channel outputs
 template <typename Final>
 __global__ void __launch_bounds__(TT) chan_final_kernel(const double* __restrict__ partial, int n_chunks, int C, double* __restrict__ sums, Final fin) {
-    __shared__ double red[2][4][64];
-    const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + l;
+    __shared__ double red[2][32][8];
+    const int l = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + l;
     double s0 = 0.0, s1 = 0.0;
     if (c < C)
-        for (int k = rl; k < n_chunks; k += 4) { s0 += partial[((size_t)k * 2 + 0) * C + c]; s1 += partial[((size_t)k * 2 + 1) * C + c]; }
+        for (int k = rl; k < n_chunks; k += 32) { s0 += partial[((size_t)k * 2 + 0) * C + c]; s1 += partial[((size_t)k * 2 + 1) * C + c]; }
     red[0][rl][l] = s0; red[1][rl][l] = s1;
     __syncthreads();
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+        if (rl < w) { red[0][rl][l] += red[0][rl + w][l]; red[1][rl][l] += red[1][rl + w][l]; }
+        __syncthreads();
+    }
     if (rl == 0 && c < C) {
-        s0 = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
-        s1 = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+        s0 = red[0][0][l];
+        s1 = red[1][0][l];
         sums[c] = s0;
         sums[C + c] = s1;
         fin(c, s0, s1);
@@ -574,6 +579,48 @@ im2col_t_kernel(const float* __restrict__ x, float* __restrict__ xt, int B, int 
         }
     }
 }
+// The same map on 64 pixels x 64 channels per workgroup with 16-byte accesses on both sides (C % 4 == 0, ldx % 4 == 0, 16-byte aligned
+// pointers; Mp % 32 == 0 makes every 4-pixel group of a row all-inside or all-outside).  LDS tile [pixel][channel], row pitch 65 floats:
+// the 4 x 16 lanes of a wave hit 64 different banks in both phases.
+__global__ void __launch_bounds__(256)
+im2col_t64_kernel(const float* __restrict__ x, float* __restrict__ xt, int B, int H, int W, int C, int ldx, int Ho, int Wo, int KH, int KW, int stride,
+                  int pad, int M, int Mp, int split) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
+    const int kh = tap / KW, kw = tap - kh * KW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + ty + 16 * r, c = c0 + tx * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M && c < C) {
+            const int ox = m % Wo, q = m / Wo, oy = q % Ho, b = q / Ho;
+            const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const float4*>(x + ((size_t)(b * H + iy) * W + ix) * ldx + c);
+        }
+        float* t = &tile[ty + 16 * r][tx * 4];
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cl = ty + 16 * r, c = c0 + cl, m = m0 + tx * 4;
+        if (c < C && m < Mp) {
+            const float v[4] = {tile[tx * 4][cl], tile[tx * 4 + 1][cl], tile[tx * 4 + 2][cl], tile[tx * 4 + 3][cl]};
+            float* row = xt + ((size_t)tap * C + c) * Mp;
+            if (split) {         // 4 pixels of one 32-pixel K unit: their hi halves and their lo halves, 8 bytes each
+                unsigned short h[4], l[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) vidc::split_bf16(v[k], h[k], l[k]);
+                unsigned short* u = reinterpret_cast<unsigned short*>(row + (m & ~31)) + (m & 31);
+                *reinterpret_cast<uint2*>(u) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                *reinterpret_cast<uint2*>(u + 32) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+            } else {
+                *reinterpret_cast<float4*>(row + m) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
 // dw_oihw[co][ci][tap] = tmp[co][tap * Cin + ci]
 __global__ void __launch_bounds__(TT) wgrad_permute_kernel(const float* __restrict__ tmp, float* __restrict__ dw, int Cout, int Cin, int taps) {
     const long long i = (long long)blockIdx.x * TT + threadIdx.x;
@@ -613,11 +660,20 @@ stem_wgrad_partial_kernel(const float* __restrict__ dy, const float* __restrict_
 namespace {
 constexpr int kRowsPerChunk = 256;        // rows per workgroup of the per-channel reductions: M = 10^4..10^5 rows -> hundreds of workgroups per 64 channels
 inline int chunks_for(long long M) { return (int)((M + kRowsPerChunk - 1) / kRowsPerChunk); }
+// Rows per workgroup of the per-channel reductions (chan_partial_kernel): about 512 workgroups per launch whatever the shape -- a function of
+// (M, C) only, so the summation order of a given tensor never changes.  Multiple of 16 (the row-lanes of a block), 32..256.
+inline int rows_for(long long M, int C) {
+    const long long cb = (C + 63) / 64;
+    long long r = (M * cb + 511) / 512;
+    r = (r + 15) / 16 * 16;
+    return (int)(r < 32 ? 32 : (r > 256 ? 256 : r));
+}
+inline int chunks_for(long long M, int C) { const int r = rows_for(M, C); return (int)((M + r - 1) / r); }
 inline unsigned blocks(long long n) { return (unsigned)((n + TT - 1) / TT); }
 }
 
 extern "C" size_t vidc_train_scratch_bytes(long long M, int C) {
-    return ((size_t)chunks_for(M) * 2 * (size_t)C + 2 * (size_t)C) * sizeof(double) + 256;
+    return ((size_t)chunks_for(M, C) * 2 * (size_t)C + 2 * (size_t)C) * sizeof(double) + 256;
 }
 
 extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
@@ -626,12 +682,12 @@ extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int 
     VIDC_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && scratch, VIDC_ERR_NULL, "vidc_bn_train_forward: null pointer");
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0, VIDC_ERR_SHAPE, "vidc_bn_train_forward: bad shape");
     hipStream_t st = vidc::as_stream(stream);
-    const int nch = chunks_for(M);
+    const int nch = chunks_for(M, C);
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, x, (const float*)nullptr, (const float*)nullptr, M, C, ldx, 0, 0,
-                       (const float*)nullptr, (const float*)nullptr, kRowsPerChunk, partial);
-    hipLaunchKernelGGL(chan_final_kernel<FinalStats>, dim3((C + 63) / 64), dim3(TT), 0, st, partial, nch, C, sums,
+                       (const float*)nullptr, (const float*)nullptr, rows_for(M, C), partial);
+    hipLaunchKernelGGL(chan_final_kernel<FinalStats>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums,
                        FinalStats{M, eps, momentum, save_mean, save_rstd, running_mean, running_var});
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, x, y, M, C, ldx, ldy, save_mean, save_rstd, gamma, beta, relu);
     VIDC_CHECK_LAUNCH("bn_train_forward");
@@ -645,11 +701,11 @@ extern "C" int vidc_bn_train_backward(const float* dy, const float* x, const flo
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!y_relu || ldy % 4 == 0), VIDC_ERR_SHAPE,
                  "vidc_bn_train_backward: bad shape");
     hipStream_t st = vidc::as_stream(stream);
-    const int nch = chunks_for(M);
+    const int nch = chunks_for(M, C);
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
-    hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean, save_rstd, kRowsPerChunk, partial);
-    hipLaunchKernelGGL(chan_final_kernel<FinalParamGrad>, dim3((C + 63) / 64), dim3(TT), 0, st, partial, nch, C, sums, FinalParamGrad{dgamma, dbeta});
+    hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean, save_rstd, rows_for(M, C), partial);
+    hipLaunchKernelGGL(chan_final_kernel<FinalParamGrad>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, FinalParamGrad{dgamma, dbeta});
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, save_mean, save_rstd,
                        gamma, sums);
     VIDC_CHECK_LAUNCH("bn_train_backward");
@@ -660,12 +716,12 @@ extern "C" int vidc_colsum(const float* dy, long long M, int C, int ld, float* o
     VIDC_REQUIRE(dy && out && scratch, VIDC_ERR_NULL, "vidc_colsum: null pointer");
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0, VIDC_ERR_SHAPE, "vidc_colsum: bad shape (C and ld multiples of 4)");
     hipStream_t st = vidc::as_stream(stream);
-    const int nch = chunks_for(M);
+    const int nch = chunks_for(M, C);
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, (const float*)nullptr, (const float*)nullptr, M, C, ld, 0, 0,
-                       (const float*)nullptr, (const float*)nullptr, kRowsPerChunk, partial);
-    hipLaunchKernelGGL(chan_final_kernel<FinalColsum>, dim3((C + 63) / 64), dim3(TT), 0, st, partial, nch, C, sums, FinalColsum{out});
+                       (const float*)nullptr, (const float*)nullptr, rows_for(M, C), partial);
+    hipLaunchKernelGGL(chan_final_kernel<FinalColsum>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, FinalColsum{out});
     VIDC_CHECK_LAUNCH("colsum");
     return VIDC_OK;
 }
@@ -830,8 +886,13 @@ extern "C" int vidc_im2col_transposed(const float* x, float* xt, int B, int H, i
     const long long M = (long long)B * Ho * Wo;
     VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0 && Mp >= M && Mp % 32 == 0 && M < (1ll << 31) &&
                      (long long)KH * KW <= 65535, VIDC_ERR_SHAPE, "vidc_im2col_transposed: bad shape (Mp = M rounded up to a multiple of 32)");
-    hipLaunchKernelGGL(im2col_t_kernel, dim3(Mp / 32, (C + 31) / 32, KH * KW), dim3(256), 0, vidc::as_stream(stream), x, xt, B, H, W, C, ldx, Ho, Wo, KH, KW,
-                       stride, pad, (int)M, Mp, split);
+    const bool wide = C % 4 == 0 && ldx % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xt)) & 15) == 0;
+    if (wide)
+        hipLaunchKernelGGL(im2col_t64_kernel, dim3((Mp + 63) / 64, (C + 63) / 64, KH * KW), dim3(256), 0, vidc::as_stream(stream), x, xt, B, H, W, C, ldx, Ho, Wo,
+                           KH, KW, stride, pad, (int)M, Mp, split);
+    else
+        hipLaunchKernelGGL(im2col_t_kernel, dim3(Mp / 32, (C + 31) / 32, KH * KW), dim3(256), 0, vidc::as_stream(stream), x, xt, B, H, W, C, ldx, Ho, Wo, KH, KW,
+                           stride, pad, (int)M, Mp, split);
     VIDC_CHECK_LAUNCH("im2col_t_kernel");
     return VIDC_OK;
 }
