@@ -133,8 +133,13 @@ enum vidc_conv_tile { VIDC_TILE_AUTO = 0, VIDC_TILE_128x128 = 1, VIDC_TILE_128x6
  * BF16X3: every operand is split as x = hi + lo (bf16 each, round-to-nearest-even) and each product is computed as
  * lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-16 relative per product; whole-path
  * depth RMSE 1.4e-5 against fp32, bar 1e-3).  A 32-channel unit of a split tensor is [32 x bf16 hi | 32 x bf16 lo],
- * i.e. the same 128 bytes as 32 floats, so all strides/offsets of the fp32 layout carry over unchanged. */
-enum vidc_conv_precision { VIDC_PREC_FP32 = 0, VIDC_PREC_BF16X3 = 1 };
+ * i.e. the same 128 bytes as 32 floats, so all strides/offsets of the fp32 layout carry over unchanged.
+ * BF16 (the arithmetic BASELINE configs[4] names for training): plain bf16 operands (vidc_cast_bf16 / pack kinds 4, 5), fp32
+ * accumulation, fp32 output.  128 bytes of a row are 64 bf16 channels, so the descriptor counts TWO channels per element:
+ * Cin, ldx, x_gs = bf16 channels / 2 (Cin a multiple of 32, i.e. 64 bf16 channels), w_gs = Cout*KH*KW*Cin.  2 MFMAs per 16 k. */
+enum vidc_conv_precision { VIDC_PREC_FP32 = 0, VIDC_PREC_BF16X3 = 1, VIDC_PREC_BF16 = 2 };
+/* fp32 NHWC rows [rows][ldx] (first C channels) -> dense bf16 rows [rows][C] (round to nearest even); C % 8 == 0. */
+int vidc_cast_bf16(const float* x, void* y, long long rows, int C, int ldx, vidc_stream_t stream);
 /* fp32 NHWC rows [rows][ldx] (first C channels) -> split image [rows][C/32][hi|lo]; C % 32 == 0. */
 int vidc_split_bf16x3(const float* x, void* y, long long rows, int C, int ldx, vidc_stream_t stream);
 /* OIHW fp32 -> split packed weights [Cout][Cin/32][KH][KW][hi|lo] (one group per call). */
@@ -435,7 +440,8 @@ int vidc_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int Cout, 
 /* All conv weights of a network re-packed by one launch (they move every optimizer step).  `items_device`: n_items descriptors in
  * device memory, sorted by block_begin; item i owns blocks [block_begin_i, block_begin_{i+1}) of 256 elements each, ceil(Cout*Cin*KH*KW
  * / 256) of them; total_blocks = their sum.  kind: 0 forward fp32 (vidc_pack_conv_weight), 1 dgrad fp32 (vidc_pack_conv_weight_dgrad),
- * 2 / 3 the same two in split-bf16 (vidc_pack_conv_weight_bf16x3; dgrad rows split like vidc_split_bf16x3). */
+ * 2 / 3 the same two in split-bf16 (vidc_pack_conv_weight_bf16x3; dgrad rows split like vidc_split_bf16x3), 4 / 5 in plain bf16 for
+ * VIDC_PREC_BF16 ([row][channels/64][KH][KW][64 x bf16]; the K-side channel count a multiple of 64). */
 typedef struct vidc_pack_item {
     const float* w;          /* OIHW parameter                                   */
     float* packed;           /* Cout*Cin*KH*KW floats                            */
@@ -453,8 +459,8 @@ int vidc_conv_wgrad(const float* dy, const float* x, float* dw_oihw, int B, int 
 /* wgrad as a GEMM on the conv kernel: dW[co][tap][ci] = sum_m dY^T[co][m] * Xt[tap*C + ci][m] is the 1x1 case of vidc_conv2d_bn_act with
  * "activations" = the rows of dY^T and "weights" = the rows of Xt (both K-contiguous, K = pixels).  vidc_im2col_transposed writes
  * xt[(tap*C + c)][m] = x[b, oy*s - p + kh, ox*s - p + kw, c] (0 outside the image and for m >= B*Ho*Wo; rows Mp long, Mp % 32 == 0);
- * with KH = KW = 1, stride 1, pad 0 it transposes dY; split != 0 writes the rows as split-bf16 operands (vidc_split_bf16x3's layout) for
- * a VIDC_PREC_BF16X3 GEMM.  vidc_wgrad_permute: dw_oihw[co][ci][tap] = tmp[co][tap*Cin + ci]. */
+ * with KH = KW = 1, stride 1, pad 0 it transposes dY; split = 1 writes the rows as split-bf16 operands (vidc_split_bf16x3's layout) for
+ * a VIDC_PREC_BF16X3 GEMM, split = 2 as plain bf16 rows (Mp % 64 == 0) for a VIDC_PREC_BF16 one.  vidc_wgrad_permute: dw_oihw[co][ci][tap] = tmp[co][tap*Cin + ci]. */
 int vidc_im2col_transposed(const float* x, float* xt, int B, int H, int W, int C, int ldx, int Ho, int Wo, int KH, int KW, int stride, int pad,
                            int Mp, int split, vidc_stream_t stream);
 int vidc_wgrad_permute(const float* tmp, float* dw_oihw, int Cout, int Cin, int taps, vidc_stream_t stream);

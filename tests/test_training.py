@@ -263,6 +263,78 @@ def test_im2col_transposed_operands(k, stride, pad, C, H, W):
     ref = torch.empty_like(xt)
     L.check(lib.vidc_split_bf16x3(L.ptr(xt), L.ptr(ref), k * k * C, Mp, Mp, st), "split")
     assert torch.equal(xs.view(torch.int32).cpu(), ref.view(torch.int32).cpu())
+    Mq = (M + 63) // 64 * 64                                               # plain bf16 rows (split = 2): Mp a multiple of 64
+    xb = torch.empty(k * k * C, Mq // 2, device=DEV)
+    L.check(lib.vidc_im2col_transposed(L.ptr(xd), L.ptr(xb), B, H, W, C, C, Ho, Wo, k, k, stride, pad, Mq, 2, st), "im2col^T bf16")
+    assert torch.equal(xb.view(torch.bfloat16).cpu(), F.pad(want, (0, Mq - Mp)).to(torch.bfloat16))
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@gpu
+@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,tile", [(64, 64, 3, 1, 1, 12, 20, 4), (128, 128, 1, 1, 0, 9, 7, 6), (192, 64, 3, 2, 1, 11, 13, 0), (64, 128, 3, 1, 1, 16, 16, 3)])
+def test_plain_bf16_conv_mode(cin, cout, k, stride, pad, H, W, tile):
+    """VIDC_PREC_BF16 (the arithmetic BASELINE configs[4] names): operands rounded to bf16 by vidc_cast_bf16 / pack kinds 4, 5, products
+    exact (bf16 x bf16 fits fp32), fp32 accumulation -- so the result equals F.conv2d of the bf16-ROUNDED operands in fp32 up to
+    summation order (1e-5 of scale), forward weights and dgrad weights alike."""
+    from vi_depth_completion_amd import _lib as L
+    import ctypes as C
+    lib, st = L.lib(), L.current_stream()
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    want = F.conv2d(_bf16_round(x), _bf16_round(w), None, stride, pad)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    xb = torch.empty(B, H, W, cin // 2, device=DEV)
+    L.check(lib.vidc_cast_bf16(L.ptr(xd), L.ptr(xb), B * H * W, cin, cin, st), "cast")
+    assert torch.equal(xb.view(torch.bfloat16).cpu(), x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16))
+    wd = w.to(DEV)
+    wp = torch.empty(w.numel() // 2, device=DEV)
+    item = (L.PackItem * 1)()
+    item[0].w, item[0].packed, item[0].Cout, item[0].Cin, item[0].KH, item[0].KW, item[0].kind, item[0].block_begin = L.ptr(wd), L.ptr(wp), cout, cin, k, k, 4, 0
+    dev = torch.frombuffer(bytearray(bytes(item)), dtype=torch.uint8).to(DEV)
+    L.check(lib.vidc_pack_conv_weights_batched(L.ptr(dev), 1, (w.numel() + 255) // 256, st), "pack")
+    y = torch.empty(B, Ho, Wo, cout, device=DEV)
+    ones, zeros = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+    d = L.ConvDesc()
+    d.x, d.w, d.y, d.scale1, d.shift1 = L.ptr(xb), L.ptr(wp), L.ptr(y), L.ptr(ones), L.ptr(zeros)
+    d.B, d.H, d.W, d.Cin, d.ldx = B, H, W, cin // 2, cin // 2
+    d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, cout, cout
+    d.KH, d.KW, d.stride, d.pad, d.flags = k, k, stride, pad, 0
+    d.groups, d.splitk, d.precision, d.tile = 1, 1, L.PREC_BF16, tile
+    d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin // 2, cout * k * k * cin // 2, cout, cout
+    if tile == 0:
+        L.check(lib.vidc_conv2d_plan(C.byref(d)), "plan")
+        d.splitk = 1
+    L.check(lib.vidc_conv2d_bn_act(C.byref(d), st), "conv bf16")
+    _close(_nchw(y), want, 1e-5, "bf16 conv")
+    # dgrad weights (kind 5): dx = conv_transpose of dy, stride 1 only here
+    if stride == 1:
+        gy = torch.randn(B, cout, Ho, Wo, generator=g)
+        want_dx = F.conv_transpose2d(_bf16_round(gy), _bf16_round(w), None, 1, pad)
+        item[0].kind = 5
+        wq = torch.empty(w.numel() // 2, device=DEV)
+        item[0].packed = L.ptr(wq)
+        dev = torch.frombuffer(bytearray(bytes(item)), dtype=torch.uint8).to(DEV)
+        L.check(lib.vidc_pack_conv_weights_batched(L.ptr(dev), 1, (w.numel() + 255) // 256, st), "pack dgrad")
+        gd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
+        gb = torch.empty(B, Ho, Wo, cout // 2, device=DEV)
+        L.check(lib.vidc_cast_bf16(L.ptr(gd), L.ptr(gb), B * Ho * Wo, cout, cout, st), "cast")
+        dx = torch.empty(B, H, W, cin, device=DEV)
+        o2, z2 = torch.ones(cin, device=DEV), torch.zeros(cin, device=DEV)
+        e = L.ConvDesc()
+        e.x, e.w, e.y, e.scale1, e.shift1 = L.ptr(gb), L.ptr(wq), L.ptr(dx), L.ptr(o2), L.ptr(z2)
+        e.B, e.H, e.W, e.Cin, e.ldx = B, Ho, Wo, cout // 2, cout // 2
+        e.Ho, e.Wo, e.Cout, e.ldy = H, W, cin, cin
+        e.KH, e.KW, e.stride, e.pad, e.flags = k, k, 1, k - 1 - pad, 0
+        e.groups, e.splitk, e.precision, e.tile = 1, 1, L.PREC_BF16, 4
+        e.x_gs, e.w_gs, e.y_gs, e.p_gs = cout // 2, cin * k * k * cout // 2, cin, cin
+        L.check(lib.vidc_conv2d_bn_act(C.byref(e), st), "dgrad bf16")
+        _close(_nchw(dx), want_dx, 1e-5, "bf16 dgrad")
 
 
 @gpu

@@ -68,7 +68,12 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--only-missing", action="store_true")
     ap.add_argument("--precisions", default="0,1")
+    ap.add_argument("--bf16", action="store_true", help="run the step in the plain-bf16 mode (VIDC_TRAIN_PRECISION=bf16) and measure its launches\n"
+                                                        "(K counted in 64-channel units, so they are signatures of their own): fills slots 4, 5 of the entries")
     a = ap.parse_args()
+    if a.bf16:
+        os.environ["VIDC_TRAIN_PRECISION"] = "bf16"
+        a.only_missing = True
     dev = torch.device("cuda")
     torch.set_grad_enabled(False)
     lib = L.lib()
@@ -86,6 +91,8 @@ def main():
     def hook(d0, role):
         sig = engine.conv_signature(d0)
         seen[sig] = seen.get(sig, 0) + 1
+        if d0.precision == 2:
+            return hook_bf16(d0, role, sig)
         if sig in table:
             return
         d = L.ConvDesc.from_buffer_copy(d0)
@@ -132,6 +139,44 @@ def main():
         table[sig] = ent
         print("%-5s %-36s %s" % (role, sig, " | ".join(line)), flush=True)
 
+    def hook_bf16(d0, role, sig):
+        ent = table.get(sig, [0, 0, 0, 0])
+        if len(ent) >= 6 and ent[4]:
+            return
+        d = L.ConvDesc.from_buffer_copy(d0)
+        d.flags &= ~L.ACCUM
+        d.workspace = ws.data_ptr()
+        M, units = d.B * d.Ho * d.Wo, d.KH * d.KW * d.Cin // 32
+        big_w = d.Cout * d.KH * d.KW * d.Cin * 4 > (32 << 20)
+        p = L.ConvDesc.from_buffer_copy(d)
+        p.tile = 0
+        lib.vidc_conv2d_plan(C.byref(p))
+        if role == "conv":
+            p.splitk = 1
+        us_plan = time_launches(lib, p, st, None if big_w else pool, junk, 6 if big_w else 16)
+        cands = []
+        for t, (bm, bn) in TILE_DIMS.items():
+            if bn > max(64, d.Cout) or bm >= 4 * max(32, M):
+                continue
+            wgs = -(-M // bm) * -(-d.Cout // bn)
+            for sk in (1, 2, 4, 8, 16, 32, 64):
+                if sk > 1 and (units // sk < 4 or wgs * (sk // 2) >= 2048):
+                    continue
+                if sk > 1 and L.SPLITK_COUNTERS + sk * M * d.Cout > ws.numel():
+                    continue
+                d.tile, d.splitk = t, sk
+                us = time_launches(lib, d, st, None if big_w else pool, junk, 6 if big_w else 16)
+                if us is not None:
+                    cands.append((us, t, sk))
+        cands.sort()
+        if not cands:
+            raise RuntimeError("no tiling ran for %s: %s" % (sig, lib.vidc_last_error().decode()))
+        us, t, sk = cands[0]
+        table[sig] = (list(ent) + [0, 0, 0, 0])[:4] + [t, sk]
+        table[sig + "#us"] = [us_plan, us]
+        print("%-5s %-36s bf16   plan %-12s sk%-2d %8.1f us -> %-12s sk%-2d %8.1f us" % (role, sig, L.TILE_NAMES[p.tile], p.splitk, us_plan or -1,
+                                                                                     L.TILE_NAMES[t], sk, us), flush=True)
+
     cnn = ModifiedFPN().to(dev)
     cnn.load_state_dict(S.seeded_state_dict(cnn.state_dict(), 1234, device=dev))
     cnn.train()
@@ -148,7 +193,7 @@ def main():
         if u and u[0]:
             total["plan"] += n * u[0]
             total["best"] += n * u[1]
-    print("conv launches per step: %d over %d signatures; fp32 plan %.1f ms -> tuned %.1f ms" % (sum(seen.values()), len(seen), total["plan"] / 1e3, total["best"] / 1e3))
+    print("conv launches per step: %d over %d signatures; plan %.1f ms -> tuned %.1f ms" % (sum(seen.values()), len(seen), total["plan"] / 1e3, total["best"] / 1e3))
     out = {k: v for k, v in sorted(table.items()) if not k.endswith("#us")}
     with open(OUT, "w") as f:
         json.dump(out, f, indent=0)

@@ -63,8 +63,8 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0:
         print(json.dumps({"metric": "training frames/sec", "value": round(world * B * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
-                          "batch_per_gpu": B, "ms_per_step": round(1e3 * dt / args.steps, 1), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 1), "dtype": ("f32 (fp32 MFMA fwd / dgrad / wgrad)" if os.environ.get("VIDC_TRAIN_PRECISION", "fp32") == "fp32" else
-                                    "f32+bf16x3 (split-bf16 3-pass MFMA fwd / dgrad / wgrad)"),
+                          "batch_per_gpu": B, "ms_per_step": round(1e3 * dt / args.steps, 1), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 1), "dtype": {"fp32": "f32 (fp32 MFMA fwd / dgrad / wgrad)", "bf16x3": "f32+bf16x3 (split-bf16 3-pass MFMA fwd / dgrad / wgrad)",
+                                    "bf16": "bf16 operands, fp32 accumulate (MFMA fwd / dgrad / wgrad); fp32 master weights, BatchNorm, loss, Adam"}[os.environ.get("VIDC_TRAIN_PRECISION", "fp32")],
                           "losses": [round(float(x), 5) for x in losses],
                           "config": "BASELINE configs[4]: ModifiedFPN training step (train-mode BN, masked L1 / (H*W), Adam), 320x240, synthetic"}))
     if world > 1:

@@ -26,7 +26,7 @@ TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: 
               9: "32x32k8", 10: "32x64k2d5", 11: "32x32k4d4", 12: "32x128d6", 13: "64x64k2d4", 14: "32x64k2L", 15: "32x64k2d5L", 16: "32x32k4d4L", 17: "64x64L", 18: "64x64k2d4L",
               19: "64x128L", 20: "128x64L", 21: "64x32k2", 22: "64x32k2d5", 23: "64x32k2d5L", 24: "128x128d3", 25: "128x128d3L", 26: "256x128", 27: "128x256"}
 TILE_COUNT = 28
-PREC_FP32, PREC_BF16X3 = 0, 1
+PREC_FP32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 SPLITK_COUNTERS = 16384            # VIDC_SPLITK_COUNTERS: ticket counters at the head of a split-K workspace
 
 _f32p = C.POINTER(C.c_float)
@@ -94,6 +94,7 @@ SIGNATURES = {
     "vidc_masked_l1_loss": (C.c_int, [_vp, _vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp]),
     "vidc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, _f, _f, _f, _f, _i, _vp]),
     "vidc_pack_conv_weight_dgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vidc_cast_bf16": (C.c_int, [_vp, _vp, C.c_longlong, _i, _i, _vp]),
     "vidc_pack_conv_weights_batched": (C.c_int, [_vp, _i, C.c_longlong, _vp]),
     "vidc_zero_stuff": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_conv_wgrad_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i]),

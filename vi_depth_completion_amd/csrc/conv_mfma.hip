@@ -117,6 +117,9 @@ __device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
 // (each 32-channel K unit is stored as [32 x hi | 32 x lo] = the same 128 bytes per row as fp32, so addressing, DMA and
 // swizzle are identical) and every K unit is 3 x 2 v_mfma_f32_32x32x16_bf16: lo*hi + hi*lo + hi*hi, fp32 accumulate.
 // Dropping lo*lo leaves ~2^-16 relative error per product: depth RMSE 1.4e-5 vs fp32 over the whole path (bar: 1e-3).
+// PREC 2 ("bf16", the training mode BASELINE configs[4] names): plain bf16 operands, fp32 accumulate.  A 128-byte unit of a row holds
+// 64 bf16 channels, so the caller describes the tensors in units of two channels (Cin, ldx = bf16 channels / 2, weights packed per 64
+// channels) and everything up to the fragment reads is unchanged; a K unit is 2 x 2 v_mfma_f32_32x32x16_bf16.
 // SPEC 1 ("loader waves"): the workgroup has NW extra waves that do nothing but the LDS-DMA of the NW compute waves (loader l
 // issues exactly what compute wave l would) and the compute waves issue no DMA at all.  A wave can issue one 1 KiB DMA per ~64 clk
 // and stalls in-order behind it, so in the small-tile kernels (6 DMAs per wave per 192 clk of MFMA) the DMA issue used to sit on
@@ -393,7 +396,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
         int fill = slot + NS - 1; if (fill >= NS) fill -= NS;     // the slot read in iteration s-1: free since the barrier
         const unsigned Ab = a_base + (unsigned)(slot * STAGE * 4);
         const unsigned Bb = b_base + (unsigned)(slot * STAGE * 4);
-        if constexpr (PREC == 1) {
+        if constexpr (PREC != 0) {
             // logical 16-byte chunks of a row's unit: 0..3 = hi (k 0-7, 8-15, 16-23, 24-31), 4..7 = lo; MFMA t covers
             // k 16t..16t+15 with lanes 0-31 supplying the first and lanes 32-63 the second 8 k.
             f32x4 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
@@ -427,9 +430,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
 #ifdef VIDC_DBG_SKIP_MFMA
                         acc[i][j][0] += __builtin_bit_cast(f32x4, xl).x + __builtin_bit_cast(f32x4, wh).x + __builtin_bit_cast(f32x4, xh).x + __builtin_bit_cast(f32x4, wl).x;
 #else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[i][j], 0, 0, 0);
+                        if constexpr (PREC == 2) {      // plain bf16: chunks 4..7 are channels 32..63 of the 64-channel unit
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wl, acc[i][j], 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[i][j], 0, 0, 0);
+                        }
 #endif
                     }
                 __builtin_amdgcn_sched_barrier(0);
@@ -896,6 +904,7 @@ int launch_tile_p(const ConvArgs& a, hipStream_t st) {
 template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int SPEC = 0>
 int launch_tile(const ConvArgs& a, hipStream_t st, int precision) {
     return precision == VIDC_PREC_BF16X3 ? launch_tile_p<BM, BN, WMW, WNW, WKW, NS, 1, SPEC>(a, st)
+           : precision == VIDC_PREC_BF16 ? launch_tile_p<BM, BN, WMW, WNW, WKW, NS, 2, SPEC>(a, st)
                                          : launch_tile_p<BM, BN, WMW, WNW, WKW, NS, 0, SPEC>(a, st);
 }
 
@@ -919,7 +928,9 @@ int validate(const vidc_conv_desc* d) {
     VIDC_REQUIRE(!(d->flags & VIDC_AFFINE2) || (d->scale2 && d->shift2), VIDC_ERR_NULL, "conv: AFFINE2 without scale2/shift2");
     VIDC_REQUIRE(!(d->flags & VIDC_RESIDUAL) || (d->residual && d->ldr >= d->Cout), VIDC_ERR_NULL, "conv: RESIDUAL without tensor");
     VIDC_REQUIRE(d->tile >= 0 && d->tile < VIDC_TILE_COUNT, VIDC_ERR_SHAPE, "conv: unknown tile id %d", d->tile);
-    VIDC_REQUIRE(d->precision == VIDC_PREC_FP32 || d->precision == VIDC_PREC_BF16X3, VIDC_ERR_SHAPE, "conv: unknown precision %d", d->precision);
+    VIDC_REQUIRE(d->precision == VIDC_PREC_FP32 || d->precision == VIDC_PREC_BF16X3 || d->precision == VIDC_PREC_BF16, VIDC_ERR_SHAPE,
+                 "conv: unknown precision %d", d->precision);
+    VIDC_REQUIRE(d->precision != VIDC_PREC_BF16 || !(d->flags & VIDC_SPLIT_OUT), VIDC_ERR_SHAPE, "conv: SPLIT_OUT writes the bf16x3 format, not plain bf16");
     VIDC_REQUIRE(d->splitk == 1 || d->workspace, VIDC_ERR_NULL, "conv: split-K needs a workspace");
     VIDC_REQUIRE(!(d->flags & VIDC_SPLIT_OUT) || (d->y_split && d->Cout % 32 == 0 && d->ldy % 32 == 0), VIDC_ERR_NULL,
                  "conv: SPLIT_OUT needs y_split and Cout, ldy multiples of 32");

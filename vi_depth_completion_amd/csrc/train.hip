@@ -398,7 +398,7 @@ pack_weight_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, in
 }
 // Every conv weight of a network re-packed in ONE launch (the parameters move every optimizer step): block -> item by binary search over
 // items[].block_begin (uniform per block: scalar loads), then the per-element maps of pack_weight_kernel / pack_weight_dgrad_kernel,
-// fp32 or split-bf16 ([row][K/32][32 x hi | 32 x lo]).
+// fp32, split-bf16 ([row][K/32][32 x hi | 32 x lo]) or plain bf16 (64 channels per K unit).
 __global__ void __launch_bounds__(TT) pack_batched_kernel(const vidc_pack_item* __restrict__ items, int n) {
     int lo = 0, hi = n - 1;
     const long long blk = blockIdx.x;
@@ -411,13 +411,16 @@ __global__ void __launch_bounds__(TT) pack_batched_kernel(const vidc_pack_item* 
     const long long idx = (blk - it.block_begin) * TT + threadIdx.x;
     if (idx >= total) return;
     const int taps = it.KH * it.KW, dgrad = it.kind & 1;
+    const int U = (it.kind & 4) ? 64 : 32;                // channels per 128-byte K unit: 64 bf16, 32 fp32 / split-bf16
     const int K = (dgrad ? it.Cout : it.Cin) * taps;
     const int row = (int)(idx / K), k = (int)(idx - (long long)row * K);
-    const int lane = k & 31, u = k >> 5;
-    const int cu = u / taps, tap = u - cu * taps, kh = tap / it.KW, kw = tap - kh * it.KW, ch = cu * 32 + lane;
+    const int lane = k % U, u = k / U;
+    const int cu = u / taps, tap = u - cu * taps, kh = tap / it.KW, kw = tap - kh * it.KW, ch = cu * U + lane;
     const float v = dgrad ? it.w[(((long long)ch * it.Cin + row) * it.KH + (it.KH - 1 - kh)) * it.KW + (it.KW - 1 - kw)]
                           : it.w[(((long long)row * it.Cin + ch) * it.KH + kh) * it.KW + kw];
-    if (it.kind & 2) {
+    if (it.kind & 4) {
+        reinterpret_cast<unsigned short*>(it.packed)[idx] = vidc::bf16_rne(v);
+    } else if (it.kind & 2) {
         unsigned short h, l;
         vidc::split_bf16(v, h, l);
         unsigned short* base = reinterpret_cast<unsigned short*>(it.packed) + ((long long)row * (K / 32) + u) * 64 + lane;
@@ -426,6 +429,19 @@ __global__ void __launch_bounds__(TT) pack_batched_kernel(const vidc_pack_item* 
     } else {
         it.packed[idx] = v;
     }
+}
+
+// fp32 NHWC rows [rows][ldx] (C channels used) -> dense bf16 rows [rows][C] (round to nearest even); one thread per 8 channels
+__global__ void __launch_bounds__(TT) cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long long rows, int C, int ldx) {
+    const int c8 = C / 8;
+    const long long idx = (long long)blockIdx.x * TT + threadIdx.x;
+    if (idx >= rows * c8) return;
+    const long long r = idx / c8;
+    const int c = (int)(idx - r * c8) * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(x + r * ldx + c), v1 = *reinterpret_cast<const float4*>(x + r * ldx + c + 4);
+    const unsigned a = vidc::bf16_rne(v0.x) | ((unsigned)vidc::bf16_rne(v0.y) << 16), b = vidc::bf16_rne(v0.z) | ((unsigned)vidc::bf16_rne(v0.w) << 16);
+    const unsigned d = vidc::bf16_rne(v1.x) | ((unsigned)vidc::bf16_rne(v1.y) << 16), e = vidc::bf16_rne(v1.z) | ((unsigned)vidc::bf16_rne(v1.w) << 16);
+    *reinterpret_cast<uint4*>(y + r * C + c) = make_uint4(a, b, d, e);
 }
 
 // z[b, oy*s, ox*s, :] = dy[b, oy, ox, :], zero elsewhere (z is B x H x W x C, dense)
@@ -567,7 +583,9 @@ im2col_t_kernel(const float* __restrict__ x, float* __restrict__ xt, int B, int 
         const int c = c0 + ty + 8 * r, m = m0 + tx;
         if (c < C && m < Mp) {
             const float v = tile[tx][ty + 8 * r];
-            if (split) {         // the 32 pixels of this tile are one K unit of the GEMM: [32 x hi | 32 x lo] in the same 128 bytes
+            if (split == 2) {    // plain bf16 rows
+                reinterpret_cast<unsigned short*>(xt)[((size_t)tap * C + c) * Mp + m] = vidc::bf16_rne(v);
+            } else if (split) {  // the 32 pixels of this tile are one K unit of the GEMM: [32 x hi | 32 x lo] in the same 128 bytes
                 unsigned short h, l;
                 vidc::split_bf16(v, h, l);
                 unsigned short* u = reinterpret_cast<unsigned short*>(xt + ((size_t)tap * C + c) * Mp + m0);
@@ -608,7 +626,11 @@ im2col_t64_kernel(const float* __restrict__ x, float* __restrict__ xt, int B, in
         if (c < C && m < Mp) {
             const float v[4] = {tile[tx * 4][cl], tile[tx * 4 + 1][cl], tile[tx * 4 + 2][cl], tile[tx * 4 + 3][cl]};
             float* row = xt + ((size_t)tap * C + c) * Mp;
-            if (split) {         // 4 pixels of one 32-pixel K unit: their hi halves and their lo halves, 8 bytes each
+            if (split == 2) {    // plain bf16 rows: 4 pixels = 8 bytes
+                unsigned short* u = reinterpret_cast<unsigned short*>(xt) + ((size_t)tap * C + c) * Mp + m;
+                *reinterpret_cast<uint2*>(u) = make_uint2((unsigned)vidc::bf16_rne(v[0]) | ((unsigned)vidc::bf16_rne(v[1]) << 16),
+                                                          (unsigned)vidc::bf16_rne(v[2]) | ((unsigned)vidc::bf16_rne(v[3]) << 16));
+            } else if (split) {  // 4 pixels of one 32-pixel K unit: their hi halves and their lo halves, 8 bytes each
                 unsigned short h[4], l[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) vidc::split_bf16(v[k], h[k], l[k]);
@@ -828,6 +850,14 @@ extern "C" int vidc_pack_conv_weights_batched(const vidc_pack_item* items_device
     return VIDC_OK;
 }
 
+extern "C" int vidc_cast_bf16(const float* x, void* y, long long rows, int C, int ldx, vidc_stream_t stream) {
+    VIDC_REQUIRE(x && y, VIDC_ERR_NULL, "vidc_cast_bf16: null pointer");
+    VIDC_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && ldx >= C && ldx % 4 == 0, VIDC_ERR_SHAPE, "vidc_cast_bf16: C must be a multiple of 8");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks(rows * (C / 8))), dim3(TT), 0, vidc::as_stream(stream), x, reinterpret_cast<unsigned short*>(y), rows, C, ldx);
+    VIDC_CHECK_LAUNCH("cast_bf16_kernel");
+    return VIDC_OK;
+}
+
 extern "C" int vidc_zero_stuff(const float* dy, float* z, int B, int Ho, int Wo, int C, int lddy, int stride, int H, int W, vidc_stream_t stream) {
     VIDC_REQUIRE(dy && z, VIDC_ERR_NULL, "vidc_zero_stuff: null pointer");
     VIDC_REQUIRE(B > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && stride >= 1 && (Ho - 1) * stride < H && (Wo - 1) * stride < W,
@@ -885,7 +915,8 @@ extern "C" int vidc_im2col_transposed(const float* x, float* xt, int B, int H, i
     VIDC_REQUIRE(x && xt, VIDC_ERR_NULL, "vidc_im2col_transposed: null pointer");
     const long long M = (long long)B * Ho * Wo;
     VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0 && Mp >= M && Mp % 32 == 0 && M < (1ll << 31) &&
-                     (long long)KH * KW <= 65535, VIDC_ERR_SHAPE, "vidc_im2col_transposed: bad shape (Mp = M rounded up to a multiple of 32)");
+                     (long long)KH * KW <= 65535 && split >= 0 && split <= 2 && (split != 2 || Mp % 64 == 0), VIDC_ERR_SHAPE,
+                 "vidc_im2col_transposed: bad shape (Mp = M rounded up to a multiple of 32; 64 for plain bf16 rows)");
     const bool wide = C % 4 == 0 && ldx % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xt)) & 15) == 0;
     if (wide)
         hipLaunchKernelGGL(im2col_t64_kernel, dim3((Mp + 63) / 64, (C + 63) / 64, KH * KW), dim3(256), 0, vidc::as_stream(stream), x, xt, B, H, W, C, ldx, Ho, Wo,

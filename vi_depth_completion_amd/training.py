@@ -123,7 +123,7 @@ class DepthCompletionTrainer:
         self.use_graph = os.environ.get("VIDC_TRAIN_GRAPH", "1") != "0"
         self._graphs, self._graph_seen = {}, {}
         self.tune_hook = None      # tools/autotune_train.py: called with every conv descriptor before it is planned
-        self.precision = L.PREC_BF16X3 if os.environ.get("VIDC_TRAIN_PRECISION", "fp32") == "bf16x3" else L.PREC_FP32
+        self.precision = {"fp32": L.PREC_FP32, "bf16x3": L.PREC_BF16X3, "bf16": L.PREC_BF16}[os.environ.get("VIDC_TRAIN_PRECISION", "fp32")]
         self.last_loss = None
 
     # ---- small helpers ------------------------------------------------------------------------------------------------------
@@ -154,6 +154,13 @@ class DepthCompletionTrainer:
             xs = self._empty(B, H, W, cin)
             L.check(L.lib().vidc_split_bf16x3(L.ptr(x_t), L.ptr(xs), B * H * W, cin, ldx, L.current_stream()), "split")
             x_t, ldx = xs, cin
+        elif self.precision == L.PREC_BF16:      # plain bf16 rows; the descriptor counts two channels per element (include/vidc.h)
+            if cin % 64:
+                raise RuntimeError("bf16 training needs conv input channels in multiples of 64 (got %d)" % cin)
+            xs = self._empty(B, H, W, cin // 2)
+            L.check(L.lib().vidc_cast_bf16(L.ptr(x_t), L.ptr(xs), B * H * W, cin, ldx, L.current_stream()), "cast")
+            x_t, cin = xs, cin // 2
+            ldx = cin
         d = L.ConvDesc()
         d.x, d.w, d.y = L.ptr(x_t), L.ptr(w_packed), L.ptr(y_t)
         d.scale1, d.shift1 = L.ptr(self._const(self._ones, cout, 1.0)), L.ptr(shift)
@@ -174,7 +181,7 @@ class DepthCompletionTrainer:
         if self.tune_hook is not None:
             self.tune_hook(d, role)
         ent = training_table().get(engine.conv_signature(d))
-        if ent is not None:
+        if ent is not None and len(ent) > 2 * d.precision + 1 and ent[2 * d.precision]:
             d.tile, d.splitk = ent[2 * d.precision], ent[2 * d.precision + 1]
         else:
             L.check(lib.vidc_conv2d_plan(C.byref(d)), "conv plan")
@@ -195,8 +202,8 @@ class DepthCompletionTrainer:
             return ent
         co, ci, kh, kw = w.shape
         if ent is None:
-            ent = self._packed[(key, kind)] = self._empty(co * ci * kh * kw)
-            self._pack_items.append((w, ent, co, ci, kh, kw, (1 if kind == "d" else 0) | (2 if self.precision == L.PREC_BF16X3 else 0)))
+            ent = self._packed[(key, kind)] = self._empty(co * ci * kh * kw // (2 if self.precision == L.PREC_BF16 else 1))
+            self._pack_items.append((w, ent, co, ci, kh, kw, (1 if kind == "d" else 0) | {L.PREC_FP32: 0, L.PREC_BF16X3: 2, L.PREC_BF16: 4}[self.precision]))
             self._pack_table = None
         self._launch_pack([it for it in self._pack_items if it[1] is ent])
         return ent
@@ -232,13 +239,16 @@ class DepthCompletionTrainer:
             return False
         lib, st = L.lib(), L.current_stream()
         taps, M = kh * kw, B * Ho * Wo
-        Mp = (M + 31) // 32 * 32
-        if taps * ci * Mp * 4 >= (1 << 31) or co * Mp >= (1 << 29) or ci % 32 or co % 4:
+        bf16 = self.precision == L.PREC_BF16
+        Mp = (M + 63) // 64 * 64 if bf16 else (M + 31) // 32 * 32
+        e = 2 if bf16 else 1                     # pixels per 4-byte element of an operand row
+        if taps * ci * Mp * 4 // e >= (1 << 31) or co * Mp // e >= (1 << 29) or ci % 32 or co % 4:
             return False
-        gt, xt, tmp = self._empty(co, Mp), self._empty(taps * ci, Mp), self._empty(co, taps * ci)
-        split = 1 if self.precision == L.PREC_BF16X3 else 0          # operands written in the split-bf16 format directly
+        gt, xt, tmp = self._empty(co, Mp // e), self._empty(taps * ci, Mp // e), self._empty(co, taps * ci)
+        split = {L.PREC_FP32: 0, L.PREC_BF16X3: 1, L.PREC_BF16: 2}[self.precision]      # operands written in the GEMM's format directly
         L.check(lib.vidc_im2col_transposed(L.ptr(g), L.ptr(gt), B, Ho, Wo, co, _ld(g), Ho, Wo, 1, 1, 1, 0, Mp, split, st), "transpose dY")
         L.check(lib.vidc_im2col_transposed(L.ptr(x.t), L.ptr(xt), B, H, W, ci, x.ld, Ho, Wo, kh, kw, stride, pad, Mp, split, st), "im2col^T")
+        Mp //= e
         n_out = taps * ci
         d = L.ConvDesc()
         d.x, d.w, d.y = L.ptr(gt), L.ptr(xt), L.ptr(tmp)
