@@ -448,6 +448,48 @@ def test_training_iteration_vs_reference(golden_dir, seeded_weights, monkeypatch
 
 
 @gpu
+def test_plain_bf16_training_mode(golden_dir, seeded_weights, monkeypatch):
+    """VIDC_TRAIN_PRECISION=bf16 -- what BASELINE configs[4] names ("bf16 ... MFMA fwd+bwd convs"; SURVEY §8 f3: "bf16 with fp32
+    master"): conv operands rounded to bf16 (8-bit mantissa), fp32 accumulation, everything else fp32.  The reference has no such mode,
+    so the bars are those of mixed-precision training against its fp32 iteration on the fixture batch, stated here: loss within 5e-3
+    relative (observed 8e-4), global gradient norm within 2e-2 (observed 3e-4), the flat gradient's cosine with the fp32 mode's above
+    0.99 (observed 0.998; per-block relative L2 up to 0.4 in the pyramids: bf16 noise flips ReLU gates under 335 train-mode
+    BatchNorms -- tools/train_bf16_check.py prints the table), head gradients within 2e-2 of scale, and six steps on the batch bring
+    the loss down like the fp32 mode's."""
+    from _probe import check_probe
+    from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
+    from vi_depth_completion_amd.training import DepthCompletionTrainer
+    f, image, normal, depth_in, gt = _train_fixture(golden_dir)
+    ins = [t.to(DEV) for t in (image, normal, depth_in, gt)]
+    grads, losses = {}, {}
+    for mode in ("fp32", "bf16"):
+        monkeypatch.setenv("VIDC_TRAIN_PRECISION", mode)
+        cnn = ModifiedFPN().to(DEV)
+        st = cnn.state_dict()
+        st.update({k: v.to(DEV) for k, v in seeded_weights["dc"].items()})
+        cnn.load_state_dict(st)
+        cnn.train()
+        tr = DepthCompletionTrainer(cnn, float(f["lr"]))
+        loss, pred = tr.forward_backward(*ins)
+        grads[mode] = tr.flat_g.double().clone()
+        if mode == "bf16":
+            assert abs(float(loss) - float(f["loss"])) < 5e-3 * float(f["loss"]), (float(loss), float(f["loss"]))
+            gn = float(grads[mode].norm())
+            assert abs(gn - float(f["grad_global_norm"])) < 2e-2 * gn
+            for k in ("feature_concat.0.weight", "feature_concat.2.weight"):
+                check_probe(f, "grad", k, tr.grad[k].cpu(), 2e-2, 1e-7)
+        tr.optimizer_step()
+        losses[mode] = [float(loss)] + [float(tr.step(*ins)) for _ in range(5)]
+        del tr, cnn
+        torch.cuda.empty_cache()
+    cos = float((grads["fp32"] * grads["bf16"]).sum() / (grads["fp32"].norm() * grads["bf16"].norm()))
+    print("bf16 vs fp32: gradient cosine %.5f; losses fp32 %s bf16 %s" % (cos, losses["fp32"], losses["bf16"]))
+    assert cos > 0.99
+    assert losses["bf16"][-1] < 0.9 * losses["bf16"][0]
+    assert abs(losses["bf16"][-1] - losses["fp32"][-1]) < 0.05 * losses["fp32"][-1]
+
+
+@gpu
 def test_training_loop_on_pipeline_inputs(seeded_weights):
     """The binding INTEGRATION.md shows: the pipeline produces what `_call_cnn` feeds the depth network (image, predicted normals,
     enriched depth), the trainer runs `_run_training_iteration` on it; four iterations on one batch bring the loss down, the parameters
