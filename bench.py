@@ -53,6 +53,8 @@ def parse():
                          "+ depth-completion net of frame t-1 as one 4-group program); streams: --in-flight frames on separate HIP "
                          "streams; sequential: back-to-back _call_cnn")
     ap.add_argument("--in-flight", type=int, default=2, help="frames executing concurrently in --mode streams")
+    ap.add_argument("--lanes", type=int, default=2, help="--mode interleaved: software-pipelined frame streams on this many HIP streams, frame i on lane "
+                                                          "i mod L (pipeline.run_interleaved(lanes=L)); results are bit-identical for every L")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the second leg (the same steps with every conv in exact fp32 MFMA arithmetic)")
     return ap.parse_args()
 
@@ -168,7 +170,7 @@ def measure(args, dev, rank, world, precision):
             for out in pipe.run_stream(frames(n), in_flight=args.in_flight):
                 pass
         else:       # n frames = n + 1 pipeline ticks, all inside the timed region; outputs stay in the program's buffer (valid until the
-            for out in pipe.run_interleaved(frames(n), copy_outputs=False):      # next item is requested: documented lifetime)
+            for out in pipe.run_interleaved(frames(n), copy_outputs=False, lanes=args.lanes):      # next item is requested: documented lifetime)
                 pass
         return out
 
@@ -340,7 +342,7 @@ def main():
                                     "pre-processing (PIL-exact resize to %dx%d, rasterisation) + warp + surface-normal net + plane "
                                     "block/enrichment + depth-completion net" % (args.source, B, "from the Mask R-CNN plane head every frame" if args.plane_head else "fixed", W, H))),
                        "height": H, "width": W, "batch_per_gpu": B, "weights": "seeded random-init (seed 1234)",
-                       "mode": args.mode, "frames_in_flight": (2 if args.mode == "interleaved" else args.in_flight if args.mode == "streams" else 1),
+                       "mode": args.mode, "lanes": (args.lanes if args.mode == "interleaved" else 1), "frames_in_flight": (2 * args.lanes if args.mode == "interleaved" else args.in_flight if args.mode == "streams" else 1),
                        "sharding": "frames round-robin over %d rank(s), no data-path collective" % world},
             "rmse_vs_oracle": (round(job["rmse"], 8) if job["rmse"] is not None else None),
             "roofline": lead["roofline"], "cpu_baseline": cpu_baseline,

@@ -157,6 +157,16 @@ def default_precision(flops):
     return L.PREC_BF16X3 if flops >= 1.5e9 else L.PREC_FP32
 
 
+# LDS bytes of the tilings (NS * (BM + BN) * 32 floats * WKW) and, for the co-residency experiment, the nearest tiling of at most 80 KB
+_TILE_LDS_KB = {1: 64, 2: 72, 3: 72, 4: 64, 5: 96, 6: 72, 7: 96, 8: 80, 9: 128, 10: 120, 11: 128, 12: 120, 13: 128, 14: 72, 15: 120, 16: 128, 17: 64,
+                18: 128, 19: 72, 20: 72, 21: 72, 22: 120, 23: 120, 24: 96, 25: 96, 26: 144, 27: 144}
+_TILE_SMALL = {5: 4, 13: 4, 18: 4, 7: 6, 9: 6, 10: 6, 11: 6, 15: 6, 16: 6, 12: 8, 22: 21, 23: 21, 24: 1, 25: 1, 26: 1, 27: 1}
+
+
+def _capped_tile(tile, cap_kb):
+    return _TILE_SMALL.get(tile, tile) if _TILE_LDS_KB.get(tile, 0) > cap_kb else tile
+
+
 def conv_signature(d):
     return "M%d_N%d_K%d_k%ds%d_G%d" % (d.B * d.Ho * d.Wo, d.Cout, d.KH * d.KW * d.Cin, d.KH, d.stride, d.groups)
 
@@ -505,6 +515,8 @@ class Program:
                 d.tile, d.splitk = ent[3], ent[4]
             else:
                 L.check(lib.vidc_conv2d_plan(C.byref(d)), "conv plan")
+        if os.environ.get("VIDC_LDS_CAP_KB"):          # experiment knob (tools/dual_stream_bench.py): tilings that leave room for a second
+            d.tile = _capped_tile(d.tile, int(os.environ["VIDC_LDS_CAP_KB"]))      # workgroup of another stream on the CU
         self._keep += [wp, s1, b1]
         return "conv:%s:%s:sk%d:%s %s" % (keys[0], L.TILE_NAMES[d.tile], d.splitk, "bf16x3" if prec else "fp32", sig)
 

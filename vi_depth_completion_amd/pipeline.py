@@ -203,81 +203,176 @@ class DepthCompletionPipeline:
         return self._frame_prog
 
     @torch.no_grad()
-    def run_interleaved(self, batches, copy_outputs=True):
+    def run_interleaved(self, batches, copy_outputs=True, lanes=None):
         """Throughput mode, software-pipelined over frames: tick t runs the surface-normal network + plane block of frame
         t and the depth-completion network of frame t-1 as ONE program (build_frame_program).  Yields the depth map of
         every batch, in order; n batches take n+1 ticks.  Per frame the arithmetic is that of `_call_cnn` (same kernels;
         the 4-group launches may use another tile than the 1-/3-group ones, i.e. fp32 sums in a different order), and the
         RANSAC / enrichment draws come off `self.rng` in the same order as back-to-back `_call_cnn` calls.
 
+        lanes = L > 1 (default: VIDC_LANES, else 1) runs L such pipelines on L HIP streams, frame i on lane i mod L, each with its
+        own program buffers and plane-block scratch: at batch 1 two thirds of a small-layer launch is fixed cost (dispatch, first
+        weight stage from HBM, split-K epilogue, drain) during which most CUs idle, and the launches of another lane fill those
+        holes (+9 % frames/s with two lanes at 320x256, batch 1; more lanes add nothing: workgroups reserve 64-128 KB of LDS, so a
+        CU rarely holds two).  Ticks are issued strictly in frame order from this one host thread, so the random draws come off
+        `self.rng` exactly as with one lane and every frame's result is bit-identical to the single-lane stream's (tested).
+        Outputs are still yielded in frame order, a lane's one round (L requests) later than with one lane; the caller's current
+        stream waits (on the device) for the tick that produced one.
+
         Data movement per tick: the frame is copied into the program's input buffer once (and from there to the depth
         network's image input one tick later, device to device); the normals and the enriched sparse depth are WRITTEN where the
         next tick reads them (no copies).  The caller's tensors are not referenced after the call that consumed them.
-        copy_outputs=False hands out the program's own output buffer: valid until the next item is requested."""
-        import itertools
+        copy_outputs=False hands out the program's own output buffer: valid until the next item is requested (with L lanes: until
+        L more items have been requested)."""
         import os
         if not self.use_gravity:
             raise NotImplementedError("run_interleaved pipelines the gravity-aligned surface-normal network; use _call_cnn with use_gravity=False")
-        dev = self.device
-        prog = None
-        have_prev = False      # a frame is waiting for its depth network (its inputs sit in the program's buffers)
-        for batch in itertools.chain(batches, [None]):
-            if batch is not None:
-                rgb = batch["image"].to(dev, non_blocking=True)
-                ds = batch["sparse_depth"].to(dev, non_blocking=True)
-                B, _, H, W = rgb.shape
-                if prog is not None and (B, H, W) != shape0:
-                    raise ValueError("run_interleaved: all batches of a stream must have the same shape (got %s after %s); "
-                                     "start a new stream for the remainder" % ((B, H, W), shape0))
-                if prog is None:
-                    shape0 = (B, H, W)
-                    prog = self.frame_program(B, H, W)
-                    self.surface_normal_cnn._check(rgb)
-                    self.cnn._check(rgb)
-                    if not prog.captured and os.environ.get("VIDC_EXEC", "graph") == "graph":
-                        side = torch.cuda.Stream()
-                        side.wait_stream(torch.cuda.current_stream())
-                        with torch.cuda.stream(side):
-                            prog.run()            # warm-up outside capture (sets kernel attributes)
-                            prog.check_chains()
-                            prog.capture_segments()
-                        torch.cuda.current_stream().wait_stream(side)
-                    sn_image, dc_image = prog.tensor(prog.inputs["sn_image"]), prog.tensor(prog.inputs["dc_image"])
-                    dc_depth = prog.tensor(prog.inputs["dc_depth"])
-                    grav = prog.storage[prog.inputs["gravity"].buf][: B * 3]
-                    algn = prog.storage[prog.inputs["aligned"].buf][: B * 3]
-            elif prog is None:
-                return
-            graph = prog.captured
-            if have_prev:             # frame t-1's image is still in the surface-normal input buffer; its normals and its enriched
-                dc_image.copy_(sn_image, non_blocking=True)       # depth were written in place by the previous tick
-            pending = None
-            if batch is not None:
-                mh = self._masks_begin(rgb) if self.args.enriched_samples != 0 else None    # ids reach the host while segment 0 runs
-                sn_image.copy_(rgb, non_blocking=True)
-                grav.copy_(batch["gravity"].to(dev).reshape(-1), non_blocking=True)
-                algn.copy_(batch["aligned_direction"].to(dev).reshape(-1), non_blocking=True)
-                prog.launch_segment(0) if graph else prog.run_segment(0)
-                normals = prog.tensor(prog.outputs["normals"])
-                if self.args.enriched_samples != 0:
-                    homo = batch["homogeneous_coordinates"].to(dev, non_blocking=True)
-                    masks = self._masks_end(mh, batch["image"], H, W)
-                    di, info = self.planes.plane_depth(normals, masks, ds, homo, rng=self.rng)
-                    pending = (di, info, self.planes.read_info_async(info))
-                else:
-                    dc_depth.copy_(ds, non_blocking=True)     # (segment 0 above has read the previous frame's depth input)
-            elif have_prev:
-                # drain tick: no new frame; the pyramids still run 4 groups (group 0 recomputes the last frame's features)
-                prog.launch_segment(0) if graph else prog.run_segment(0)
-            if have_prev:
-                prog.launch_segment(1) if graph else prog.run_segment(1)
-            if pending is not None:
-                di, info, info_host = pending       # the host waits for the counts while segment 1 keeps the GPU busy;
-                self.planes.enrich(ds, di, info, self.args.enriched_samples, rng=self.rng, info_host=info_host, out=dc_depth)   # written in place
-            if have_prev:
-                out = prog.tensor(prog.outputs["depth"])
-                yield out.clone() if copy_outputs else out
-            have_prev = batch is not None
+        n = int(lanes if lanes is not None else os.environ.get("VIDC_LANES", "1"))
+        if n < 1:
+            raise ValueError("run_interleaved: lanes must be >= 1")
+        lane_objs = [_Lane(self, k, own_stream=n > 1) for k in range(n)]
+        k = 0
+        if n == 1:                              # on the caller's stream; an output is handed out by the tick that computed it
+            for batch in batches:
+                out = lane_objs[0]._tick(batch, copy_outputs)
+                if out is not None:
+                    yield out
+            out = lane_objs[0]._tick(None, copy_outputs)
+            if out is not None:
+                yield out
+            return
+        # L lanes: a lane's output is handed out at the START of its next visit (the caller's stream then waits for a tick that was
+        # issued a whole round ago and has mostly run), never right after its own tick -- a wait for the tick just issued, sitting on
+        # the caller's stream, would make the next lane (which must wait for the caller's stream: its inputs come from there) wait for
+        # it too and serialise the lanes.
+        for batch in batches:
+            lane = lane_objs[k % n]
+            k += 1
+            out = lane.collect()
+            if out is not None:
+                yield out
+            lane.launch(batch, copy_outputs)
+        for j in range(n):                      # drain ticks, oldest pending frame first
+            lane = lane_objs[(k + j) % n]
+            out = lane.collect()
+            if out is not None:
+                yield out
+            lane.launch(None, copy_outputs)
+        for j in range(n):
+            out = lane_objs[(k + j) % n].collect()
+            if out is not None:
+                yield out
+
+
+class _Lane:
+    """One software-pipelined frame stream of `DepthCompletionPipeline.run_interleaved`: its frame program (cached on the pipeline per
+    lane index), its plane-block scratch, optionally its own HIP stream, and the one frame whose depth network is still pending."""
+
+    def __init__(self, pipe, index, own_stream):
+        self.pipe, self.index = pipe, index
+        self.prog, self.shape0, self.have_prev, self.pending_out = None, None, False, None
+        cache = pipe.__dict__.setdefault("_lane_cache", {})
+        ent = cache.setdefault(index, {})
+        self.cache = ent
+        if "planes" not in ent:
+            ent["planes"] = pipe.planes if index == 0 else PlaneBlock()
+        if own_stream and "stream" not in ent:
+            ent["stream"] = torch.cuda.Stream(device=pipe.device)
+        self.planes = ent["planes"]
+        self.stream = ent.get("stream") if own_stream else None
+
+    def _program(self, B, H, W):
+        p = self.pipe
+        if self.index == 0:
+            return p.frame_program(B, H, W)
+        key = (B, H, W, p.surface_normal_cnn._version, p.cnn._version, p.surface_normal_cnn.warp_2dof_alignment.align_corners)
+        if self.cache.get("prog_key") != key:
+            self.cache["prog"] = build_frame_program(p.surface_normal_cnn, p.cnn, B, H, W, p.device)
+            self.cache["prog_key"] = key
+        return self.cache["prog"]
+
+    def launch(self, batch, copy_outputs):
+        """(lanes > 1) one tick on this lane's stream; the output it computes, if any, is kept for `collect`."""
+        self.stream.wait_stream(torch.cuda.current_stream())      # the batch comes from the caller's stream, and whoever read the
+        with torch.cuda.stream(self.stream):                      # previous output out of the program's buffer did so there
+            out = self._tick(batch, copy_outputs)
+            if out is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                self.pending_out = (out, ev)
+
+    def collect(self):
+        if self.pending_out is None:
+            return None
+        out, ev = self.pending_out
+        self.pending_out = None
+        torch.cuda.current_stream().wait_event(ev)                # device-side: readers on the caller's stream find `out` complete
+        return out
+
+    def _tick(self, batch, copy_outputs):
+        import os
+        pipe = self.pipe
+        dev = pipe.device
+        if batch is not None:
+            rgb = batch["image"].to(dev, non_blocking=True)
+            ds = batch["sparse_depth"].to(dev, non_blocking=True)
+            B, _, H, W = rgb.shape
+            if self.prog is not None and (B, H, W) != self.shape0:
+                raise ValueError("run_interleaved: all batches of a stream must have the same shape (got %s after %s); "
+                                 "start a new stream for the remainder" % ((B, H, W), self.shape0))
+            if self.prog is None:
+                self.shape0 = (B, H, W)
+                prog = self.prog = self._program(B, H, W)
+                pipe.surface_normal_cnn._check(rgb)
+                pipe.cnn._check(rgb)
+                if not prog.captured and os.environ.get("VIDC_EXEC", "graph") == "graph":
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        prog.run()            # warm-up outside capture (sets kernel attributes)
+                        prog.check_chains()
+                        prog.capture_segments()
+                    torch.cuda.current_stream().wait_stream(side)
+                self.sn_image, self.dc_image = prog.tensor(prog.inputs["sn_image"]), prog.tensor(prog.inputs["dc_image"])
+                self.dc_depth = prog.tensor(prog.inputs["dc_depth"])
+                self.grav = prog.storage[prog.inputs["gravity"].buf][: B * 3]
+                self.algn = prog.storage[prog.inputs["aligned"].buf][: B * 3]
+        elif self.prog is None or not self.have_prev:
+            return None
+        prog = self.prog
+        graph = prog.captured
+        have_prev = self.have_prev
+        if have_prev:             # frame t-1's image is still in the surface-normal input buffer; its normals and its enriched
+            self.dc_image.copy_(self.sn_image, non_blocking=True)       # depth were written in place by the previous tick
+        pending = None
+        if batch is not None:
+            mh = pipe._masks_begin(rgb) if pipe.args.enriched_samples != 0 else None    # ids reach the host while segment 0 runs
+            self.sn_image.copy_(rgb, non_blocking=True)
+            self.grav.copy_(batch["gravity"].to(dev).reshape(-1), non_blocking=True)
+            self.algn.copy_(batch["aligned_direction"].to(dev).reshape(-1), non_blocking=True)
+            prog.launch_segment(0) if graph else prog.run_segment(0)
+            normals = prog.tensor(prog.outputs["normals"])
+            if pipe.args.enriched_samples != 0:
+                homo = batch["homogeneous_coordinates"].to(dev, non_blocking=True)
+                masks = pipe._masks_end(mh, batch["image"], H, W)
+                di, info = self.planes.plane_depth(normals, masks, ds, homo, rng=pipe.rng)
+                pending = (di, info, self.planes.read_info_async(info))
+            else:
+                self.dc_depth.copy_(ds, non_blocking=True)     # (segment 0 above has read the previous frame's depth input)
+        elif have_prev:
+            # drain tick: no new frame; the pyramids still run 4 groups (group 0 recomputes the last frame's features)
+            prog.launch_segment(0) if graph else prog.run_segment(0)
+        if have_prev:
+            prog.launch_segment(1) if graph else prog.run_segment(1)
+        if pending is not None:
+            di, info, info_host = pending       # the host waits for the counts while segment 1 keeps the GPU busy;
+            self.planes.enrich(ds, di, info, pipe.args.enriched_samples, rng=pipe.rng, info_host=info_host, out=self.dc_depth)   # written in place
+        out = None
+        if have_prev:
+            out = prog.tensor(prog.outputs["depth"])
+            out = out.clone() if copy_outputs else out
+        self.have_prev = batch is not None
+        return out
 
     @torch.no_grad()
     def run_stream(self, batches, in_flight=2, frame_rng=None):
