@@ -438,8 +438,9 @@ int vidc_adam_step(float* p, const float* g, float* m, float* v, long long n, fl
  * ([Cin][Cout/32][KH][KW][32], kernel flipped); a stride-s conv first spreads dY over the input grid with vidc_zero_stuff. */
 int vidc_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, vidc_stream_t stream);
 /* All conv weights of a network re-packed by one launch (they move every optimizer step).  `items_device`: n_items descriptors in
- * device memory, sorted by block_begin; item i owns blocks [block_begin_i, block_begin_{i+1}) of 256 elements each, ceil(Cout*Cin*KH*KW
- * / 256) of them; total_blocks = their sum.  kind: 0 forward fp32 (vidc_pack_conv_weight), 1 dgrad fp32 (vidc_pack_conv_weight_dgrad),
+ * device memory, sorted by block_begin; item i owns the vidc_pack_item_blocks(...) workgroups from block_begin_i on (0 = unsupported
+ * shape: kernels up to 3x3, the K-side channel count a multiple of the unit); total_blocks = their sum.  kind: 0 forward fp32
+ * (vidc_pack_conv_weight), 1 dgrad fp32 (vidc_pack_conv_weight_dgrad),
  * 2 / 3 the same two in split-bf16 (vidc_pack_conv_weight_bf16x3; dgrad rows split like vidc_split_bf16x3), 4 / 5 in plain bf16 for
  * VIDC_PREC_BF16 ([row][channels/64][KH][KW][64 x bf16]; the K-side channel count a multiple of 64). */
 typedef struct vidc_pack_item {
@@ -449,6 +450,7 @@ typedef struct vidc_pack_item {
     int32_t kind, reserved;
     int64_t block_begin;
 } vidc_pack_item;
+long long vidc_pack_item_blocks(int Cout, int Cin, int KH, int KW, int kind);
 int vidc_pack_conv_weights_batched(const vidc_pack_item* items_device, int n_items, long long total_blocks, vidc_stream_t stream);
 int vidc_zero_stuff(const float* dy, float* z, int B, int Ho, int Wo, int C, int lddy, int stride, int H, int W, vidc_stream_t stream);
 /* wgrad: dw_oihw[co][ci][kh][kw] = sum over output pixels of dy[m][co] * x[pixel(m) at the tap][ci], on v_mfma_f32_32x32x2_f32 with the

@@ -297,7 +297,7 @@ def test_plain_bf16_conv_mode(cin, cout, k, stride, pad, H, W, tile):
     item = (L.PackItem * 1)()
     item[0].w, item[0].packed, item[0].Cout, item[0].Cin, item[0].KH, item[0].KW, item[0].kind, item[0].block_begin = L.ptr(wd), L.ptr(wp), cout, cin, k, k, 4, 0
     dev = torch.frombuffer(bytearray(bytes(item)), dtype=torch.uint8).to(DEV)
-    L.check(lib.vidc_pack_conv_weights_batched(L.ptr(dev), 1, (w.numel() + 255) // 256, st), "pack")
+    L.check(lib.vidc_pack_conv_weights_batched(L.ptr(dev), 1, lib.vidc_pack_item_blocks(cout, cin, k, k, 4), st), "pack")
     y = torch.empty(B, Ho, Wo, cout, device=DEV)
     ones, zeros = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
     d = L.ConvDesc()
@@ -320,7 +320,7 @@ def test_plain_bf16_conv_mode(cin, cout, k, stride, pad, H, W, tile):
         wq = torch.empty(w.numel() // 2, device=DEV)
         item[0].packed = L.ptr(wq)
         dev = torch.frombuffer(bytearray(bytes(item)), dtype=torch.uint8).to(DEV)
-        L.check(lib.vidc_pack_conv_weights_batched(L.ptr(dev), 1, (w.numel() + 255) // 256, st), "pack dgrad")
+        L.check(lib.vidc_pack_conv_weights_batched(L.ptr(dev), 1, lib.vidc_pack_item_blocks(cout, cin, k, k, 5), st), "pack dgrad")
         gd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
         gb = torch.empty(B, Ho, Wo, cout // 2, device=DEV)
         L.check(lib.vidc_cast_bf16(L.ptr(gd), L.ptr(gb), B * Ho * Wo, cout, cout, st), "cast")
@@ -367,7 +367,7 @@ def test_batched_weight_packing_equals_the_per_layer_packs():
     blocks = 0
     for t, (w, out, co, ci, kh, kw, kind) in zip(table, items):
         t.w, t.packed, t.Cout, t.Cin, t.KH, t.KW, t.kind, t.block_begin = L.ptr(w), L.ptr(out), co, ci, kh, kw, kind, blocks
-        blocks += (w.numel() + 255) // 256
+        blocks += lib.vidc_pack_item_blocks(co, ci, kh, kw, kind)
     dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(DEV)
     L.check(lib.vidc_pack_conv_weights_batched(L.ptr(dev), len(items), blocks, st), "batched pack")
     for (w, out, *_rest), ref in zip(items, want):

@@ -397,9 +397,34 @@ pack_weight_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, in
     wp[idx] = w[(((long long)co * Cin + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
 }
 // Every conv weight of a network re-packed in ONE launch (the parameters move every optimizer step): block -> item by binary search over
-// items[].block_begin (uniform per block: scalar loads), then the per-element maps of pack_weight_kernel / pack_weight_dgrad_kernel,
-// fp32, split-bf16 ([row][K/32][32 x hi | 32 x lo]) or plain bf16 (64 channels per K unit).
+// items[].block_begin (uniform per block: scalar loads).  Both maps are staged through LDS so that the parameter is read and the packed
+// copy written in contiguous runs:
+//  forward (kind & 1 == 0): a U-channel K unit of a row is the same U*taps contiguous elements in the parameter ([U][taps]) and in the
+//      packed row ([taps][U]) -- a local transpose; a block does kPackUnits of them (for a 1x1 conv it is a copy);
+//  dgrad (kind & 1): a block takes U output channels x kPackCi input channels: U contiguous runs of kPackCi*taps parameter elements in,
+//      kPackCi*taps runs of U packed elements out (kernel flipped).
+// U = 32 channels per 128-byte unit for fp32 / split-bf16 ([32 x hi | 32 x lo]), 64 for plain bf16.
+constexpr int kPackUnits = 8, kPackCi = 8;
+__host__ __device__ inline long long pack_item_blocks(int Cout, int Cin, int KH, int KW, int kind) {
+    const int U = (kind & 4) ? 64 : 32;
+    if (!(kind & 1)) return ((long long)Cout * (Cin / U) + kPackUnits - 1) / kPackUnits;
+    return (long long)(Cout / U) * ((Cin + kPackCi - 1) / kPackCi);
+}
+__device__ inline void pack_store(const vidc_pack_item& it, long long off, float v) {
+    if (it.kind & 4) {
+        reinterpret_cast<unsigned short*>(it.packed)[off] = vidc::bf16_rne(v);
+    } else if (it.kind & 2) {
+        unsigned short h, l;
+        vidc::split_bf16(v, h, l);
+        unsigned short* base = reinterpret_cast<unsigned short*>(it.packed) + (off >> 5) * 64 + (off & 31);
+        base[0] = h;
+        base[32] = l;
+    } else {
+        it.packed[off] = v;
+    }
+}
 __global__ void __launch_bounds__(TT) pack_batched_kernel(const vidc_pack_item* __restrict__ items, int n) {
+    __shared__ float tile[64 * (kPackCi * 9 + 1)];          // 64 channels x (8 x 9 + 1) floats = 18.25 KB; also holds 8 units x 64 x 9
     int lo = 0, hi = n - 1;
     const long long blk = blockIdx.x;
     while (lo < hi) {
@@ -407,27 +432,32 @@ __global__ void __launch_bounds__(TT) pack_batched_kernel(const vidc_pack_item* 
         if (items[mid].block_begin <= blk) lo = mid; else hi = mid - 1;
     }
     const vidc_pack_item it = items[lo];
-    const long long total = (long long)it.Cout * it.Cin * it.KH * it.KW;
-    const long long idx = (blk - it.block_begin) * TT + threadIdx.x;
-    if (idx >= total) return;
-    const int taps = it.KH * it.KW, dgrad = it.kind & 1;
-    const int U = (it.kind & 4) ? 64 : 32;                // channels per 128-byte K unit: 64 bf16, 32 fp32 / split-bf16
-    const int K = (dgrad ? it.Cout : it.Cin) * taps;
-    const int row = (int)(idx / K), k = (int)(idx - (long long)row * K);
-    const int lane = k % U, u = k / U;
-    const int cu = u / taps, tap = u - cu * taps, kh = tap / it.KW, kw = tap - kh * it.KW, ch = cu * U + lane;
-    const float v = dgrad ? it.w[(((long long)ch * it.Cin + row) * it.KH + (it.KH - 1 - kh)) * it.KW + (it.KW - 1 - kw)]
-                          : it.w[(((long long)row * it.Cin + ch) * it.KH + kh) * it.KW + kw];
-    if (it.kind & 4) {
-        reinterpret_cast<unsigned short*>(it.packed)[idx] = vidc::bf16_rne(v);
-    } else if (it.kind & 2) {
-        unsigned short h, l;
-        vidc::split_bf16(v, h, l);
-        unsigned short* base = reinterpret_cast<unsigned short*>(it.packed) + ((long long)row * (K / 32) + u) * 64 + lane;
-        base[0] = h;
-        base[32] = l;
+    const int lb = (int)(blk - it.block_begin);
+    const int taps = it.KH * it.KW, U = (it.kind & 4) ? 64 : 32, seg = U * taps;
+    if (!(it.kind & 1)) {
+        const long long units = (long long)it.Cout * (it.Cin / U), u0 = (long long)lb * kPackUnits;
+        const int cnt = (int)min((long long)kPackUnits, units - u0) * seg;
+        const float* src = it.w + u0 * seg;
+        for (int i = threadIdx.x; i < cnt; i += TT) tile[i] = src[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += TT) {
+            const int u = i / seg, r = i - u * seg, tap = r / U, lane = r - tap * U;
+            pack_store(it, u0 * seg + i, tile[u * seg + lane * taps + tap]);
+        }
     } else {
-        it.packed[idx] = v;
+        const int ci_tiles = (it.Cin + kPackCi - 1) / kPackCi;
+        const int cu = lb / ci_tiles, ci0 = (lb - cu * ci_tiles) * kPackCi, nci = min(kPackCi, it.Cin - ci0);
+        const int run = nci * taps, pitch = kPackCi * taps + 1;
+        for (int i = threadIdx.x; i < U * run; i += TT) {
+            const int col = i / run, r = i - col * run;
+            tile[col * pitch + r] = it.w[((long long)(cu * U + col) * it.Cin + ci0) * taps + r];
+        }
+        __syncthreads();
+        const long long Kp = (long long)it.Cout * taps;
+        for (int i = threadIdx.x; i < run * U; i += TT) {
+            const int cl = i / seg, r = i - cl * seg, tap = r / U, lane = r - tap * U;
+            pack_store(it, (long long)(ci0 + cl) * Kp + (long long)(cu * taps + tap) * U + lane, tile[lane * pitch + cl * taps + (taps - 1 - tap)]);
+        }
     }
 }
 
@@ -665,13 +695,15 @@ stem_wgrad_partial_kernel(const float* __restrict__ dy, const float* __restrict_
     const long long M = (long long)B * Ho * Wo;
     const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
     double s = 0.0;
-    for (long long m = r0; m < r1; ++m) {
-        const int ox = (int)(m % Wo);
-        const long long q = m / Wo;
-        const int oy = (int)(q % Ho), b = (int)(q / Ho);
+    int ox = (int)(r0 % Wo);                              // (b, oy, ox) of the row walk incrementally: no division in the loop
+    const long long q0 = r0 / Wo;
+    int oy = (int)(q0 % Ho), b = (int)(q0 / Ho);
+    const float* gp = dy + r0 * lddy + co;
+    for (long long m = r0; m < r1; ++m, gp += lddy) {
         const int iy = 2 * oy - 1 + kh, ix = 2 * ox - 1 + kw;
         if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            s += (double)dy[m * lddy + co] * (double)x[(((long long)b * Cin + ci) * H + iy) * W + ix];
+            s += (double)*gp * (double)x[(((long long)b * Cin + ci) * H + iy) * W + ix];
+        if (++ox == Wo) { ox = 0; if (++oy == Ho) { oy = 0; ++b; } }
     }
     partial[(size_t)blockIdx.y * n + idx] = s;
 }
@@ -680,6 +712,7 @@ stem_wgrad_partial_kernel(const float* __restrict__ dy, const float* __restrict_
 
 // ---- C ABI ----------------------------------------------------------------------------------------------------------------------
 namespace {
+constexpr int kStemRows = 256;            // rows per workgroup of vidc_stem_wgrad (M = 153 600 at batch 8: 600 chunks x 7 blocks)
 constexpr int kRowsPerChunk = 256;        // rows per workgroup of the per-channel reductions: M = 10^4..10^5 rows -> hundreds of workgroups per 64 channels
 inline int chunks_for(long long M) { return (int)((M + kRowsPerChunk - 1) / kRowsPerChunk); }
 // Rows per workgroup of the per-channel reductions (chan_partial_kernel): about 512 workgroups per launch whatever the shape -- a function of
@@ -842,6 +875,13 @@ extern "C" int vidc_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed,
     return VIDC_OK;
 }
 
+extern "C" long long vidc_pack_item_blocks(int Cout, int Cin, int KH, int KW, int kind) {
+    if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || KH * KW > 9 || kind < 0 || kind > 5) return 0;
+    const int U = (kind & 4) ? 64 : 32;
+    if (((kind & 1) ? Cout : Cin) % U) return 0;          // the K-side channel count must fill whole 128-byte units
+    return pack_item_blocks(Cout, Cin, KH, KW, kind);
+}
+
 extern "C" int vidc_pack_conv_weights_batched(const vidc_pack_item* items_device, int n_items, long long total_blocks, vidc_stream_t stream) {
     VIDC_REQUIRE(items_device, VIDC_ERR_NULL, "vidc_pack_conv_weights_batched: null pointer");
     VIDC_REQUIRE(n_items > 0 && total_blocks > 0 && total_blocks < (1ll << 31), VIDC_ERR_SHAPE, "vidc_pack_conv_weights_batched: bad item / block count");
@@ -944,7 +984,7 @@ extern "C" int vidc_stem_wgrad(const float* dy, const float* x_nchw, float* dw_o
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long M = (long long)B * Ho * Wo;
     const int n = Cout * Cin * 9;
-    const int rows = 1024;
+    const int rows = kStemRows;
     const int chunks = (int)((M + rows - 1) / rows);
     double* partial = reinterpret_cast<double*>(scratch);
     hipLaunchKernelGGL(stem_wgrad_partial_kernel, dim3(blocks(n), chunks), dim3(TT), 0, st, dy, x_nchw, B, Cin, H, W, Ho, Wo, Cout, lddy, rows, partial);
@@ -956,5 +996,5 @@ extern "C" int vidc_stem_wgrad(const float* dy, const float* x_nchw, float* dw_o
 extern "C" size_t vidc_stem_wgrad_scratch_bytes(int B, int Cin, int H, int W, int Cout) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long M = (long long)B * Ho * Wo;
-    return (size_t)((M + 1023) / 1024) * (size_t)Cout * Cin * 9 * sizeof(double);
+    return (size_t)((M + kStemRows - 1) / kStemRows) * (size_t)Cout * Cin * 9 * sizeof(double);
 }

@@ -213,7 +213,10 @@ class DepthCompletionTrainer:
         blocks = 0
         for t, (w, out, co, ci, kh, kw, kind) in zip(table, items):
             t.w, t.packed, t.Cout, t.Cin, t.KH, t.KW, t.kind, t.block_begin = L.ptr(w), L.ptr(out), co, ci, kh, kw, kind, blocks
-            blocks += (co * ci * kh * kw + 255) // 256
+            nb = L.lib().vidc_pack_item_blocks(co, ci, kh, kw, kind)
+            if nb <= 0:
+                raise RuntimeError("conv weight %dx%dx%dx%d cannot be packed for kind %d (K-side channels must fill whole 128-byte units)" % (co, ci, kh, kw, kind))
+            blocks += nb
         dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
         L.check(L.lib().vidc_pack_conv_weights_batched(L.ptr(dev), len(items), blocks, L.current_stream()), "pack")
         return dev, blocks
