@@ -401,14 +401,16 @@ size_t vidc_train_scratch_bytes(long long M, int C);
 
 /* nn.BatchNorm2d in train() mode (+ the ReLU that follows it when relu != 0): batch mean / biased variance over the M rows,
  * y = (x - mean) * invstd * gamma + beta; running_mean/var (may be NULL) <- (1 - momentum) * old + momentum * (mean, unbiased var);
- * save_mean / save_rstd [C] are kept for the backward. */
+ * save_mean / save_rstd [C] are kept for the backward.  y_bf16 (may be NULL): additionally the output rounded to bf16 as dense rows of C
+ * values -- the operand the next conv of a VIDC_PREC_BF16 step reads (saves its vidc_cast_bf16 launch). */
 int vidc_bn_train_forward(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
-                          void* scratch, vidc_stream_t stream);
-/* Its backward.  y_relu: the forward output when a ReLU followed (its mask is applied to dy), else NULL.  dx may alias dy. */
+                          void* y_bf16, void* scratch, vidc_stream_t stream);
+/* Its backward.  y_relu: the forward output when a ReLU followed (its mask is applied to dy), else NULL.  dx may alias dy.
+ * dx_bf16 (may be NULL): dx as dense bf16 rows as well (the dgrad conv of the layer in front reads it). */
 int vidc_bn_train_backward(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
                            int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
-                           void* scratch, vidc_stream_t stream);
+                           void* dx_bf16, void* scratch, vidc_stream_t stream);
 /* out[c] = sum over rows of dy[.][c]: the bias gradient of a convolution. */
 int vidc_colsum(const float* dy, long long M, int C, int ld, float* out, void* scratch, vidc_stream_t stream);
 /* y = a + b, ReLU optional (Bottleneck: relu(bn3(conv3(.)) + identity); decoder: z1 + z2 + z3 + z4). */

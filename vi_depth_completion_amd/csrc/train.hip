@@ -127,7 +127,8 @@ __global__ void __launch_bounds__(TT) chan_final_kernel(const double* __restrict
 // y = x * alpha + beta' with alpha = invstd * gamma, beta' = beta - mean * alpha (torch's batch_norm_cpu_transform_input), ReLU optional
 __global__ void __launch_bounds__(TT)
 bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long long M, int C, int ldx, int ldy, const float* __restrict__ mean,
-                const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta, int relu) {
+                const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                unsigned short* __restrict__ y_bf16) {
     const int c4 = C >> 2;
     const long long i = (long long)blockIdx.x * TT + threadIdx.x;
     if (i >= M * c4) return;
@@ -143,13 +144,16 @@ bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long long M,
         out[k] = relu ? fmaxf(o, 0.f) : o;
     }
     *reinterpret_cast<float4*>(y + r * ldy + c) = make_float4(out[0], out[1], out[2], out[3]);
+    if (y_bf16)         // the bf16 operand copy the next conv of a VIDC_PREC_BF16 step reads (dense rows of C bf16), saving its cast launch
+        *reinterpret_cast<uint2*>(y_bf16 + r * C + c) = make_uint2(vidc::bf16_rne(out[0]) | ((unsigned)vidc::bf16_rne(out[1]) << 16),
+                                                                   vidc::bf16_rne(out[2]) | ((unsigned)vidc::bf16_rne(out[3]) << 16));
 }
 
 // dx = gamma * invstd * (dy' - sum(dy')/M - xhat * sum(dy' * xhat)/M); dgamma = sum(dy' * xhat); dbeta = sum(dy')
 __global__ void __launch_bounds__(TT)
 bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ dx, long long M, int C,
                     int lddy, int ldx, int ldy, int lddx, const float* __restrict__ mean, const float* __restrict__ rstd,
-                    const float* __restrict__ gamma, const double* __restrict__ sums) {
+                    const float* __restrict__ gamma, const double* __restrict__ sums, unsigned short* __restrict__ dx_bf16) {
     const int c4 = C >> 2;
     const long long i = (long long)blockIdx.x * TT + threadIdx.x;
     if (i >= M * c4) return;
@@ -171,6 +175,9 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, c
         o[k] = gamma[c + k] * rstd[c + k] * (g[k] - m1 - xh * m2);
     }
     *reinterpret_cast<float4*>(dx + r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+    if (dx_bf16)
+        *reinterpret_cast<uint2*>(dx_bf16 + r * C + c) = make_uint2(vidc::bf16_rne(o[0]) | ((unsigned)vidc::bf16_rne(o[1]) << 16),
+                                                                    vidc::bf16_rne(o[2]) | ((unsigned)vidc::bf16_rne(o[3]) << 16));
 }
 
 // ---- elementwise ---------------------------------------------------------------------------------------------------------------
@@ -733,7 +740,7 @@ extern "C" size_t vidc_train_scratch_bytes(long long M, int C) {
 
 extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
                                      float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
-                                     void* scratch, vidc_stream_t stream) {
+                                     void* y_bf16, void* scratch, vidc_stream_t stream) {
     VIDC_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && scratch, VIDC_ERR_NULL, "vidc_bn_train_forward: null pointer");
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0, VIDC_ERR_SHAPE, "vidc_bn_train_forward: bad shape");
     hipStream_t st = vidc::as_stream(stream);
@@ -744,14 +751,15 @@ extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int 
                        (const float*)nullptr, (const float*)nullptr, rows_for(M, C), partial);
     hipLaunchKernelGGL(chan_final_kernel<FinalStats>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums,
                        FinalStats{M, eps, momentum, save_mean, save_rstd, running_mean, running_var});
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, x, y, M, C, ldx, ldy, save_mean, save_rstd, gamma, beta, relu);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, x, y, M, C, ldx, ldy, save_mean, save_rstd, gamma, beta, relu,
+                       reinterpret_cast<unsigned short*>(y_bf16));
     VIDC_CHECK_LAUNCH("bn_train_forward");
     return VIDC_OK;
 }
 
 extern "C" int vidc_bn_train_backward(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
                                       int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
-                                      void* scratch, vidc_stream_t stream) {
+                                      void* dx_bf16, void* scratch, vidc_stream_t stream) {
     VIDC_REQUIRE(dy && x && dx && gamma && save_mean && save_rstd && dgamma && dbeta && scratch, VIDC_ERR_NULL, "vidc_bn_train_backward: null pointer");
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!y_relu || ldy % 4 == 0), VIDC_ERR_SHAPE,
                  "vidc_bn_train_backward: bad shape");
@@ -762,7 +770,7 @@ extern "C" int vidc_bn_train_backward(const float* dy, const float* x, const flo
     hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean, save_rstd, rows_for(M, C), partial);
     hipLaunchKernelGGL(chan_final_kernel<FinalParamGrad>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, FinalParamGrad{dgamma, dbeta});
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, save_mean, save_rstd,
-                       gamma, sums);
+                       gamma, sums, reinterpret_cast<unsigned short*>(dx_bf16));
     VIDC_CHECK_LAUNCH("bn_train_backward");
     return VIDC_OK;
 }

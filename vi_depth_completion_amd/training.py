@@ -35,10 +35,10 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 class Act:
     """An activation: NHWC rows `t` (B,H,W,C view, possibly a channel slice of a wider buffer) + its gradient (same geometry)."""
-    __slots__ = ("t", "grad")
+    __slots__ = ("t", "grad", "bf", "grad_bf")      # bf / grad_bf: bf16 operand copies (dense rows) written by the producing kernel
 
     def __init__(self, t):
-        self.t, self.grad = t, None
+        self.t, self.grad, self.bf, self.grad_bf = t, None, None, None
 
     @property
     def ld(self):
@@ -144,7 +144,7 @@ class DepthCompletionTrainer:
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
     # ---- conv: forward, dgrad, wgrad --------------------------------------------------------------------------------------------
-    def _conv_call(self, x_t, w_packed, shift, y_t, kh, kw, stride, pad, relu, accumulate):
+    def _conv_call(self, x_t, w_packed, shift, y_t, kh, kw, stride, pad, relu, accumulate, x_bf=None):
         """One launch of the inference conv kernel.  In bf16x3 mode the activations are split here (one extra pass over x); `w_packed`
         must already be in the matching format (`_pack`)."""
         B, H, W, cin = x_t.shape
@@ -157,8 +157,10 @@ class DepthCompletionTrainer:
         elif self.precision == L.PREC_BF16:      # plain bf16 rows; the descriptor counts two channels per element (include/vidc.h)
             if cin % 64:
                 raise RuntimeError("bf16 training needs conv input channels in multiples of 64 (got %d)" % cin)
-            xs = self._empty(B, H, W, cin // 2)
-            L.check(L.lib().vidc_cast_bf16(L.ptr(x_t), L.ptr(xs), B * H * W, cin, ldx, L.current_stream()), "cast")
+            xs = x_bf                             # the producer wrote the bf16 copy already (bn / bn backward)
+            if xs is None:
+                xs = self._empty(B, H, W, cin // 2)
+                L.check(L.lib().vidc_cast_bf16(L.ptr(x_t), L.ptr(xs), B * H * W, cin, ldx, L.current_stream()), "cast")
             x_t, cin = xs, cin // 2
             ldx = cin
         d = L.ConvDesc()
@@ -279,14 +281,14 @@ class DepthCompletionTrainer:
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
         wp = self._pack(key, "f", w)
         y = Act(out if out is not None else self._empty(B, Ho, Wo, co))
-        self._conv_call(x.t, wp, bias if bias is not None else self._const(self._zeros, co, 0.0), y.t, kh, kw, stride, pad, relu, False)
+        self._conv_call(x.t, wp, bias if bias is not None else self._const(self._zeros, co, 0.0), y.t, kh, kw, stride, pad, relu, False, x_bf=x.bf)
 
         def backward():
-            g = y.grad
+            g, g_bf = y.grad, y.grad_bf
             if relu:                                         # y = relu(conv): mask first
                 gm = self._empty(B, Ho, Wo, co)
                 L.check(L.lib().vidc_relu_backward(L.ptr(g), L.ptr(y.t), L.ptr(gm), y.rows, co, _ld(g), y.ld, co, 0, L.current_stream()), "relu_bwd")
-                g = gm
+                g, g_bf = gm, None
             lib = L.lib()
             # weight gradient and bias gradient (column sums)
             if not self._wgrad_gemm(g, x, key, (B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad)):
@@ -302,12 +304,14 @@ class DepthCompletionTrainer:
             wd = self._pack(key, "d", w)
             gz = g
             if stride > 1:
-                gz = self._empty(B, H, W, co)
+                gz, g_bf = self._empty(B, H, W, co), None
                 L.check(lib.vidc_zero_stuff(L.ptr(g), L.ptr(gz), B, Ho, Wo, co, _ld(g), stride, H, W, L.current_stream()), "zero_stuff")
             acc = x.grad is not None
             if not acc:
                 x.grad = self._empty(B, H, W, ci)
-            self._conv_call(gz, wd, self._const(self._zeros, ci, 0.0), x.grad, kh, kw, 1, kh - 1 - pad, False, acc)
+            if acc:
+                x.grad_bf = None                             # x.grad changes below
+            self._conv_call(gz, wd, self._const(self._zeros, ci, 0.0), x.grad, kh, kw, 1, kh - 1 - pad, False, acc, x_bf=g_bf)
 
         self.tape.append(backward)
         return y
@@ -318,22 +322,26 @@ class DepthCompletionTrainer:
         y = Act(out if out is not None else torch.empty_like(x.t))
         mean, rstd = self._empty(Cc), self._empty(Cc)
         gamma, beta = self.param[key + ".weight"], self.param[key + ".bias"]
+        bf16 = self.precision == L.PREC_BF16 and Cc % 64 == 0
+        if bf16:
+            y.bf = self._empty(*x.t.shape[:-1], Cc // 2)
         L.check(L.lib().vidc_bn_train_forward(L.ptr(x.t), L.ptr(y.t), x.rows, Cc, x.ld, y.ld, L.ptr(gamma), L.ptr(beta), L.ptr(self.buf[key + ".running_mean"]),
                                               L.ptr(self.buf[key + ".running_var"]), BN_EPS, BN_MOMENTUM, int(relu), L.ptr(mean), L.ptr(rstd),
-                                              L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_forward")
+                                              L.ptr(y.bf) if y.bf is not None else None, L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_forward")
         self._nbt.append(self.buf[key + ".num_batches_tracked"])
 
         def backward():
             acc = x.grad is not None
             dx = self._empty(*x.t.shape) if acc else None
             target = dx if acc else self._empty(*x.t.shape)
+            tbf = self._empty(*x.t.shape[:-1], Cc // 2) if (bf16 and not acc) else None
             L.check(L.lib().vidc_bn_train_backward(L.ptr(y.grad), L.ptr(x.t), L.ptr(y.t) if relu else None, L.ptr(target), x.rows, Cc, _ld(y.grad), x.ld, y.ld,
                                                    Cc, L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(self.grad[key + ".weight"]), L.ptr(self.grad[key + ".bias"]),
-                                                   L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_backward")
+                                                   L.ptr(tbf) if tbf is not None else None, L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_backward")
             if acc:
                 self._accumulate(x, target)
             else:
-                x.grad = target
+                x.grad, x.grad_bf = target, tbf
 
         self.tape.append(backward)
         return y
@@ -349,6 +357,7 @@ class DepthCompletionTrainer:
         if x.grad is None:
             x.grad = g
             return
+        x.grad_bf = None                                     # the in-place sum below makes a bf16 copy of x.grad stale
         Cc = x.t.shape[-1]
         L.check(L.lib().vidc_relu_backward(L.ptr(g), None, L.ptr(x.grad), x.rows, Cc, _ld(g), 0, _ld(x.grad), 1, L.current_stream()), "accumulate")
 
