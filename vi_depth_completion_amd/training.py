@@ -16,9 +16,11 @@ state_dict layout; parameters and their .grad become views of two flat buffers) 
 the flat gradient buffer (RCCL): frames shard over ranks, every rank normalises BatchNorm over ITS frames (what the reference's
 DataParallel replicas do as well) and gradients are SUMMED, which equals the reference's single loss over the whole batch.
 There is no CPU path.  Arithmetic: exact fp32 MFMA products in all three conv passes (the reference's arithmetic: gradients sit at
-the reference's own fp32 noise floor).  VIDC_TRAIN_PRECISION=bf16x3 runs the forward and dgrad convs in the split-bf16 3-pass mode of
-the inference path (~2^-16 per product): 12 % faster per step, loss identical to 6 digits, individual gradient tensors up to ~6 % of
-their scale away (flipped ReLU gates propagate through the train-mode BatchNorms) -- a throughput option, not the parity mode."""
+the reference's own fp32 noise floor).  VIDC_TRAIN_PRECISION=bf16x3 runs the three conv passes in the split-bf16 3-pass mode of
+the inference path (~2^-16 per product; 1.5x the step rate) and VIDC_TRAIN_PRECISION=bf16 in plain bf16 with fp32 accumulation -- the
+arithmetic BASELINE configs[4] names (2x; fp32 master weights, BatchNorm, loss and Adam in all modes).  Both keep the loss to 4-6
+digits; individual gradient tensors move by percents of their scale (flipped ReLU gates propagate through the train-mode BatchNorms):
+throughput modes, not the parity mode (tests/test_training.py states their bars)."""
 import ctypes as C
 import json
 import os
