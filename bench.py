@@ -225,6 +225,9 @@ def measure(args, dev, rank, world, precision):
                  "arithmetic": ("bf16x3: 3 x v_mfma_f32_32x32x16_bf16 per fp32-equivalent product" if prec else "v_mfma_f32_32x32x2_f32"),
                  "launches_per_frame": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2), "gflop_per_launch": round(fl / cnt / 1e9, 3),
                  "ms_per_frame": round(ms, 3),
+                 "timing_note": "per-launch durations are taken on ONE stream (the frame program alone, HIP events between ops, rescaled to its graph replay time); "
+                                "with --lanes 2 launches of the two streams overlap and a kernel trace of the run shows longer per-kernel durations: "
+                                "profiles/r2_kernel_stats_lanes1.csv (--lanes 1) is the trace these numbers agree with",
                  "traffic_note": "PMC FETCH_SIZE/WRITE_SIZE of this kernel class: profiles/ (rocprofv3 --pmc on the whole "
                                  "bench process segfaults in rocprofv3 on this pool, so counters are collected on tools/conv_bench.py)"}
             if prec:
