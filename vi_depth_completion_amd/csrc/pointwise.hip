@@ -55,17 +55,43 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
 }
 
 // ---- max-pool 3x3 stride 2 pad 1, NHWC -----------------------------------------------------------------------
+// Workgroups are handed to the 8 XCDs (8 private L2s) round-robin in linear launch order.  These kernels read every input row from
+// several output rows and every input pixel from neighbouring column blocks, so instead of letting neighbours land on different
+// XCDs, XCD k takes the k-th contiguous BAND of the (row, column-block) space: workgroup L of the launch = the (L / 8)-th block of XCD
+// L % 8.  gridDim.x is a multiple of 8 (host side), so every XCD gets the same number of blocks.  (rocprofv3 FETCH_SIZE: the bilinear
+// upsample fetched 3.3-6.6x its input before, the max-pool 1.6x.)
+__device__ __forceinline__ void xcd_band_block(unsigned& bx, unsigned& by) {
+    const unsigned gx = gridDim.x, L = blockIdx.y * gx + blockIdx.x, per = (gx >> 3) * gridDim.y;
+    const unsigned idx = (L & 7u) * per + (L >> 3);
+    by = idx / gx;
+    bx = idx - by * gx;
+}
+// The same idea with the bands cut into groups of kRowGroup rows dealt to the XCDs in turn (gridDim.y a multiple of 8 * kRowGroup): the
+// eight L2s then work within a window of 8 * kRowGroup rows of the output instead of in eight regions far apart, which keeps the DRAM
+// pages they write close together; only the rows at the group seams are fetched twice.
+constexpr unsigned kRowGroup = 4;
+__device__ __forceinline__ void xcd_rowgroup_block(unsigned& bx, unsigned& by) {
+    const unsigned gx = gridDim.x, L = blockIdx.y * gx + blockIdx.x;
+    const unsigned k = L & 7u, j = L >> 3, per_group = kRowGroup * gx;
+    const unsigned t = j / per_group, r = j - t * per_group;
+    const unsigned rr = r / gx;
+    by = (t * 8u + k) * kRowGroup + rr;
+    bx = r - rr * gx;
+}
+
 __global__ void __launch_bounds__(256)
 maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int ldx, int Ho, int Wo, int ldy,
                unsigned short* __restrict__ ysp) {
     // grid.y = output row (image, oy): wave-uniform, so the per-thread index math is one 32-bit division (the first version
     // decomposed a 64-bit linear index with three emulated 64-bit divisions per thread: VALU-bound at 52-62 % of the HBM peak)
     const unsigned q = (unsigned)C / 4u;
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned bx, by;
+    xcd_band_block(bx, by);
+    const unsigned i = bx * blockDim.x + threadIdx.x;
     if (i >= (unsigned)Wo * q) return;
     const int ox = (int)(i / q);
     const int c = (int)(i - (unsigned)ox * q) * 4;
-    const int b = (int)(blockIdx.y / (unsigned)Ho), oy = (int)(blockIdx.y - (unsigned)b * (unsigned)Ho);
+    const int b = (int)(by / (unsigned)Ho), oy = (int)(by - (unsigned)b * (unsigned)Ho);
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -99,11 +125,14 @@ __global__ void __launch_bounds__(256)
 upsample_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int h, int w, int C, int ldx, int H, int W, int ldy,
                 int flags, unsigned short* __restrict__ ysp) {
     const unsigned q = (unsigned)C / 4u;                   // grid.y = output row (image, oy), see maxpool_kernel
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned bx, by;
+    xcd_rowgroup_block(bx, by);
+    const unsigned i = bx * blockDim.x + threadIdx.x;
     if (i >= (unsigned)W * q) return;
     const int ox = (int)(i / q);
     const int c = (int)(i - (unsigned)ox * q) * 4;
-    const int b = (int)(blockIdx.y / (unsigned)H), oy = (int)(blockIdx.y - (unsigned)b * (unsigned)H);
+    if (by >= (unsigned)(B * H)) return;                   // rows of the padded grid
+    const int b = (int)(by / (unsigned)H), oy = (int)(by - (unsigned)b * (unsigned)H);
     int y0, y1, x0, x1; float ly, lx;
     src_index(oy, h, H, y0, y1, ly);
     src_index(ox, w, W, x0, x1, lx);
@@ -266,7 +295,8 @@ extern "C" int vidc_maxpool3x3s2(const float* x, float* y, int B, int H, int W, 
                  VIDC_ERR_SHAPE, "vidc_maxpool3x3s2: bad shape (C, ldx, ldy must be multiples of 4)");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     VIDC_REQUIRE((long long)B * Ho <= 65535, VIDC_ERR_SHAPE, "vidc_maxpool3x3s2: B * Ho = %lld rows exceed the grid", (long long)B * Ho);
-    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)vidc::cdiv(Wo * (C / 4), 256), (unsigned)(B * Ho)), dim3(256), 0, vidc::as_stream(stream), x, y, B, H, W,
+    // grid.x rounded up to a multiple of 8 (idle workgroups return at once) for xcd_band_block()
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)(vidc::cdiv(Wo * (C / 4), 256) + 7) / 8 * 8, (unsigned)(B * Ho)), dim3(256), 0, vidc::as_stream(stream), x, y, B, H, W,
                        C, ldx, Ho, Wo, ldy, reinterpret_cast<unsigned short*>(y_split));
     VIDC_CHECK_LAUNCH("maxpool_kernel");
     return VIDC_OK;
@@ -280,8 +310,9 @@ extern "C" int vidc_upsample_bilinear_ac(const float* x, float* y, int B, int h,
     VIDC_REQUIRE(ldx >= C * (((flags >> 8) & 0xFF) > 1 ? ((flags >> 8) & 0xFF) : 1) && ldy >= C, VIDC_ERR_SHAPE, "vidc_upsample_bilinear_ac: bad channel strides");
     VIDC_REQUIRE(B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, VIDC_ERR_SHAPE,
                  "vidc_upsample_bilinear_ac: bad shape");
-    VIDC_REQUIRE((long long)B * H <= 65535, VIDC_ERR_SHAPE, "vidc_upsample_bilinear_ac: B * H = %lld rows exceed the grid", (long long)B * H);
-    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)vidc::cdiv(W * (C / 4), 256), (unsigned)(B * H)), dim3(256), 0, vidc::as_stream(stream), x, y, B, h, w,
+    VIDC_REQUIRE((long long)B * H <= 65504, VIDC_ERR_SHAPE, "vidc_upsample_bilinear_ac: B * H = %lld rows exceed the grid", (long long)B * H);
+    // (grid.x a multiple of 8, grid.y of 32: xcd_rowgroup_block())
+    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)(vidc::cdiv(W * (C / 4), 256) + 7) / 8 * 8, (unsigned)((B * H + 31) / 32 * 32)), dim3(256), 0, vidc::as_stream(stream), x, y, B, h, w,
                        C, ldx, H, W, ldy, flags, reinterpret_cast<unsigned short*>(y_split));
     VIDC_CHECK_LAUNCH("upsample_kernel");
     return VIDC_OK;
