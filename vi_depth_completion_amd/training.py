@@ -119,8 +119,11 @@ class DepthCompletionTrainer:
         self.buf = {k: b for k, b in cnn.named_buffers()}
         self.buckets = GradientBuckets(n)
         self.step_count = 0
-        self._ones, self._zeros, self._packed, self._scratch, self._nbt = {}, {}, {}, None, []
-        self._gemm_ws = None
+        self._ones, self._zeros, self._packed, self._scratch, self._nbt = {}, {}, {}, {}, []
+        self._gemm_ws = {}          # split-K workspace per stream lane (lane 0 = the caller's stream)
+        self._cur = 0               # stream lane the ops being recorded / replayed run on (0 = main, 1..3 = the three pyramids)
+        self._lanes = None
+        self.n_lanes = int(os.environ.get("VIDC_TRAIN_STREAMS", "3"))
         self._pack_items, self._pack_table, self._packed_fresh = [], None, False
         self.use_graph = os.environ.get("VIDC_TRAIN_GRAPH", "1") != "0"
         self._graphs, self._graph_seen = {}, {}
@@ -132,12 +135,23 @@ class DepthCompletionTrainer:
     def _const(self, store, n, value):
         if n not in store:
             store[n] = torch.full((n,), value, dtype=torch.float32, device=self.device)
+            torch.cuda.current_stream().synchronize()     # made on one stream lane, read by all of them from now on
         return store[n]
 
     def _scratch_bytes(self, nbytes):
-        if self._scratch is None or self._scratch.numel() < nbytes:
-            self._scratch = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
-        return self._scratch
+        sc = self._scratch.get(self._cur)                 # one scratch per stream lane: the lanes run concurrently
+        if sc is None or sc.numel() < nbytes:
+            sc = self._scratch[self._cur] = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
+        return sc
+
+    def _record(self, fn):
+        fn._lane = self._cur
+        self.tape.append(fn)
+
+    def _lane_streams(self):
+        if self._lanes is None:
+            self._lanes = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        return self._lanes
 
     def _train_scratch(self, M, Cc):
         return self._scratch_bytes(L.lib().vidc_train_scratch_bytes(M, Cc))
@@ -193,9 +207,10 @@ class DepthCompletionTrainer:
                 d.splitk = 1
         need = lib.vidc_conv2d_workspace_bytes(C.byref(d))
         if need:
-            if self._gemm_ws is None or self._gemm_ws.numel() * 4 < need:
-                self._gemm_ws = torch.zeros(int(need // 4 * 1.5) + 16, dtype=torch.float32, device=self.device)
-            d.workspace = L.ptr(self._gemm_ws)
+            ws = self._gemm_ws.get(self._cur)
+            if ws is None or ws.numel() * 4 < need:
+                ws = self._gemm_ws[self._cur] = torch.zeros(int(need // 4 * 1.5) + 16, dtype=torch.float32, device=self.device)
+            d.workspace = L.ptr(ws)
 
     def _pack(self, key, kind, w):
         """Packed weights of conv `key` for the forward ('f') or the dgrad ('d': kernel flipped, channels transposed) launch, in the
@@ -315,7 +330,7 @@ class DepthCompletionTrainer:
                 x.grad_bf = None                             # x.grad changes below
             self._conv_call(gz, wd, self._const(self._zeros, ci, 0.0), x.grad, kh, kw, 1, kh - 1 - pad, False, acc, x_bf=g_bf)
 
-        self.tape.append(backward)
+        self._record(backward)
         return y
 
     # ---- BatchNorm (train mode) + ReLU ---------------------------------------------------------------------------------------------
@@ -345,7 +360,7 @@ class DepthCompletionTrainer:
             else:
                 x.grad, x.grad_bf = target, tbf
 
-        self.tape.append(backward)
+        self._record(backward)
         return y
 
     def flush_counters(self):
@@ -377,7 +392,7 @@ class DepthCompletionTrainer:
             self._accumulate(a, g)
             self._accumulate(b, g)
 
-        self.tape.append(backward)
+        self._record(backward)
         return y
 
     def maxpool(self, x):
@@ -391,7 +406,7 @@ class DepthCompletionTrainer:
             L.check(L.lib().vidc_maxpool3x3s2_backward(L.ptr(x.t), L.ptr(y.grad), L.ptr(dx), B, H, W, Cc, x.ld, _ld(y.grad), Cc, L.current_stream()), "maxpool_bwd")
             self._accumulate(x, dx)
 
-        self.tape.append(backward)
+        self._record(backward)
         return y
 
     def upsample(self, x, size):
@@ -405,7 +420,7 @@ class DepthCompletionTrainer:
                     "upsample_bwd")
             self._accumulate(x, dx)
 
-        self.tape.append(backward)
+        self._record(backward)
         return y
 
     # ---- network walk (depth_completion.py:16-65, 154-165) ----------------------------------------------------------------------
@@ -424,7 +439,7 @@ class DepthCompletionTrainer:
             L.check(L.lib().vidc_stem_wgrad(L.ptr(g), L.ptr(x_nchw), L.ptr(self.grad[p + "conv1.conv1_1.weight"]), B, cin, H, W, out_channels, out_channels,
                                             L.ptr(sc), L.current_stream()), "stem_wgrad")
 
-        self.tape.append(backward)
+        self._record(backward)
         return y
 
     def _bottleneck(self, x, p, stride, project, out=None):
@@ -464,9 +479,26 @@ class DepthCompletionTrainer:
         cat = [self._empty(B, sizes[l][0], sizes[l][1], 3 * chans[l]) for l in range(4)]
         levels = [Act(c) for c in cat]
         subs = []
+        # The three pyramids are independent until the decoder: each runs on its own HIP stream (forward here, backward in
+        # loss_and_backward), so the fixed cost of one pyramid's ~100 small launches hides under the other two's -- in the captured graph
+        # they are three parallel branches.  Scratch and split-K workspaces are per lane.  VIDC_TRAIN_STREAMS=1: one stream.
+        main = torch.cuda.current_stream()
+        multi = self.n_lanes > 1
         for pi, (name, x) in enumerate((("resnet_rgb", image), ("resnet_normal", normal), ("resnet_depth", depth_in))):
             outs = [cat[l][..., pi * chans[l]:(pi + 1) * chans[l]] for l in range(4)]
-            subs.append(self._pyramid(x.contiguous().float(), name + ".", getattr(self.cnn, name), outs))
+            x = x.contiguous().float()
+            if not multi:
+                subs.append(self._pyramid(x, name + ".", getattr(self.cnn, name), outs))
+                continue
+            side = self._lane_streams()[pi]
+            side.wait_stream(main)
+            self._cur = pi + 1
+            with torch.cuda.stream(side):
+                subs.append(self._pyramid(x, name + ".", getattr(self.cnn, name), outs))
+            self._cur = 0
+        if multi:
+            for side in self._lane_streams():
+                main.wait_stream(side)
 
         def split_level_grads():                     # runs (in the backward) once the decoder has produced d(concat): slices become the
             for l in range(4):                       # gradients of the three pyramids' level outputs
@@ -475,7 +507,7 @@ class DepthCompletionTrainer:
                     subs[pi][l].grad = g if subs[pi][l].grad is None else subs[pi][l].grad
         # NB: appended BEFORE the decoder ops, so it runs after all of them in the reversed tape; a level's slice is also fed by the next
         # stage of its pyramid, whose backward (later in the reversed order) accumulates into the same slice.
-        self.tape.append(split_level_grads)
+        self._record(split_level_grads)
 
         zs = []
         for b in (1, 2, 3, 4):
@@ -515,7 +547,7 @@ class DepthCompletionTrainer:
             L.check(lib.vidc_head_backward(L.ptr(g_low), L.ptr(h.t), L.ptr(w2), L.ptr(h.grad), L.ptr(self.grad["feature_concat.2.weight"]),
                                            L.ptr(self.grad["feature_concat.2.bias"]), B, hh, hw_, 192, h.ld, 192, L.ptr(sc), L.current_stream()), "head_bwd")
 
-        self.tape.append(head_backward)
+        self._record(head_backward)
         self._pred = pred
         self.flush_counters()
         return pred
@@ -531,8 +563,26 @@ class DepthCompletionTrainer:
         sc = self._scratch_bytes((n // 512 + 64) * 8)
         L.check(L.lib().vidc_masked_l1_loss(L.ptr(pred), L.ptr(gt), n, H * W, L.ptr(loss), L.ptr(self._pred_grad), L.ptr(terms), L.ptr(sc), L.current_stream()),
                 "loss")
+        main = torch.cuda.current_stream()
+        forked = []
         for fn in reversed(self.tape):
-            fn()
+            lane = getattr(fn, "_lane", 0)
+            if lane == 0 or self.n_lanes <= 1:
+                for side in forked:                       # (does not happen in this network: the pyramids are the first ops recorded)
+                    main.wait_stream(side)
+                forked = []
+                fn()
+                continue
+            side = self._lane_streams()[lane - 1]
+            if side not in forked:
+                side.wait_stream(main)                    # the decoder's backward produced this pyramid's level gradients
+                forked.append(side)
+            self._cur = lane
+            with torch.cuda.stream(side):
+                fn()
+            self._cur = 0
+        for side in forked:
+            main.wait_stream(side)
         self.tape = []
         return loss
 
