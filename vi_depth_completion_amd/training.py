@@ -121,7 +121,7 @@ class DepthCompletionTrainer:
         self.step_count = 0
         self._ones, self._zeros, self._packed, self._scratch, self._nbt = {}, {}, {}, {}, []
         self._gemm_ws = {}          # split-K workspace per stream lane (lane 0 = the caller's stream)
-        self._cur = 0               # stream lane the ops being recorded / replayed run on (0 = main, 1..3 = the three pyramids)
+        self._cur = 0               # stream lane the ops being recorded / replayed run on (0 = main, 1..3 = the three pyramids, 1..4 = the decoder branches)
         self._lanes = None
         self.n_lanes = int(os.environ.get("VIDC_TRAIN_STREAMS", "3"))
         self._pack_items, self._pack_table, self._packed_fresh = [], None, False
@@ -150,7 +150,7 @@ class DepthCompletionTrainer:
 
     def _lane_streams(self):
         if self._lanes is None:
-            self._lanes = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            self._lanes = [torch.cuda.Stream(device=self.device) for _ in range(4)]
         return self._lanes
 
     def _train_scratch(self, M, Cc):
@@ -509,8 +509,7 @@ class DepthCompletionTrainer:
         # stage of its pyramid, whose backward (later in the reversed order) accumulates into the same slice.
         self._record(split_level_grads)
 
-        zs = []
-        for b in (1, 2, 3, 4):
+        def branch(b):
             t = levels[b - 1]
             idx, target = 0, b
             for step in _BRANCH_PLAN[b]:
@@ -523,7 +522,22 @@ class DepthCompletionTrainer:
                     k = step[0]
                     t = self.bn(self.conv(t, q, 1, k // 2), "feature%d_upsamping.%d" % (b, idx + 1), True)
                     idx += 3
-            zs.append(t)
+            return t
+
+        zs = []
+        for b in (1, 2, 3, 4):                       # the four decoder branches are independent until z1 + z2 + z3 + z4: one lane each
+            if not multi:
+                zs.append(branch(b))
+                continue
+            side = self._lane_streams()[b - 1]
+            side.wait_stream(main)
+            self._cur = b
+            with torch.cuda.stream(side):
+                zs.append(branch(b))
+            self._cur = 0
+        if multi:
+            for side in self._lane_streams():
+                main.wait_stream(side)
         z = self.add(self.add(self.add(zs[0], zs[1], False), zs[2], False), zs[3], False)
         h = self.conv(z, "feature_concat.0", 1, 1, relu=True)
         # padded 1x1 head -> bilinear to (H, W) -> ReLU (depth_completion.py:143-147)
