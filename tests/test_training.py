@@ -34,6 +34,15 @@ def _bucket_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
     GradientBuckets(1000, 256).all_reduce(flat)
+    # the split the trainer uses across ranks: the tail of the buffer (the decoder's gradients) first, the head later, each in its
+    # own buckets; callbacks called before the data is used
+    two = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    b = GradientBuckets(1000, 256)
+    waits = b.all_reduce_async(two, 600, None)
+    waits += b.all_reduce_async(two, 0, 600)
+    for w in waits:
+        w()
+    assert torch.equal(two, flat)
     if rank == 0:
         out.put(flat.clone())
     dist.barrier()

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--same-data", action="store_true", help="every rank trains on rank 0's frames: the summed gradient is N x the single-rank one and\n"
+                                                             "Adam's update does not depend on the gradient's scale, so the losses must follow the single-rank run")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
@@ -42,14 +44,16 @@ def main():
     cnn.train()
     tr = DepthCompletionTrainer(cnn, 1e-4)
     B = args.batch
-    b = S.synthetic_batch(B, 240, 320, 1234, frame0=rank * B)
+    b = S.synthetic_batch(B, 240, 320, 1234, frame0=0 if args.same_data else rank * B)
     image = b["image"].to(dev)
     normal = torch.nn.functional.normalize(image - 0.5, dim=1)
     depth_in = b["sparse_depth"].to(dev)
     gt = S.synthetic_ground_truth_depth(b["image"], 1234).to(dev)
     losses = []
     for _ in range(args.warmup):
-        tr.step(image, normal, depth_in, gt)
+        losses.append(tr.step(image, normal, depth_in, gt))
+    warm = [round(float(x), 6) for x in losses]
+    losses = []
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -65,7 +69,7 @@ def main():
         print(json.dumps({"metric": "training frames/sec", "value": round(world * B * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
                           "batch_per_gpu": B, "ms_per_step": round(1e3 * dt / args.steps, 1), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 1), "dtype": {"fp32": "f32 (fp32 MFMA fwd / dgrad / wgrad)", "bf16x3": "f32+bf16x3 (split-bf16 3-pass MFMA fwd / dgrad / wgrad)",
                                     "bf16": "bf16 operands, fp32 accumulate (MFMA fwd / dgrad / wgrad); fp32 master weights, BatchNorm, loss, Adam"}[os.environ.get("VIDC_TRAIN_PRECISION", "fp32")],
-                          "losses": [round(float(x), 5) for x in losses],
+                          "losses": warm + [round(float(x), 6) for x in losses],
                           "config": "BASELINE configs[4]: ModifiedFPN training step (train-mode BN, masked L1 / (H*W), Adam), 320x240, synthetic"}))
     if world > 1:
         dist.destroy_process_group()

@@ -77,18 +77,32 @@ class GradientBuckets:
         self.ranges = [(a, min(n_elements, a + bucket_elements)) for a in range(0, n_elements, bucket_elements)]
 
     def all_reduce(self, flat):
+        for w in self.all_reduce_async(flat):
+            w()
+        return flat
+
+    def all_reduce_async(self, flat, lo=0, hi=None):
+        """Starts the SUM over ranks of flat[lo:hi], bucket by bucket, and returns the completion callbacks (call every one before the
+        data is used).  RCCL: the collectives run on the process group's own stream, after the work already enqueued on the current
+        stream, and overlap whatever is enqueued next -- the decoder's gradients travel while the pyramids' backward runs
+        (DepthCompletionTrainer.step).  gloo (trying the N > 1 path on a box without a second GPU): through the host, synchronous."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return flat
-        stage = dist.get_backend() == "gloo" and flat.is_cuda       # (gloo = trying the N > 1 path without RCCL: through the host)
+            return []
+        hi = flat.numel() if hi is None else hi
+        stage = dist.get_backend() == "gloo" and flat.is_cuda
+        waits = []
         for a, b in self.ranges:
+            a, b = max(a, lo), min(b, hi)
+            if a >= b:
+                continue
             if stage:
                 h = flat[a:b].cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM)
                 flat[a:b].copy_(h)
             else:
-                dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM)
-        return flat
+                waits.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, async_op=True).wait)
+        return waits
 
 
 class DepthCompletionTrainer:
@@ -118,6 +132,11 @@ class DepthCompletionTrainer:
             o += k_n
         self.buf = {k: b for k, b in cnn.named_buffers()}
         self.buckets = GradientBuckets(n)
+        # the decoder's parameters (feature*_upsamping, feature_concat) form the tail of the flat buffers (named_parameters order): their
+        # gradients are complete when the decoder's backward is, long before the pyramids' -- they are all-reduced while those still run
+        offs = {k: int((self.grad[k].data_ptr() - self.flat_g.data_ptr()) // 4) for k, _ in self.named}
+        dec = [offs[k] for k, _ in self.named if k.startswith("feature")]
+        self._dec_off = min(dec) if dec and all(k.startswith("feature") for k, _ in self.named if offs[k] >= min(dec)) else n
         self.step_count = 0
         self._ones, self._zeros, self._packed, self._scratch, self._nbt = {}, {}, {}, {}, []
         self._gemm_ws = {}          # split-K workspace per stream lane (lane 0 = the caller's stream)
@@ -507,6 +526,7 @@ class DepthCompletionTrainer:
                     subs[pi][l].grad = g if subs[pi][l].grad is None else subs[pi][l].grad
         # NB: appended BEFORE the decoder ops, so it runs after all of them in the reversed tape; a level's slice is also fed by the next
         # stage of its pyramid, whose backward (later in the reversed order) accumulates into the same slice.
+        split_level_grads._decoder_done = True       # everything recorded after this point (= run before it) is the decoder's backward
         self._record(split_level_grads)
 
         def branch(b):
@@ -566,7 +586,7 @@ class DepthCompletionTrainer:
         self.flush_counters()
         return pred
 
-    def loss_and_backward(self, pred, depth_gt):
+    def loss_and_backward(self, pred, depth_gt, stop_after_decoder=False):
         """network_run.py:163-173 + `total_loss.backward()`: fills the flat gradient buffer; returns the loss (0-dim fp64 GPU tensor)."""
         B, _, H, W = pred.shape
         n = pred.numel()
@@ -577,19 +597,29 @@ class DepthCompletionTrainer:
         sc = self._scratch_bytes((n // 512 + 64) * 8)
         L.check(L.lib().vidc_masked_l1_loss(L.ptr(pred), L.ptr(gt), n, H * W, L.ptr(loss), L.ptr(self._pred_grad), L.ptr(terms), L.ptr(sc), L.current_stream()),
                 "loss")
+        self._run_tape(stop_after_decoder)
+        return loss
+
+    def _run_tape(self, stop_after_decoder=False):
+        """Runs the recorded backward closures, last first, each on the stream lane it was recorded on.  stop_after_decoder: return once
+        the decoder's part is done (its last closure hands the level gradients to the pyramids), leaving the pyramids' closures in
+        self.tape for a second call -- the caller starts the all-reduce of the decoder's gradients in between."""
         main = torch.cuda.current_stream()
         forked = []
-        for fn in reversed(self.tape):
+        while self.tape:
+            fn = self.tape.pop()
             lane = getattr(fn, "_lane", 0)
             if lane == 0 or self.n_lanes <= 1:
-                for side in forked:                       # (does not happen in this network: the pyramids are the first ops recorded)
+                for side in forked:
                     main.wait_stream(side)
                 forked = []
                 fn()
+                if stop_after_decoder and getattr(fn, "_decoder_done", False):
+                    return
                 continue
             side = self._lane_streams()[lane - 1]
             if side not in forked:
-                side.wait_stream(main)                    # the decoder's backward produced this pyramid's level gradients
+                side.wait_stream(main)                    # the work recorded before this lane's (decoder backward / loss) is on main
                 forked.append(side)
             self._cur = lane
             with torch.cuda.stream(side):
@@ -597,8 +627,6 @@ class DepthCompletionTrainer:
             self._cur = 0
         for side in forked:
             main.wait_stream(side)
-        self.tape = []
-        return loss
 
     @torch.no_grad()
     def forward_backward(self, image, normal, depth_in, depth_gt):
@@ -612,47 +640,81 @@ class DepthCompletionTrainer:
         return loss, pred
 
     @torch.no_grad()
-    def optimizer_step(self):
-        """torch.optim.Adam.step over the flat buffers; gradients are summed over ranks first (frame-sharded batch)."""
-        self.buckets.all_reduce(self.flat_g)
+    def optimizer_step(self, reduced=False):
+        """torch.optim.Adam.step over the flat buffers; gradients are summed over ranks first (frame-sharded batch) unless `step` has
+        done that already, overlapped with the backward."""
+        if not reduced:
+            self.buckets.all_reduce(self.flat_g)
         self.step_count += 1
         L.check(L.lib().vidc_adam_step(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.m), L.ptr(self.v), self.flat_p.numel(), self.lr, self.betas[0],
                                        self.betas[1], self.eps, self.step_count, L.current_stream()), "adam")
         self._packed_fresh = False      # so are the trainer's own packed copies (re-made by the next forward's repack())
         self.cnn._invalidate()          # the inference programs' packed / BN-folded copies are stale now
 
+    def _distributed(self):
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
     def step(self, image, normal, depth_in, depth_gt):
         """One `_run_training_iteration`: returns the loss (0-dim fp64 GPU tensor, this rank's frames).
 
         The forward + backward of a step is ~4000 launches from Python (~17 us of host time each: host-bound once the convs run in the
-        bf16x3 mode), all with shape-static arguments, so from the third step of a given input shape on it is replayed as ONE captured
-        hipGraph (VIDC_TRAIN_GRAPH=0: always eager).  The all-reduce and the Adam launch (its bias correction takes the step number
-        by value) stay outside the graph."""
+        bf16 modes), all with shape-static arguments, so from the third step of a given input shape on it is replayed as captured
+        hipGraphs (VIDC_TRAIN_GRAPH=0: always eager).  The all-reduce and the Adam launch (its bias correction takes the step number
+        by value) stay outside the graphs.  Across ranks the backward is cut where the decoder's part ends: the all-reduce of the
+        decoder's gradients (59 % of the 1.24 GB) is started there and runs under the pyramids' backward, the rest follows."""
+        multi = self._distributed()
         if self.use_graph:
-            loss = self._graphed_forward_backward(image, normal, depth_in, depth_gt)
+            loss, waits = self._graphed_forward_backward(image, normal, depth_in, depth_gt, multi)
         else:
-            loss, _ = self.forward_backward(image, normal, depth_in, depth_gt)
-        self.optimizer_step()
+            loss, waits = self._eager_forward_backward(image, normal, depth_in, depth_gt, multi)
+        for w in waits:
+            w()
+        self.optimizer_step(reduced=multi)
         self.last_loss = loss
         return loss
 
-    def _graphed_forward_backward(self, image, normal, depth_in, depth_gt):
+    @torch.no_grad()
+    def _eager_forward_backward(self, image, normal, depth_in, depth_gt, multi):
+        if not multi:
+            return self.forward_backward(image, normal, depth_in, depth_gt)[0], []
+        pred = self.forward(image.float(), normal.float(), depth_in.float())
+        loss = self.loss_and_backward(pred, depth_gt, stop_after_decoder=True)
+        waits = self.buckets.all_reduce_async(self.flat_g, self._dec_off, None)
+        self._run_tape()
+        waits += self.buckets.all_reduce_async(self.flat_g, 0, self._dec_off)
+        return loss, waits
+
+    def _graphed_forward_backward(self, image, normal, depth_in, depth_gt, multi=False):
         ins = (image, normal, depth_in, depth_gt)
-        key = tuple((tuple(t.shape), t.dtype) for t in ins)
+        key = tuple((tuple(t.shape), t.dtype) for t in ins) + (multi,)
         ent = self._graphs.get(key)
         if ent is None:
             seen = self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
             if seen <= 2:                     # eager: creates the packed-weight table, constants, scratch and split-K workspace
-                return self.forward_backward(*ins)[0]
+                return self._eager_forward_backward(*ins, multi)
             static = [t.clone() for t in ins]
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
+            graph, rest = torch.cuda.CUDAGraph(), None
             with torch.cuda.graph(graph):
-                loss, pred = self.forward_backward(*static)
-            ent = self._graphs[key] = (graph, static, loss, pred)
-        graph, static, loss, pred = ent
+                if multi:
+                    pred = self.forward(static[0].float(), static[1].float(), static[2].float())
+                    loss = self.loss_and_backward(pred, static[3], stop_after_decoder=True)
+                else:
+                    loss, pred = self.forward_backward(*static)
+            if multi:                         # second graph: the pyramids' backward (same memory pool: it reads the first one's tensors)
+                rest = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(rest, pool=graph.pool()):
+                    self._run_tape()
+            ent = self._graphs[key] = (graph, rest, static, loss, pred)
+        graph, rest, static, loss, pred = ent
         for dst, src in zip(static, ins):
             dst.copy_(src)
         self._packed_fresh = True             # the graph starts with repack()
         graph.replay()
-        return loss.clone()
+        waits = []
+        if rest is not None:
+            waits = self.buckets.all_reduce_async(self.flat_g, self._dec_off, None)
+            rest.replay()
+            waits += self.buckets.all_reduce_async(self.flat_g, 0, self._dec_off)
+        return loss.clone(), waits
