@@ -263,6 +263,57 @@ class DepthCompletionPipeline:
             if out is not None:
                 yield out
 
+    @torch.no_grad()
+    def run_stream(self, batches, in_flight=2, frame_rng=None):
+        """Throughput mode: yields the depth map of every batch, in order, with up to `in_flight` frames executing
+        concurrently on separate HIP streams (frame i's depth network overlaps frame i+1's surface-normal network --
+        at batch 1 the 134 small layer-3 convolutions per network cannot fill 256 CUs on their own).
+
+        Same kernels and arithmetic as `_call_cnn`.  The RANSAC / enrichment draws of different frames interleave
+        differently on the shared `self.rng` than in back-to-back `_call_cnn` calls (frame i+1's hypotheses are drawn
+        before frame i's enrichment indices); pass `frame_rng(i) -> np.random.RandomState` to give every frame its own
+        generator, in which case the outputs are identical to sequential calls using the same per-frame generators."""
+        import collections
+        if not hasattr(self, "_slots") or len(self._slots) != in_flight:
+            self._slots = [{"stream": torch.cuda.Stream(device=self.device), "planes": PlaneBlock(), "state": None, "out": None,
+                            "done": torch.cuda.Event()} for _ in range(in_flight)]
+        main = torch.cuda.current_stream(self.device)
+        order = collections.deque()
+
+        def finish_stage2(sl, k):
+            with torch.cuda.stream(sl["stream"]):
+                sl["out"] = self._stage2(sl["state"], slot=k, planes=sl["planes"]).clone()
+                sl["done"].record(sl["stream"])
+            sl["state"] = None
+
+        for i, batch in enumerate(batches):
+            k = i % in_flight
+            sl = self._slots[k]
+            if sl["state"] is not None:
+                finish_stage2(sl, k)             # host waits here for frame i-in_flight's counts; the other slots keep the GPU busy
+            if sl["out"] is not None and len(order) >= in_flight:
+                j = order.popleft()
+                sj = self._slots[j]
+                sj["done"].synchronize()
+                out, sj["out"] = sj["out"], None
+                yield out
+            sl["stream"].wait_stream(main)
+            with torch.cuda.stream(sl["stream"]):
+                sl["state"] = self._stage1(batch, slot=k, planes=sl["planes"], rng=frame_rng(i) if frame_rng else None)
+            order.append(k)
+        # drain: RNG order must stay frame order, so finish the pending second stages oldest first
+        pending = list(order)
+        for j in pending:
+            if self._slots[j]["state"] is not None:
+                finish_stage2(self._slots[j], j)
+        while order:
+            j = order.popleft()
+            sj = self._slots[j]
+            sj["done"].synchronize()
+            out, sj["out"] = sj["out"], None
+            main.wait_stream(sj["stream"])
+            yield out
+
 
 class _Lane:
     """One software-pipelined frame stream of `DepthCompletionPipeline.run_interleaved`: its frame program (cached on the pipeline per
@@ -373,54 +424,3 @@ class _Lane:
             out = out.clone() if copy_outputs else out
         self.have_prev = batch is not None
         return out
-
-    @torch.no_grad()
-    def run_stream(self, batches, in_flight=2, frame_rng=None):
-        """Throughput mode: yields the depth map of every batch, in order, with up to `in_flight` frames executing
-        concurrently on separate HIP streams (frame i's depth network overlaps frame i+1's surface-normal network --
-        at batch 1 the 134 small layer-3 convolutions per network cannot fill 256 CUs on their own).
-
-        Same kernels and arithmetic as `_call_cnn`.  The RANSAC / enrichment draws of different frames interleave
-        differently on the shared `self.rng` than in back-to-back `_call_cnn` calls (frame i+1's hypotheses are drawn
-        before frame i's enrichment indices); pass `frame_rng(i) -> np.random.RandomState` to give every frame its own
-        generator, in which case the outputs are identical to sequential calls using the same per-frame generators."""
-        import collections
-        if not hasattr(self, "_slots") or len(self._slots) != in_flight:
-            self._slots = [{"stream": torch.cuda.Stream(device=self.device), "planes": PlaneBlock(), "state": None, "out": None,
-                            "done": torch.cuda.Event()} for _ in range(in_flight)]
-        main = torch.cuda.current_stream(self.device)
-        order = collections.deque()
-
-        def finish_stage2(sl, k):
-            with torch.cuda.stream(sl["stream"]):
-                sl["out"] = self._stage2(sl["state"], slot=k, planes=sl["planes"]).clone()
-                sl["done"].record(sl["stream"])
-            sl["state"] = None
-
-        for i, batch in enumerate(batches):
-            k = i % in_flight
-            sl = self._slots[k]
-            if sl["state"] is not None:
-                finish_stage2(sl, k)             # host waits here for frame i-in_flight's counts; the other slots keep the GPU busy
-            if sl["out"] is not None and len(order) >= in_flight:
-                j = order.popleft()
-                sj = self._slots[j]
-                sj["done"].synchronize()
-                out, sj["out"] = sj["out"], None
-                yield out
-            sl["stream"].wait_stream(main)
-            with torch.cuda.stream(sl["stream"]):
-                sl["state"] = self._stage1(batch, slot=k, planes=sl["planes"], rng=frame_rng(i) if frame_rng else None)
-            order.append(k)
-        # drain: RNG order must stay frame order, so finish the pending second stages oldest first
-        pending = list(order)
-        for j in pending:
-            if self._slots[j]["state"] is not None:
-                finish_stage2(self._slots[j], j)
-        while order:
-            j = order.popleft()
-            sj = self._slots[j]
-            sj["done"].synchronize()
-            out, sj["out"] = sj["out"], None
-            main.wait_stream(sj["stream"])
-            yield out
