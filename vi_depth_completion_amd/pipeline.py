@@ -216,7 +216,9 @@ class DepthCompletionPipeline:
         holes (+9 % frames/s with two lanes at 320x256, batch 1; more lanes add nothing: workgroups reserve 64-128 KB of LDS, so a
         CU rarely holds two).  Ticks are issued strictly in frame order from this one host thread, so the random draws come off
         `self.rng` exactly as with one lane and every frame's result is bit-identical to the single-lane stream's (tested).
-        Outputs are still yielded in frame order, a lane's one round (L requests) later than with one lane; the caller's current
+        The host's one wait per frame (for its enrichment candidate counts) is deferred to the next visit, after that visit's segment
+        has been launched, so the GPU never idles under it.  Outputs are still yielded in frame order, a lane's one round (L requests)
+        later than with one lane; the caller's current
         stream waits (on the device) for the tick that produced one.
 
         Data movement per tick: the frame is copied into the program's input buffer once (and from there to the depth
@@ -245,13 +247,25 @@ class DepthCompletionPipeline:
         # issued a whole round ago and has mostly run), never right after its own tick -- a wait for the tick just issued, sitting on
         # the caller's stream, would make the next lane (which must wait for the caller's stream: its inputs come from there) wait for
         # it too and serialise the lanes.
+        # The one host synchronisation of a frame -- reading its enrichment candidate counts -- is also DEFERRED by one visit: frame i's
+        # surface-normal segment is launched in visit i, its counts are awaited in visit i+1 AFTER frame i+1's surface-normal segment
+        # has been launched (on the other lane), so the GPU always has a segment queued while the host waits.  The draws keep their
+        # order -- hypotheses(i), enrichment(i), hypotheses(i+1), ... -- because enrichment(i) is drawn before hypotheses(i+1) in that
+        # visit; the enrichment kernel only has to precede frame i+L's segment on its own lane, which is launched L - 1 visits later.
+        waiting = None                          # the lane whose last frame still needs its enrichment
         for batch in batches:
             lane = lane_objs[k % n]
             k += 1
             out = lane.collect()
             if out is not None:
                 yield out
-            lane.launch(batch, copy_outputs)
+            lane.phase_a(batch)
+            if waiting is not None:
+                waiting.finish_enrich()
+            lane.phase_b(copy_outputs)
+            waiting = lane if lane.pending_enrich is not None else None
+        if waiting is not None:
+            waiting.finish_enrich()
         for j in range(n):                      # drain ticks, oldest pending frame first
             lane = lane_objs[(k + j) % n]
             out = lane.collect()
@@ -321,7 +335,7 @@ class _Lane:
 
     def __init__(self, pipe, index, own_stream):
         self.pipe, self.index = pipe, index
-        self.prog, self.shape0, self.have_prev, self.pending_out = None, None, False, None
+        self.prog, self.shape0, self.have_prev, self.pending_out, self.pending_enrich, self._frame = None, None, False, None, None, None
         cache = pipe.__dict__.setdefault("_lane_cache", {})
         ent = cache.setdefault(index, {})
         self.cache = ent
@@ -343,14 +357,96 @@ class _Lane:
         return self.cache["prog"]
 
     def launch(self, batch, copy_outputs):
-        """(lanes > 1) one tick on this lane's stream; the output it computes, if any, is kept for `collect`."""
+        """(lanes > 1) one whole tick on this lane's stream (the drain ticks); the output it computes, if any, is kept for `collect`."""
         self.stream.wait_stream(torch.cuda.current_stream())      # the batch comes from the caller's stream, and whoever read the
         with torch.cuda.stream(self.stream):                      # previous output out of the program's buffer did so there
-            out = self._tick(batch, copy_outputs)
-            if out is not None:
-                ev = torch.cuda.Event()
-                ev.record()
-                self.pending_out = (out, ev)
+            self._keep_output(self._tick(batch, copy_outputs))
+
+    def _keep_output(self, out):
+        if out is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.pending_out = (out, ev)
+
+    def phase_a(self, batch):
+        """(lanes > 1) first half of a tick: the frame into the program's inputs and segment 0 (all four pyramids + the surface-normal
+        decoder) launched.  Nothing here draws random numbers or waits for the device."""
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            pipe, dev = self.pipe, self.pipe.device
+            rgb = batch["image"].to(dev, non_blocking=True)
+            ds = batch["sparse_depth"].to(dev, non_blocking=True)
+            self._prepare(rgb)
+            prog = self.prog
+            if self.have_prev:
+                self.dc_image.copy_(self.sn_image, non_blocking=True)
+            mh = pipe._masks_begin(rgb) if pipe.args.enriched_samples != 0 else None
+            self.sn_image.copy_(rgb, non_blocking=True)
+            self.grav.copy_(batch["gravity"].to(dev).reshape(-1), non_blocking=True)
+            self.algn.copy_(batch["aligned_direction"].to(dev).reshape(-1), non_blocking=True)
+            prog.launch_segment(0) if prog.captured else prog.run_segment(0)
+            self._frame = (batch, rgb, ds, mh)
+
+    def phase_b(self, copy_outputs):
+        """Second half: hypothesis draws + plane kernels of the frame, the asynchronous read of its candidate counts, then segment 1
+        (the depth decoder of the lane's previous frame).  The enrichment itself waits for `finish_enrich`."""
+        with torch.cuda.stream(self.stream):
+            pipe, prog = self.pipe, self.prog
+            batch, rgb, ds, mh = self._frame
+            self._frame = None
+            _, _, H, W = rgb.shape
+            if pipe.args.enriched_samples != 0:
+                normals = prog.tensor(prog.outputs["normals"])
+                homo = batch["homogeneous_coordinates"].to(pipe.device, non_blocking=True)
+                masks = pipe._masks_end(mh, batch["image"], H, W)
+                di, info = self.planes.plane_depth(normals, masks, ds, homo, rng=pipe.rng)
+                self.pending_enrich = (ds, di, info, self.planes.read_info_async(info))
+            else:
+                self.dc_depth.copy_(ds, non_blocking=True)
+            out = None
+            if self.have_prev:
+                prog.launch_segment(1) if prog.captured else prog.run_segment(1)
+                out = prog.tensor(prog.outputs["depth"])
+                out = out.clone() if copy_outputs else out
+            self.have_prev = True
+            self._keep_output(out)
+
+    def finish_enrich(self):
+        """Waits for the frame's candidate counts, draws its enrichment samples and writes the enriched depth where the lane's next
+        segment 0 reads it."""
+        if self.pending_enrich is None:
+            return
+        ds, di, info, info_host = self.pending_enrich
+        self.pending_enrich = None
+        with torch.cuda.stream(self.stream):
+            self.planes.enrich(ds, di, info, self.pipe.args.enriched_samples, rng=self.pipe.rng, info_host=info_host, out=self.dc_depth)
+
+    def _prepare(self, rgb):
+        """Builds / captures the lane's frame program at the first frame, checks the shape afterwards."""
+        import os
+        pipe = self.pipe
+        B, _, H, W = rgb.shape
+        if self.prog is not None:
+            if (B, H, W) != self.shape0:
+                raise ValueError("run_interleaved: all batches of a stream must have the same shape (got %s after %s); "
+                                 "start a new stream for the remainder" % ((B, H, W), self.shape0))
+            return
+        self.shape0 = (B, H, W)
+        prog = self.prog = self._program(B, H, W)
+        pipe.surface_normal_cnn._check(rgb)
+        pipe.cnn._check(rgb)
+        if not prog.captured and os.environ.get("VIDC_EXEC", "graph") == "graph":
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                prog.run()            # warm-up outside capture (sets kernel attributes)
+                prog.check_chains()
+                prog.capture_segments()
+            torch.cuda.current_stream().wait_stream(side)
+        self.sn_image, self.dc_image = prog.tensor(prog.inputs["sn_image"]), prog.tensor(prog.inputs["dc_image"])
+        self.dc_depth = prog.tensor(prog.inputs["dc_depth"])
+        self.grav = prog.storage[prog.inputs["gravity"].buf][: B * 3]
+        self.algn = prog.storage[prog.inputs["aligned"].buf][: B * 3]
 
     def collect(self):
         if self.pending_out is None:
@@ -368,26 +464,7 @@ class _Lane:
             rgb = batch["image"].to(dev, non_blocking=True)
             ds = batch["sparse_depth"].to(dev, non_blocking=True)
             B, _, H, W = rgb.shape
-            if self.prog is not None and (B, H, W) != self.shape0:
-                raise ValueError("run_interleaved: all batches of a stream must have the same shape (got %s after %s); "
-                                 "start a new stream for the remainder" % ((B, H, W), self.shape0))
-            if self.prog is None:
-                self.shape0 = (B, H, W)
-                prog = self.prog = self._program(B, H, W)
-                pipe.surface_normal_cnn._check(rgb)
-                pipe.cnn._check(rgb)
-                if not prog.captured and os.environ.get("VIDC_EXEC", "graph") == "graph":
-                    side = torch.cuda.Stream()
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        prog.run()            # warm-up outside capture (sets kernel attributes)
-                        prog.check_chains()
-                        prog.capture_segments()
-                    torch.cuda.current_stream().wait_stream(side)
-                self.sn_image, self.dc_image = prog.tensor(prog.inputs["sn_image"]), prog.tensor(prog.inputs["dc_image"])
-                self.dc_depth = prog.tensor(prog.inputs["dc_depth"])
-                self.grav = prog.storage[prog.inputs["gravity"].buf][: B * 3]
-                self.algn = prog.storage[prog.inputs["aligned"].buf][: B * 3]
+            self._prepare(rgb)
         elif self.prog is None or not self.have_prev:
             return None
         prog = self.prog
