@@ -439,6 +439,11 @@ int vidc_adam_step(float* p, const float* g, float* m, float* v, long long n, fl
 /* dgrad: the gradient w.r.t. a conv's input is vidc_conv2d_bn_act of dY (stride 1, pad KH-1-pad) with these weights
  * ([Cin][Cout/32][KH][KW][32], kernel flipped); a stride-s conv first spreads dY over the input grid with vidc_zero_stuff. */
 int vidc_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, vidc_stream_t stream);
+/* HOST function (no device work): numpy.random.RandomState.permutation(n)[0:k] replayed on the generator's own MT19937 state (key624 =
+ * get_state()[1], *pos = get_state()[2]), advancing it exactly as numpy does -- the n - 1 bounded draws of the Fisher-Yates shuffle.  The
+ * reference draws its RANSAC hypotheses this way per plane (main.py:43, :78); this is its largest item of host time per frame.  idx_out: k
+ * int32, scratch: n int32.  n < 2^31. */
+int vidc_host_mt19937_permutation_prefix(uint32_t* key624, int32_t* pos, long long n, int k, int32_t* idx_out, int32_t* scratch);
 /* All conv weights of a network re-packed by one launch (they move every optimizer step).  `items_device`: n_items descriptors in
  * device memory, sorted by block_begin; item i owns the vidc_pack_item_blocks(...) workgroups from block_begin_i on (0 = unsupported
  * shape: kernels up to 3x3, the K-side channel count a multiple of the unit); total_blocks = their sum.  kind: 0 forward fp32

@@ -255,3 +255,35 @@ def test_program_buffer_reuse_is_safe(recorded_programs, recorded_frame_program)
         others = {st[b].data_ptr() for b in range(len(st)) if b not in prog.pinned and st[b] is not None}
         assert not (set(pinned) & others)
         assert prog.bytes_allocated < 600e6
+
+
+def test_native_permutation_replays_numpy_legacy_stream():
+    """vidc_host_mt19937_permutation_prefix (csrc/host_rng.hip) against numpy itself: RandomState.permutation(n)[0:300] draw by draw,
+    the generator state afterwards word by word, and the next draw -- for sizes on both sides of the 624-word refill of the MT19937
+    state and of the 300-hypothesis cut, from a fresh and from a used generator; np.random (the module) works the same way."""
+    from vi_depth_completion_amd import plane
+    for seed in (0, 5, 11):
+        for n in (0, 1, 2, 3, 17, 299, 300, 301, 623, 624, 625, 1000, 4097, 38400):
+            a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+            a.random_sample(seed * 7), b.random_sample(seed * 7)
+            want = a.permutation(np.r_[0:n])[0:min(300, n)]
+            st = plane._LegacyStream.open(b)
+            got = st.permutation_prefix(n, 300)
+            st.commit()
+            assert got.dtype == np.int32 and np.array_equal(want, got), (seed, n)
+            sa, sb = a.get_state(), b.get_state()
+            assert sa[2] == sb[2] and np.array_equal(sa[1], sb[1]), (seed, n)
+            assert a.randint(0, 1 << 30) == b.randint(0, 1 << 30)
+    saved = np.random.get_state()
+    try:
+        np.random.seed(3)
+        want = np.random.permutation(np.r_[0:700])[0:300]
+        np.random.seed(3)
+        st = plane._LegacyStream.open(np.random)
+        assert np.array_equal(st.permutation_prefix(700, 300), want)
+    finally:
+        np.random.set_state(saved)
+    assert plane._LegacyStream.open(np.random.default_rng(0)) is None       # not the legacy generator: draw_normal_hypotheses falls back
+    lib = L.lib()
+    assert lib.vidc_host_mt19937_permutation_prefix(None, None, 4, 2, None, None) != 0
+

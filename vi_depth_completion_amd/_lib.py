@@ -95,6 +95,7 @@ SIGNATURES = {
     "vidc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, _f, _f, _f, _f, _i, _vp]),
     "vidc_pack_conv_weight_dgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vidc_cast_bf16": (C.c_int, [_vp, _vp, C.c_longlong, _i, _i, _vp]),
+    "vidc_host_mt19937_permutation_prefix": (C.c_int, [_vp, _vp, C.c_longlong, _i, _vp, _vp]),
     "vidc_pack_item_blocks": (C.c_longlong, [_i, _i, _i, _i, _i]),
     "vidc_pack_conv_weights_batched": (C.c_int, [_vp, _i, C.c_longlong, _vp]),
     "vidc_zero_stuff": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -6,6 +6,8 @@ the numpy legacy RNG draws (np.random.permutation / np.random.randint, in the re
 maps, which arrive as numpy arrays from the plane detector (predictor.py:143-150) -- and hands index arrays to the
 device.  Everything else (RANSAC, offset, projection, override, scatter) is one launch per stage for the whole batch.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -14,38 +16,81 @@ from . import _lib as L
 NUM_HYPOTHESES = 300   # main.py:38,68
 
 
-def draw_normal_hypotheses(id_maps, rng=np.random, dense=None):
+class _LegacyStream:
+    """numpy's legacy MT19937 stream of `rng` (np.random itself or a RandomState) opened for native replay: permutation prefixes are
+    drawn by vidc_host_mt19937_permutation_prefix on a copy of the state, `commit()` writes the advanced state back.  None when `rng`
+    is something else (a Generator, a stub): the caller then uses rng.permutation."""
+
+    @staticmethod
+    def open(rng):
+        try:
+            st = rng.get_state()
+        except (AttributeError, TypeError):
+            return None
+        if not isinstance(st, tuple) or st[0] != "MT19937":
+            return None
+        s = _LegacyStream()
+        s.rng, s.key, s.pos, s.tail = rng, np.ascontiguousarray(st[1], dtype=np.uint32).copy(), C.c_int32(int(st[2])), st[3:]
+        s.scratch = None
+        return s
+
+    def permutation_prefix(self, n, k):
+        k = min(k, n)
+        out = np.empty(k, dtype=np.int32)
+        if self.scratch is None or self.scratch.shape[0] < n:
+            self.scratch = np.empty(max(n, 1), dtype=np.int32)
+        L.check(L.lib().vidc_host_mt19937_permutation_prefix(self.key.ctypes.data, C.addressof(self.pos), n, k, out.ctypes.data, self.scratch.ctypes.data),
+                "permutation_prefix")
+        return out
+
+    def commit(self):
+        self.rng.set_state(("MT19937", self.key, int(self.pos.value)) + tuple(self.tail))
+
+
+def plane_groups(id_map):
+    """Pixels of an id map grouped by plane: (classes > 0 ascending, like torch.unique; for each the flat pixel indices ascending, like
+    np.flatnonzero(flat == cls)).  One stable sort instead of one pass over the map per plane."""
+    flat = np.asarray(id_map).reshape(-1)
+    if flat.dtype != np.uint8:
+        flat = flat.astype(np.int64)
+    counts = np.bincount(flat)
+    if counts.shape[0] == 1:
+        return []                          # only background: the reference returns its inputs unchanged (main.py:135-137)
+    order = np.argsort(flat, kind="stable")
+    starts = np.concatenate(([0], np.cumsum(counts)))
+    return [(int(cls), order[starts[cls]:starts[cls + 1]]) for cls in np.flatnonzero(counts) if cls != 0]
+
+
+def draw_normal_hypotheses(id_maps, rng=np.random, dense=None, groups=None):
     """For every image and every plane id > 0 (ascending, like torch.unique), draw the hypothesis rows exactly as
     mean_normal_ranasc does (main.py:43) and convert them to flat pixel indices.
     `dense`: {slot index: n_pts} -- planes known (from a first device pass) to be accepted with n_pts > 300 sparse points on
     them: plane_offset_ransac then draws np.random.permutation(np.r_[0:n_pts])[0:300] (main.py:78) right after the plane's normal
     hypotheses and before the next plane's, which is where it is drawn here.
+    `groups`: plane_groups() of every map, if the caller has them already (unchanged id maps: PlaneBlock keeps them).
+    The permutations run natively on the generator's MT19937 state when `rng` is numpy's legacy generator (same draws, same state
+    afterwards: tests/test_abi.py), through rng.permutation otherwise.
     Returns (slots int32 [n,4] = (b, cls, hyp_offset, n_hyp), hyp_pix int32, {slot index: offset hypothesis ranks int32 [300]})."""
     slots, hyp, dense_hyp = [], [], {}
     off = 0
+    stream = _LegacyStream.open(rng)
+
+    def prefix(n):
+        if stream is not None:
+            return stream.permutation_prefix(n, NUM_HYPOTHESES)
+        return rng.permutation(np.r_[0:n])[0:min(NUM_HYPOTHESES, n)]
+
     for b, m in enumerate(id_maps):
-        flat = np.asarray(m).reshape(-1)
-        if flat.dtype != np.uint8:
-            flat = flat.astype(np.int64)
-        counts = np.bincount(flat)
-        if counts.shape[0] == 1:
-            continue                      # only background: the reference returns its inputs unchanged (main.py:135-137)
-        # one stable sort groups the pixels by plane id with ascending pixel index inside every plane (= np.flatnonzero(flat == cls)
-        # for every cls, without one pass over the map per plane: the detector finds 5-9 planes per image)
-        order = np.argsort(flat, kind="stable")
-        starts = np.concatenate(([0], np.cumsum(counts)))
-        for cls in np.flatnonzero(counts):
-            if cls == 0:
-                continue
-            pix = order[starts[cls]:starts[cls + 1]]
-            n = pix.shape[0]
-            idx = rng.permutation(np.r_[0:n])[0:min(NUM_HYPOTHESES, n)]
+        for cls, pix in (groups[b] if groups is not None else plane_groups(m)):
+            idx = prefix(pix.shape[0])
             hyp.append(pix[idx].astype(np.int32))
             k = len(slots)
-            slots.append((b, int(cls), off, len(idx)))
+            slots.append((b, cls, off, len(idx)))
             off += len(idx)
             if dense and k in dense:
-                dense_hyp[k] = rng.permutation(np.r_[0:dense[k]])[0:NUM_HYPOTHESES].astype(np.int32)
+                dense_hyp[k] = prefix(dense[k]).astype(np.int32)
+    if stream is not None:
+        stream.commit()
     slots = np.asarray(slots, dtype=np.int32).reshape(-1, 4)
     hyp = np.concatenate(hyp).astype(np.int32) if hyp else np.zeros(0, dtype=np.int32)
     return slots, hyp, dense_hyp
@@ -98,10 +143,20 @@ class PlaneBlock:
 
     def __init__(self):
         self._ids_dev = self._ids_host = self._ids_event = None
+        self._groups = self._groups_src = None
         self.last_records = None
         self._bufs = {}
         self._up1, self._up2 = _Upload(), _Upload()
         self._ctx = None
+
+    def _groups_of(self, id_maps):
+        """plane_groups() of the batch's id maps, recomputed only when their content changed (a fixed mask or a static scene)."""
+        arr = np.stack([np.asarray(m, dtype=np.uint8) for m in id_maps]) if all(np.asarray(m).dtype == np.uint8 for m in id_maps) else None
+        if arr is None:
+            return [plane_groups(m) for m in id_maps]
+        if self._groups is None or self._groups_src.shape != arr.shape or not np.array_equal(self._groups_src, arr):
+            self._groups_src, self._groups = arr, [plane_groups(m) for m in arr]
+        return self._groups
 
     def _upload_ids(self, id_maps, device):
         """The (B,H,W) uint8 id maps on the device.  Uploaded only when their CONTENT changed since the last batch (a fixed plane mask, or
@@ -157,7 +212,7 @@ class PlaneBlock:
         HW = H * W
         dev = normals.device
         ds = ctx["ds"].view(B, HW)
-        slots, hyp, dense_hyp = draw_normal_hypotheses(ctx["ids"], rng, ctx["dense"])
+        slots, hyp, dense_hyp = draw_normal_hypotheses(ctx["ids"], rng, ctx["dense"], groups=self._groups_of(ctx["ids"]))
         n_slots = slots.shape[0]
         bufs = self._buffers(dev, B, HW, n_slots)
         di = bufs["di"]
