@@ -103,6 +103,26 @@ def test_config2_640x480_batch8_with_plane_head(pipe, detector, detector_weights
         pipe.plane_masks_extraction = saved
 
 
+def test_two_lanes_with_the_plane_head_are_bit_identical(pipe, detector):
+    """The mode `bench.py --plane-head` times: `run_interleaved(lanes=2)` with the Mask R-CNN plane head in the loop (its id maps travel
+    device -> host -> plane block every frame, through a staging buffer the lanes share) and the enrichment wait of a frame deferred to
+    the next visit.  Six batch-2 frames: every depth map bit-identical to the one-lane stream's."""
+    frames = [_to_dev(S.synthetic_batch(2, 240, 320, 1234, frame0=200 + 2 * i)) for i in range(6)]
+    saved = pipe.plane_masks_extraction
+    try:
+        pipe.plane_masks_extraction = detector
+        runs = []
+        for lanes in (1, 2):
+            pipe.rng = np.random.RandomState(17)
+            runs.append([o.cpu() for o in pipe.run_interleaved(iter(frames), lanes=lanes)])
+        assert len(runs[0]) == len(runs[1]) == 6
+        for f, (a, b) in enumerate(zip(*runs)):
+            assert torch.equal(a, b), "frame %d differs between one and two lanes" % f
+        assert not torch.equal(runs[0][0], runs[0][1])
+    finally:
+        pipe.plane_masks_extraction = saved
+
+
 def test_config3_1280x720_share_of_one_gpu(pipe, seeded_weights):
     """configs[3]: 1280x720 stream, global batch 32 = 4 per GPU x 8.  Rank 5 of 8 takes global batches 5 and 13 (frames round-robin by
     batch, bench.py): uint8 1280x720 -> device-side pre-processing -> batch 4 -> the pipeline (plane mask fixed, like the bench line
