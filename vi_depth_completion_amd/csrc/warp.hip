@@ -125,13 +125,25 @@ __device__ inline float sample(const float* __restrict__ plane, const Taps& t) {
     return fmaf(plane[t.o11], t.w11, fmaf(plane[t.o10], t.w10, fmaf(plane[t.o01], t.w01, plane[t.o00] * t.w00)));
 }
 
+// Workgroups go to the 8 XCDs (8 private L2s) round-robin in linear launch order; a block of 256 consecutive output pixels gathers from
+// source rows that its neighbours need too.  XCD k therefore takes the k-th contiguous band of the (image, pixel block) space instead of
+// every eighth block (gridDim.x is a multiple of 8, host side): rocprofv3 FETCH_SIZE was 3.7x the input with the round-robin order.
+__device__ __forceinline__ void xcd_band_block(unsigned& bx, unsigned& by) {
+    const unsigned gx = gridDim.x, L = blockIdx.y * gx + blockIdx.x, per = (gx >> 3) * gridDim.y;
+    const unsigned idx = (L & 7u) * per + (L >> 3);
+    by = idx / gx;
+    bx = idx - by * gx;
+}
+
 // One thread per output pixel (lanes run along X, so the NCHW stores are fully coalesced and the
 // gathers of neighbouring lanes hit neighbouring source pixels); all C channels reuse one tap set.
 __global__ void __launch_bounds__(256)
 warp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ params, float* __restrict__ y, int C, int H, int W,
                 float cx, float cy, int align_corners) {
-    const int b = blockIdx.y;
-    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned bx, by;
+    xcd_band_block(bx, by);
+    const int b = (int)by;
+    const int pix = (int)(bx * blockDim.x + threadIdx.x);
     if (pix >= H * W) return;
     const int Y = pix / W, X = pix - Y * W;
     const float* p = params + (size_t)b * VIDC_WARP_PARAMS;
@@ -155,8 +167,10 @@ warp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ params, f
 __global__ void __launch_bounds__(256)
 warp_inv_rot_norm_kernel(const float* __restrict__ x, const float* __restrict__ params, float* __restrict__ z, int H, int W,
                          float cx, float cy, int align_corners, int normalize) {
-    const int b = blockIdx.y;
-    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned bx, by;
+    xcd_band_block(bx, by);
+    const int b = (int)by;
+    const int pix = (int)(bx * blockDim.x + threadIdx.x);
     if (pix >= H * W) return;
     const int Y = pix / W, X = pix - Y * W;
     const float* p = params + (size_t)b * VIDC_WARP_PARAMS;
@@ -202,7 +216,7 @@ extern "C" int vidc_warp2dof_fwd(const float* x, const float* params, float* y, 
                                  int align_corners, vidc_stream_t stream) {
     VIDC_REQUIRE(x && params && y, VIDC_ERR_NULL, "vidc_warp2dof_fwd: null pointer");
     VIDC_REQUIRE(B > 0 && C > 0 && H > 1 && W > 1, VIDC_ERR_SHAPE, "vidc_warp2dof_fwd: bad shape");
-    hipLaunchKernelGGL(warp_fwd_kernel, dim3(vidc::cdiv(H * W, 256), B), dim3(256), 0, vidc::as_stream(stream), x, params, y, C,
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3((vidc::cdiv(H * W, 256) + 7) / 8 * 8, B), dim3(256), 0, vidc::as_stream(stream), x, params, y, C,
                        H, W, cx, cy, align_corners);
     VIDC_CHECK_LAUNCH("warp_fwd_kernel");
     return VIDC_OK;
@@ -212,7 +226,7 @@ extern "C" int vidc_warp2dof_inv_rot_norm(const float* x, const float* params, f
                                           float cy, int align_corners, int normalize, vidc_stream_t stream) {
     VIDC_REQUIRE(x && params && z, VIDC_ERR_NULL, "vidc_warp2dof_inv_rot_norm: null pointer");
     VIDC_REQUIRE(B > 0 && H > 1 && W > 1, VIDC_ERR_SHAPE, "vidc_warp2dof_inv_rot_norm: bad shape");
-    hipLaunchKernelGGL(warp_inv_rot_norm_kernel, dim3(vidc::cdiv(H * W, 256), B), dim3(256), 0, vidc::as_stream(stream), x,
+    hipLaunchKernelGGL(warp_inv_rot_norm_kernel, dim3((vidc::cdiv(H * W, 256) + 7) / 8 * 8, B), dim3(256), 0, vidc::as_stream(stream), x,
                        params, z, H, W, cx, cy, align_corners, normalize);
     VIDC_CHECK_LAUNCH("warp_inv_rot_norm_kernel");
     return VIDC_OK;
