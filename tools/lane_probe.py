@@ -1,7 +1,19 @@
-import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
-import bench
-from vi_depth_completion_amd import synthetic as S
+"""Frames/s of pipeline.run_interleaved at 320x256, batch 1, with (enriched_samples=200) and without (0) the plane block / enrichment,
+for one and two lanes: the probe that showed the host's wait for the enrichment counts -- not the GPU -- to bound the two-lane mode
+(489 vs 617 frames/s) before that wait was deferred.
+
+    python tools/lane_probe.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from vi_depth_completion_amd import synthetic as S  # noqa: E402
 torch.set_grad_enabled(False)
 dev = torch.device("cuda")
 H, W = 256, 320
