@@ -27,10 +27,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--top", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--iters", type=int, default=24)
     ap.add_argument("--budget-s", type=float, default=1500.0)
     a = ap.parse_args()
-    H, W, B = a.height, 320, 1
+    H, W, B = a.height, 320, a.batch
     dev = torch.device("cuda")
     cc = (0.5 * 319.87654, 0.5 * 239.87603 * H / 240.0)
     pipe = DepthCompletionPipeline(enriched_samples=200, cc_img=cc, device=dev)

@@ -84,6 +84,13 @@ class FramePreprocessor:
                                                        L.ptr(self.by), L.ptr(self.ky), self.ksy, L.current_stream()), "resize")
         return y
 
+    def _upload(self, t):
+        """Small host tensor -> fresh device tensor through (cached) pinned memory: a copy out of pageable memory would block the host
+        until the device has caught up with everything queued before it -- a whole tick of the stream being pre-processed for."""
+        p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        p.copy_(t)
+        return p.to(self.device, non_blocking=True)
+
     def rasterize(self, klt_tracks):
         """list of B arrays (N_i, 4) = (id, X, Y, Z) -> (B,1,Ho,Wo) float32 sparse depth."""
         B = len(klt_tracks)
@@ -92,8 +99,8 @@ class FramePreprocessor:
         offs = np.zeros(B + 1, np.int32)
         offs[1:] = np.cumsum([r.shape[0] for r in rows])
         allr = np.concatenate(rows) if offs[-1] else np.zeros((1, 4))
-        tr = torch.from_numpy(np.ascontiguousarray(allr)).to(self.device)
-        of = torch.from_numpy(offs).to(self.device)
+        tr = self._upload(torch.from_numpy(np.ascontiguousarray(allr)))
+        of = self._upload(torch.from_numpy(offs))
         d = torch.empty((B, 1, Ho, Wo), dtype=torch.float32, device=self.device)
         L.check(L.lib().vidc_rasterize_sparse_depth(L.ptr(tr), L.ptr(of), B, self.fc[0], self.fc[1], self.cc[0], self.cc[1], L.ptr(d), Ho, Wo,
                                                     L.current_stream()), "rasterize")
@@ -107,5 +114,5 @@ class FramePreprocessor:
         B = img.shape[0]
         ga = [gravity_and_alignment(g) for g in np.asarray(gravity_raw, dtype=np.float64).reshape(B, 3)]
         return {"image": self.resize(img), "sparse_depth": self.rasterize(klt_tracks),
-                "gravity": torch.stack([g for g, _ in ga]).to(self.device), "aligned_direction": torch.stack([a for _, a in ga]).to(self.device),
+                "gravity": self._upload(torch.stack([g for g, _ in ga])), "aligned_direction": self._upload(torch.stack([a for _, a in ga])),
                 "homogeneous_coordinates": self.homogeneous.unsqueeze(0).expand(B, -1, -1, -1)}
