@@ -780,6 +780,12 @@ def test_run_interleaved_lanes_are_bit_identical(pipeline):
             else:
                 for f, (a, b) in enumerate(zip(ref, outs)):
                     assert torch.equal(a, b), "frame %d differs with %d lanes" % (f, lanes)
+        # host-resident batches (what the reference's DataLoader hands out) go up through pinned memory: same results
+        pipeline.rng = np.random.RandomState(99)
+        host_frames = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in f.items()} for f in frames]
+        outs = [o.cpu() for o in pipeline.run_interleaved(iter(host_frames), lanes=2)]
+        for f, (a, b) in enumerate(zip(ref, outs)):
+            assert torch.equal(a, b), "frame %d differs for host-resident batches" % f
         pipeline.rng = np.random.RandomState(99)
         short = [o.cpu() for o in pipeline.run_interleaved(iter(frames[:2]), lanes=3, copy_outputs=True)]
         assert len(short) == 2 and torch.equal(short[0], ref[0]) and torch.equal(short[1], ref[1])

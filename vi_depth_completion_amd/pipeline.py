@@ -15,6 +15,17 @@ from .networks.surface_normal import SurfaceNormalPrediction
 from .plane import PlaneBlock
 
 
+def _dev(t, dev):
+    """A batch tensor on the device.  Host tensors (the reference's DataLoader hands out CPU batches) go through cached pinned memory
+    with an asynchronous copy: a copy out of pageable memory blocks the host until the device has caught up with everything queued
+    before it, i.e. a whole tick in the stream modes."""
+    if t.is_cuda:
+        return t
+    p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    p.copy_(t)
+    return p.to(dev, non_blocking=True)
+
+
 class FixedPlaneMask:
     """Plane-mask provider for the perf configuration ("plane mask fixed", BASELINE.json configs[1]); has the
     `run_on_tensor(image) -> uint8 (H,W) id map` interface of COCODemo (plane_mask_detection/demo/predictor.py:143-150)."""
@@ -149,17 +160,17 @@ class DepthCompletionPipeline:
         """warp + surface-normal net + plane block, enqueued on the current stream (main.py:262-283)."""
         dev = self.device
         planes = planes or self.planes
-        ds = input_batch["sparse_depth"].to(dev, non_blocking=True)
-        rgb = input_batch["image"].to(dev, non_blocking=True)
+        ds = _dev(input_batch["sparse_depth"], dev)
+        rgb = _dev(input_batch["image"], dev)
         mh = self._masks_begin(rgb) if self.args.enriched_samples != 0 else None      # the id maps travel to the host under the normal net
         if self.use_gravity:
-            normals = self.surface_normal_cnn.enqueue(rgb, input_batch["gravity"].to(dev), input_batch["aligned_direction"].to(dev), slot)
+            normals = self.surface_normal_cnn.enqueue(rgb, _dev(input_batch["gravity"], dev), _dev(input_batch["aligned_direction"], dev), slot)
         else:
             normals = self.surface_normal_cnn(rgb)                                                           # main.py:270-271
         rng = rng if rng is not None else self.rng
         st = {"ds": ds, "rgb": rgb, "normals": normals, "di": None, "nnz": None, "rng": rng}
         if self.args.enriched_samples != 0:
-            homo = input_batch["homogeneous_coordinates"].to(dev, non_blocking=True)
+            homo = _dev(input_batch["homogeneous_coordinates"], dev)
             masks = self._masks_end(mh, input_batch["image"], ds.shape[-2], ds.shape[-1])
             st["di"], st["nnz"] = planes.plane_depth(normals, masks, ds, homo, rng=rng)
         return st
@@ -375,16 +386,16 @@ class _Lane:
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             pipe, dev = self.pipe, self.pipe.device
-            rgb = batch["image"].to(dev, non_blocking=True)
-            ds = batch["sparse_depth"].to(dev, non_blocking=True)
+            rgb = _dev(batch["image"], dev)
+            ds = _dev(batch["sparse_depth"], dev)
             self._prepare(rgb)
             prog = self.prog
             if self.have_prev:
                 self.dc_image.copy_(self.sn_image, non_blocking=True)
             mh = pipe._masks_begin(rgb) if pipe.args.enriched_samples != 0 else None
             self.sn_image.copy_(rgb, non_blocking=True)
-            self.grav.copy_(batch["gravity"].to(dev).reshape(-1), non_blocking=True)
-            self.algn.copy_(batch["aligned_direction"].to(dev).reshape(-1), non_blocking=True)
+            self.grav.copy_(_dev(batch["gravity"], dev).reshape(-1), non_blocking=True)
+            self.algn.copy_(_dev(batch["aligned_direction"], dev).reshape(-1), non_blocking=True)
             prog.launch_segment(0) if prog.captured else prog.run_segment(0)
             self._frame = (batch, rgb, ds, mh)
 
@@ -398,7 +409,7 @@ class _Lane:
             _, _, H, W = rgb.shape
             if pipe.args.enriched_samples != 0:
                 normals = prog.tensor(prog.outputs["normals"])
-                homo = batch["homogeneous_coordinates"].to(pipe.device, non_blocking=True)
+                homo = _dev(batch["homogeneous_coordinates"], pipe.device)
                 masks = pipe._masks_end(mh, batch["image"], H, W)
                 di, info = self.planes.plane_depth(normals, masks, ds, homo, rng=pipe.rng)
                 self.pending_enrich = (ds, di, info, self.planes.read_info_async(info))
@@ -462,8 +473,8 @@ class _Lane:
         pipe = self.pipe
         dev = pipe.device
         if batch is not None:
-            rgb = batch["image"].to(dev, non_blocking=True)
-            ds = batch["sparse_depth"].to(dev, non_blocking=True)
+            rgb = _dev(batch["image"], dev)
+            ds = _dev(batch["sparse_depth"], dev)
             B, _, H, W = rgb.shape
             self._prepare(rgb)
         elif self.prog is None or not self.have_prev:
@@ -477,12 +488,12 @@ class _Lane:
         if batch is not None:
             mh = pipe._masks_begin(rgb) if pipe.args.enriched_samples != 0 else None    # ids reach the host while segment 0 runs
             self.sn_image.copy_(rgb, non_blocking=True)
-            self.grav.copy_(batch["gravity"].to(dev).reshape(-1), non_blocking=True)
-            self.algn.copy_(batch["aligned_direction"].to(dev).reshape(-1), non_blocking=True)
+            self.grav.copy_(_dev(batch["gravity"], dev).reshape(-1), non_blocking=True)
+            self.algn.copy_(_dev(batch["aligned_direction"], dev).reshape(-1), non_blocking=True)
             prog.launch_segment(0) if graph else prog.run_segment(0)
             normals = prog.tensor(prog.outputs["normals"])
             if pipe.args.enriched_samples != 0:
-                homo = batch["homogeneous_coordinates"].to(dev, non_blocking=True)
+                homo = _dev(batch["homogeneous_coordinates"], dev)
                 masks = pipe._masks_end(mh, batch["image"], H, W)
                 di, info = self.planes.plane_depth(normals, masks, ds, homo, rng=pipe.rng)
                 pending = (di, info, self.planes.read_info_async(info))
