@@ -23,7 +23,12 @@ pool = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in S.synthetic_bat
 def frames(n):
     for i in range(n):
         yield pool[i % 4]
-for es in (200, 0):
+host_pool = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.items()} for b in pool]
+for es, name, src in ((200, "device-resident frames", pool), (200, "HOST-resident frames (pinned staging + async copy inside the timed region)", host_pool), (0, "device-resident, no plane block", pool)):
+    def frames(n, src=src):
+        for i in range(n):
+            yield src[i % 4]
+    print(name, flush=True)
     pipe.args.enriched_samples = es
     for lanes in (1, 2):
         for out in pipe.run_interleaved(frames(30), copy_outputs=False, lanes=lanes): pass

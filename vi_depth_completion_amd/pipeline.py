@@ -15,15 +15,35 @@ from .networks.surface_normal import SurfaceNormalPrediction
 from .plane import PlaneBlock
 
 
-def _dev(t, dev):
-    """A batch tensor on the device.  Host tensors (the reference's DataLoader hands out CPU batches) go through cached pinned memory
-    with an asynchronous copy: a copy out of pageable memory blocks the host until the device has caught up with everything queued
-    before it, i.e. a whole tick in the stream modes."""
-    if t.is_cuda:
-        return t
-    p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-    p.copy_(t)
-    return p.to(dev, non_blocking=True)
+class _Stager:
+    """Host-resident batch tensors (the reference's DataLoader hands out CPU batches) -> the device, without blocking the host: a
+    copy out of pageable memory makes the host wait until the device has caught up with everything queued before it (a whole tick in
+    the stream modes), and pinned memory from torch's caching allocator is not reusable while a copy out of it is still queued, so
+    every frame would allocate fresh pinned memory (milliseconds per call; measured 38 frames/s).  Hence a small ring of persistent
+    pinned buffers per tensor name, each rewritten only after the copy out of it has completed."""
+
+    def __init__(self, depth=2):
+        self.depth, self.rings, self.turn = depth, {}, {}
+
+    def __call__(self, name, t, dev):
+        if t.is_cuda:
+            return t
+        key = (name, tuple(t.shape), t.dtype)
+        ring = self.rings.setdefault(key, [])
+        i = self.turn.get(key, 0)
+        self.turn[key] = i + 1
+        if len(ring) < self.depth:
+            ring.append([torch.empty(t.shape, dtype=t.dtype, pin_memory=True), None])
+        slot = ring[i % len(ring)] if len(ring) == self.depth else ring[-1]
+        if slot[1] is not None:
+            slot[1].synchronize()
+        # (numpy, not Tensor.copy_: a torch CPU copy of a megabyte goes through the OpenMP pool, whose workers then spin on every core of
+        #  the host and slow the launching thread down tenfold -- measured 47 frames/s)
+        np.copyto(slot[0].numpy(), t.detach().numpy())
+        d = slot[0].to(dev, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        return d
 
 
 class FixedPlaneMask:
@@ -107,6 +127,7 @@ class DepthCompletionPipeline:
             self.surface_normal_cnn = SurfaceNormalDORN().to(self.device)                                    # main.py:245
         self.plane_masks_extraction = None
         self.planes = PlaneBlock()
+        self._stage = _Stager()
         self.rng = rng
         self.eval_mode()
 
@@ -160,17 +181,17 @@ class DepthCompletionPipeline:
         """warp + surface-normal net + plane block, enqueued on the current stream (main.py:262-283)."""
         dev = self.device
         planes = planes or self.planes
-        ds = _dev(input_batch["sparse_depth"], dev)
-        rgb = _dev(input_batch["image"], dev)
+        ds = self._stage("sparse_depth", input_batch["sparse_depth"], dev)
+        rgb = self._stage("image", input_batch["image"], dev)
         mh = self._masks_begin(rgb) if self.args.enriched_samples != 0 else None      # the id maps travel to the host under the normal net
         if self.use_gravity:
-            normals = self.surface_normal_cnn.enqueue(rgb, _dev(input_batch["gravity"], dev), _dev(input_batch["aligned_direction"], dev), slot)
+            normals = self.surface_normal_cnn.enqueue(rgb, self._stage("gravity", input_batch["gravity"], dev), self._stage("aligned_direction", input_batch["aligned_direction"], dev), slot)
         else:
             normals = self.surface_normal_cnn(rgb)                                                           # main.py:270-271
         rng = rng if rng is not None else self.rng
         st = {"ds": ds, "rgb": rgb, "normals": normals, "di": None, "nnz": None, "rng": rng}
         if self.args.enriched_samples != 0:
-            homo = _dev(input_batch["homogeneous_coordinates"], dev)
+            homo = self._stage("homogeneous_coordinates", input_batch["homogeneous_coordinates"], dev)
             masks = self._masks_end(mh, input_batch["image"], ds.shape[-2], ds.shape[-1])
             st["di"], st["nnz"] = planes.plane_depth(normals, masks, ds, homo, rng=rng)
         return st
@@ -348,6 +369,7 @@ class _Lane:
     def __init__(self, pipe, index, own_stream):
         self.pipe, self.index = pipe, index
         self.prog, self.shape0, self.have_prev, self.pending_out, self.pending_enrich, self._frame = None, None, False, None, None, None
+        self._stage = pipe.__dict__.setdefault("_lane_stagers", {}).setdefault(index, _Stager())
         cache = pipe.__dict__.setdefault("_lane_cache", {})
         ent = cache.setdefault(index, {})
         self.cache = ent
@@ -386,16 +408,16 @@ class _Lane:
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             pipe, dev = self.pipe, self.pipe.device
-            rgb = _dev(batch["image"], dev)
-            ds = _dev(batch["sparse_depth"], dev)
+            rgb = self._stage("image", batch["image"], dev)
+            ds = self._stage("sparse_depth", batch["sparse_depth"], dev)
             self._prepare(rgb)
             prog = self.prog
             if self.have_prev:
                 self.dc_image.copy_(self.sn_image, non_blocking=True)
             mh = pipe._masks_begin(rgb) if pipe.args.enriched_samples != 0 else None
             self.sn_image.copy_(rgb, non_blocking=True)
-            self.grav.copy_(_dev(batch["gravity"], dev).reshape(-1), non_blocking=True)
-            self.algn.copy_(_dev(batch["aligned_direction"], dev).reshape(-1), non_blocking=True)
+            self.grav.copy_(self._stage("gravity", batch["gravity"], dev).reshape(-1), non_blocking=True)
+            self.algn.copy_(self._stage("aligned_direction", batch["aligned_direction"], dev).reshape(-1), non_blocking=True)
             prog.launch_segment(0) if prog.captured else prog.run_segment(0)
             self._frame = (batch, rgb, ds, mh)
 
@@ -409,7 +431,7 @@ class _Lane:
             _, _, H, W = rgb.shape
             if pipe.args.enriched_samples != 0:
                 normals = prog.tensor(prog.outputs["normals"])
-                homo = _dev(batch["homogeneous_coordinates"], pipe.device)
+                homo = self._stage("homogeneous_coordinates", batch["homogeneous_coordinates"], pipe.device)
                 masks = pipe._masks_end(mh, batch["image"], H, W)
                 di, info = self.planes.plane_depth(normals, masks, ds, homo, rng=pipe.rng)
                 self.pending_enrich = (ds, di, info, self.planes.read_info_async(info))
@@ -473,8 +495,8 @@ class _Lane:
         pipe = self.pipe
         dev = pipe.device
         if batch is not None:
-            rgb = _dev(batch["image"], dev)
-            ds = _dev(batch["sparse_depth"], dev)
+            rgb = self._stage("image", batch["image"], dev)
+            ds = self._stage("sparse_depth", batch["sparse_depth"], dev)
             B, _, H, W = rgb.shape
             self._prepare(rgb)
         elif self.prog is None or not self.have_prev:
@@ -488,12 +510,12 @@ class _Lane:
         if batch is not None:
             mh = pipe._masks_begin(rgb) if pipe.args.enriched_samples != 0 else None    # ids reach the host while segment 0 runs
             self.sn_image.copy_(rgb, non_blocking=True)
-            self.grav.copy_(_dev(batch["gravity"], dev).reshape(-1), non_blocking=True)
-            self.algn.copy_(_dev(batch["aligned_direction"], dev).reshape(-1), non_blocking=True)
+            self.grav.copy_(self._stage("gravity", batch["gravity"], dev).reshape(-1), non_blocking=True)
+            self.algn.copy_(self._stage("aligned_direction", batch["aligned_direction"], dev).reshape(-1), non_blocking=True)
             prog.launch_segment(0) if graph else prog.run_segment(0)
             normals = prog.tensor(prog.outputs["normals"])
             if pipe.args.enriched_samples != 0:
-                homo = _dev(batch["homogeneous_coordinates"], dev)
+                homo = self._stage("homogeneous_coordinates", batch["homogeneous_coordinates"], dev)
                 masks = pipe._masks_end(mh, batch["image"], H, W)
                 di, info = self.planes.plane_depth(normals, masks, ds, homo, rng=pipe.rng)
                 pending = (di, info, self.planes.read_info_async(info))
