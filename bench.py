@@ -252,7 +252,15 @@ def measure(args, dev, rank, world, precision):
                  "conv_ms_per_frame": round(conv_ms, 3), "conv_launches_per_frame": n_launch,
                  "conv_stack": {"executed_gflop_per_frame": round(conv_flops / 1e9, 2),
                                 "tflops_fp32_equivalent": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
-                                "tflops_bf16_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / (conv_ms * 1e-3) / 1e12, 2)},
+                                "tflops_bf16_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / (conv_ms * 1e-3) / 1e12, 2),
+                                "note": "over the conv time of ONE frame program alone (single stream)",
+                                # the same FLOPs at the frame rate of the timed region of this rank (with --lanes 2 the launches of two
+                                # frame programs overlap, so the chip executes more per second than one program's own conv time implies)
+                                "at_measured_frame_rate": {
+                                    "tflops_fp32_equivalent": round(conv_flops / B * (args.steps * B / elapsed) / 1e12, 2),
+                                    "tflops_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / B * (args.steps * B / elapsed) / 1e12, 2),
+                                    "frac_of_peak_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / B * (args.steps * B / elapsed) / 1e12
+                                                                   / (PEAK_BF16_MFMA_TFLOPS if precision == "mixed" else PEAK_F32_MFMA_TFLOPS), 4)}},
                  "reference_formulation_gflop_per_frame": round(flops / 1e9, 2),
                  "conv_stack_tflops_reference_formulation": round(flops / (conv_ms * 1e-3) / 1e12, 2),
                  "precision_mode": precision,
