@@ -26,6 +26,7 @@ SHAPES = {  # name: (H, W, cin, cout, k, G, tile, precision)
     "f1_3x3_768": (64, 80, 768, 768, 3, 1, 3, 1),
     "now_l3_1x1_256to1024_G4": (16, 20, 256, 1024, 1, 4, 20, 1),
     "now_l3_1x1_1024to256_G4": (16, 20, 1024, 256, 1, 4, 23, 1),
+    "now_l3_3x3_G4_64x64k2d4": (16, 20, 256, 256, 3, 4, 13, 1),
     "f1_3x3_768_128x128d3L": (64, 80, 768, 768, 3, 1, 25, 1),
     "f1_3x3_768_128x128d3": (64, 80, 768, 768, 3, 1, 24, 1),
 }
