@@ -243,9 +243,9 @@ def measure(args, dev, rank, world, precision):
             pmc = None
         if pmc:
             roofline["traffic"] = pmc["traffic_bytes"]
-            roofline["traffic_note"] = ("bytes per launch = FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE from rocprofv3 --pmc passes on "
-                                        "tools/conv_bench.py, %s; algorithmic bytes of that launch %d (profiles/pmc_traffic.json; --pmc on the "
-                                        "whole bench process segfaults in rocprofv3 on this pool)" % (pmc["shape"], pmc["algorithmic_bytes"]))
+            roofline["traffic_note"] = ("bytes per launch = FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE from rocprofv3 --pmc passes: %s; %s; "
+                                        "algorithmic bytes of that launch %d (profiles/pmc_traffic.json; --pmc on the whole bench process "
+                                        "segfaults in rocprofv3 on this pool)" % (pmc["command"], pmc["shape"], pmc["algorithmic_bytes"]))
         ranked = sorted(kernels, key=lambda k: -kernels[k][0])
         extra = {"program_ms": ({"frame_program_tick": round(sn_total, 3)} if args.mode == "interleaved" else
                                 {"surface_normal": round(sn_total, 3), "depth_completion": round(dc_total, 3)}),
