@@ -786,6 +786,14 @@ def test_run_interleaved_lanes_are_bit_identical(pipeline):
         outs = [o.cpu() for o in pipeline.run_interleaved(iter(host_frames), lanes=2)]
         for f, (a, b) in enumerate(zip(ref, outs)):
             assert torch.equal(a, b), "frame %d differs for host-resident batches" % f
+        # without enrichment (enriched_samples = 0: the sparse depth goes to the depth network as it is) the lanes agree as well
+        es = pipeline.args.enriched_samples
+        try:
+            pipeline.args.enriched_samples = 0
+            plain = [[o.cpu() for o in pipeline.run_interleaved(iter(frames[:4]), lanes=lanes)] for lanes in (1, 2)]
+            assert len(plain[0]) == 4 and all(torch.equal(a, b) for a, b in zip(*plain))
+        finally:
+            pipeline.args.enriched_samples = es
         pipeline.rng = np.random.RandomState(99)
         short = [o.cpu() for o in pipeline.run_interleaved(iter(frames[:2]), lanes=3, copy_outputs=True)]
         assert len(short) == 2 and torch.equal(short[0], ref[0]) and torch.equal(short[1], ref[1])
