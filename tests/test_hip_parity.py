@@ -815,6 +815,32 @@ def test_run_interleaved_golden(pipeline, golden_dir):
     assert rmse < 1e-3, rmse
 
 
+def test_two_lanes_on_the_demo_frames_enrich_and_agree(pipeline, golden_dir):
+    """The reference's demo frames (real images, real VI-SLAM points: planes are found and candidates enriched, so the deferred
+    enrichment wait and the draw order across lanes are actually exercised) as one stream drawing from one generator: every frame's
+    depth bit-identical for one and two lanes, enrichment demonstrably on (the result changes when it is switched off), and the first
+    frame -- whose draws are those of the golden run -- within 1e-3 RMSE of the reference's depth."""
+    fs = [np.load(os.path.join(golden_dir, n + ".npz")) for n in GOLDEN_FRAMES]
+    frames = [_golden_batch(f, n) for f, n in zip(fs, GOLDEN_FRAMES)] * 2
+    saved, es = pipeline.rng, pipeline.args.enriched_samples
+    try:
+        runs = []
+        for lanes in (1, 2):
+            np.random.seed(int(fs[0]["np_seed"]))
+            pipeline.rng = np.random
+            runs.append([o.cpu() for o in pipeline.run_interleaved(iter(frames), lanes=lanes)])
+        assert len(runs[0]) == len(frames)
+        for i, (a, b) in enumerate(zip(*runs)):
+            assert torch.equal(a, b), "frame %d differs between one and two lanes" % i
+        rmse = float(np.sqrt(np.mean((runs[1][0][0, 0].numpy() - fs[0]["depth"]) ** 2)))
+        assert rmse < 1e-3, rmse
+        pipeline.args.enriched_samples = 0
+        plain = [o.cpu() for o in pipeline.run_interleaved(iter(frames[:2]), lanes=2)]
+        assert not torch.equal(plain[0], runs[1][0]), "enrichment had no effect on the demo frame: the test would not exercise it"
+    finally:
+        pipeline.rng, pipeline.args.enriched_samples = saved, es
+
+
 def test_modules_refuse_cpu_and_training(pipeline):
     with pytest.raises(RuntimeError, match="GPU"):
         pipeline.cnn(torch.zeros(1, 3, 240, 320), torch.zeros(1, 3, 240, 320), torch.zeros(1, 1, 240, 320))
