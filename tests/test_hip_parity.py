@@ -620,6 +620,15 @@ def test_dense_depth_input_in_the_pipeline(pipeline, seeded_weights):
         dev_batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
         outs = [o.cpu() for o in pipeline.run_interleaved(iter([dev_batch]))]
         assert float((outs[0] - ref).pow(2).mean().sqrt()) < 1e-3
+        # ... and with two lanes, where the branch is resolved one visit late (the generator is rewound to the frame's first draw and
+        # its hypotheses replayed with the extra permutation BEFORE the next frame's are drawn): a dense frame between sparse ones
+        sparse = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in S.synthetic_batch(1, 240, 320, 1234, frame0=22).items()}
+        stream = [sparse, dev_batch, sparse, dev_batch]
+        runs = []
+        for lanes in (1, 2):
+            pipeline.rng = np.random.RandomState(8)
+            runs.append([o.cpu() for o in pipeline.run_interleaved(iter(stream), lanes=lanes)])
+        assert all(torch.equal(a, b) for a, b in zip(*runs)) and len(runs[1]) == 4
     finally:
         pipeline.rng = saved          # the module-scoped pipeline draws from np.random in the golden tests
 
