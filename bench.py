@@ -285,6 +285,9 @@ def main():
     dev = torch.device("cuda", local)
     torch.set_grad_enabled(False)
     if world > 1:
+        # N ranks share the host: keep every rank's torch CPU pool (synthetic inputs are generated on the CPU before the timed region)
+        # to its share of the cores, so that N pools of spinning OpenMP workers do not slow the N launching threads down
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
         import torch.distributed as dist
         backend = os.environ.get("VIDC_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" to try the N > 1 path on a 1-GPU box
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
