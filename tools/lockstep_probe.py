@@ -24,6 +24,12 @@ def main():
     cc = (0.5 * 319.87654, 0.5 * 239.87603 * H / 240.0)
     pipe = DepthCompletionPipeline(enriched_samples=200, cc_img=cc, device=dev)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    table = engine.tuning_table()
+    for item in [v for v in os.environ.get("VIDC_OVERRIDE", "").split(",") if v]:      # "signature:tile:splitk,..." (tile experiments)
+        sig, t, sk = item.split(":")
+        e = list(table[sig])
+        table[sig] = [int(t), int(sk), 1] + e[3:5]
+        print("override %s -> tile %s sk %s (was %s)" % (sig, t, sk, e[:2]), flush=True)
 
     def build(shared):
         ws = engine.JointWeightStore({"sn": pipe.surface_normal_cnn, "dc": pipe.cnn}) if shared else None
@@ -52,8 +58,10 @@ def main():
                 a.launch_segment(1, stream=sa); b.launch_segment(1, stream=sb)
         torch.cuda.synchronize()
 
-    for shared in (True, False):
+    for shared in ((True,) if os.environ.get("VIDC_OVERRIDE") else (True, False)):
         progs = build(shared)
+        one = min(progs[0].time(iters=20, use_graph=True, stream=streams[0].cuda_stream) for _ in range(3))
+        print("one program alone: %.3f ms per tick" % one, flush=True)
         for stagger in (False, True):
             run(progs, 5, stagger)
             best = None
