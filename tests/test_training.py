@@ -530,17 +530,17 @@ def test_training_loop_on_pipeline_inputs(seeded_weights):
 @gpu
 def test_graph_replay_equals_eager_steps(seeded_weights):
     """`step()` replays forward + backward as one captured hipGraph from the third step of a shape on: five steps on changing inputs,
-    graph on against graph off -- the same kernels in the same order with fixed-order reductions, so losses, parameters and running
-    statistics are bit-identical."""
+    graph on against graph off, and stream lanes on against one stream -- the same kernels with fixed-order reductions, so losses,
+    parameters and running statistics are bit-identical."""
     from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
     from vi_depth_completion_amd.training import DepthCompletionTrainer
     runs = []
-    for use_graph in (False, True):
+    for use_graph, lanes in ((False, 4), (True, 4), (False, 1)):      # (the last run: everything on ONE stream)
         cnn = ModifiedFPN().to(DEV)
         cnn.load_state_dict({k: v.to(DEV) for k, v in seeded_weights["dc"].items()})
         cnn.train()
         tr = DepthCompletionTrainer(cnn, 1e-4)
-        tr.use_graph = use_graph
+        tr.use_graph, tr.n_lanes = use_graph, lanes
         losses = []
         for it in range(5):
             b = S.synthetic_batch(1, 96, 128, 77, frame0=it)
@@ -550,10 +550,14 @@ def test_graph_replay_equals_eager_steps(seeded_weights):
             losses.append(float(tr.step(image, normal, b["sparse_depth"].to(DEV), gt)))
         assert bool(tr._graphs) == use_graph
         runs.append((losses, tr.flat_p.clone(), {k: v.clone() for k, v in cnn.state_dict().items() if "running" in k or "tracked" in k}))
-    (l0, p0, s0), (l1, p1, s1) = runs
+    (l0, p0, s0), (l1, p1, s1), (l2, p2, s2) = runs
     assert l0 == l1, (l0, l1)
     assert torch.equal(p0, p1)
     assert all(torch.equal(s0[k], s1[k]) for k in s0)
+    # the three pyramids / four decoder branches on their own HIP streams against everything on one stream: the same kernels, per-lane
+    # scratch and split-K workspaces -- bit-identical as well
+    assert l0 == l2, (l0, l2)
+    assert torch.equal(p0, p2) and all(torch.equal(s0[k], s2[k]) for k in s0)
     assert int(s1["resnet_rgb.bn1.num_batches_tracked"]) == 5 if "resnet_rgb.bn1.num_batches_tracked" in s1 else True
 
 
