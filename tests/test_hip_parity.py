@@ -803,6 +803,12 @@ def test_run_interleaved_lanes_are_bit_identical(pipeline):
             assert len(plain[0]) == 4 and all(torch.equal(a, b) for a, b in zip(*plain))
         finally:
             pipeline.args.enriched_samples = es
+        # a frame of another shape in the stream is refused (by the lane that would have taken it), not mis-computed
+        other = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in S.synthetic_batch(2, 240, 320, 1234, frame0=90).items()}
+        with pytest.raises(ValueError, match="same shape"):
+            list(pipeline.run_interleaved(iter([frames[0], frames[1], frames[2], other]), lanes=2))
+        with pytest.raises(ValueError, match="lanes"):
+            list(pipeline.run_interleaved(iter(frames[:1]), lanes=0))
         pipeline.rng = np.random.RandomState(99)
         short = [o.cpu() for o in pipeline.run_interleaved(iter(frames[:2]), lanes=3, copy_outputs=True)]
         assert len(short) == 2 and torch.equal(short[0], ref[0]) and torch.equal(short[1], ref[1])
