@@ -2,6 +2,8 @@
 """Headline benchmark: frames/s of the per-frame depth-completion hot path on N MI355X (BASELINE.json).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N ...           no RANK in the environment: spawns the N ranks itself (a torch.distributed.run child process,
+                                           started BEFORE this process touches the GPU) and exits with the child's code
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Workload = BASELINE.json configs[1]: synthetic 320x256 RGB + 200-point sparse depth, batch 1, plane mask fixed;
@@ -56,7 +58,50 @@ def parse():
     ap.add_argument("--lanes", type=int, default=2, help="--mode interleaved: software-pipelined frame streams on this many HIP streams, frame i on lane "
                                                           "i mod L (pipeline.run_interleaved(lanes=L)); results are bit-identical for every L")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the second leg (the same steps with every conv in exact fp32 MFMA arithmetic)")
+    ap.add_argument("--no-sequential-leg", action="store_true", help="skip the short back-to-back _call_cnn measurement (per-frame latency and the "
+                                                                       "rate of the operator the reference's harness calls, network_run.py:294-296)")
+    ap.add_argument("--sequential-frames", type=int, default=20)
+    ap.add_argument("--cpu-threads", default="8,16,32,64,128", help="thread counts tried for the CPU baseline (one frame each); the best one runs --cpu-frames")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="no GPU work: every rank only joins the process group and gathers a fake record (tests/test_bench_launcher.py runs "
+                         "`bench.py --gpus 2 --launcher-selftest` under gloo on the CPU: spawn, rendezvous, gather, the n_gpus check)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` called without a launcher: start the N ranks as a CHILD process (torch.distributed.run, rendezvous on
+    127.0.0.1) and return its exit code.  This process has not initialised the GPU (torch.cuda.device_count() does not on this
+    image), and it never replaces itself with another program."""
+    import socket
+    import subprocess
+    backend = os.environ.get("VIDC_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and n_dev < args.gpus and not args.launcher_selftest:
+        print("bench.py: --gpus %d needs %d GPUs, this node shows %d (VIDC_DIST_BACKEND=gloo shares GPUs between ranks to try the "
+              "multi-rank path on a smaller box)" % (args.gpus, args.gpus, n_dev), file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or args.gpus) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_selftest(args, rank, world):
+    """The N > 1 plumbing without the GPU: group, gather, the rank-count check, ONE line from rank 0."""
+    import torch.distributed as dist
+    rec = sharding.metric_record(args.steps, 1.0 + 0.5 * rank, 0.0, 0.0)
+    got = sharding.gather_records(rec)
+    assert got.shape[0] == world, "gathered %d records from a world of %d" % (got.shape[0], world)
+    job = sharding.combine(got)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher-selftest", "n_gpus": int(got.shape[0]), "frames": job["frames"], "seconds": job["seconds"],
+                          "backend": (dist.get_backend() if world > 1 else "none")}), flush=True)
 
 
 def build_pipeline(H, W, dev, plane_head=False):
@@ -94,7 +139,9 @@ TILE_TEMPLATE = {"128x128": (128, 128, 2, 2, 1, 2), "128x64": (128, 64, 2, 2, 1,
                  "64x64k2d4L": (64, 64, 2, 2, 2, 4), "64x128L": (64, 128, 2, 2, 1, 3), "128x64L": (128, 64, 2, 2, 1, 3),
                  "64x32k2": (64, 32, 2, 1, 2, 3), "64x32k2d5": (64, 32, 2, 1, 2, 5), "64x32k2d5L": (64, 32, 2, 1, 2, 5),
                  "128x128d3": (128, 128, 2, 2, 1, 3), "128x128d3L": (128, 128, 2, 2, 1, 3), "256x128": (256, 128, 4, 2, 1, 3),
-                 "128x256": (128, 256, 2, 4, 1, 3)}
+                 "128x256": (128, 256, 2, 4, 1, 3),
+                 "32x64k2d2": (32, 64, 1, 2, 2, 2), "64x64d2": (64, 64, 2, 2, 1, 2), "32x32k4d2": (32, 32, 1, 1, 4, 2), "64x128d2": (64, 128, 2, 2, 1, 2),
+                 "64x32k2d2": (64, 32, 2, 1, 2, 2)}
 
 
 def kernel_name(tile, prec):
@@ -187,6 +234,25 @@ def measure(args, dev, rank, world, precision):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
+    # ---- the operator the reference's harness calls, frame after frame (network_run.py:294-296: one _call_cnn per batch, its output
+    #      consumed before the next call): per-frame latency and the rate with ONE frame in flight.  Outside the timed region. ----------
+    sequential = None
+    if rank == 0 and not args.no_sequential_leg and args.sequential_frames > 0:
+        it = frames(args.sequential_frames + 3)
+        for _ in range(3):
+            pipe._call_cnn(next(it))
+        torch.cuda.synchronize()
+        lat = []
+        for b_ in it:
+            t1 = time.perf_counter()
+            pipe._call_cnn(b_)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        lat.sort()
+        sequential = {"what": "%d back-to-back _call_cnn calls, host synchronised after each (one frame in flight)" % len(lat),
+                      "frames_per_s": round(len(lat) * B / sum(lat), 2), "latency_ms_median": round(1e3 * lat[len(lat) // 2], 3),
+                      "latency_ms_max": round(1e3 * lat[-1], 3)}
+
     # ---- roofline of the dominant kernel (fused conv), measured live with HIP events -- before the
     #      CPU baseline, whose OpenMP workers keep spinning and would slow the launching thread ---------------------
     roofline = None
@@ -263,12 +329,12 @@ def measure(args, dev, rank, world, precision):
                                                                    / (PEAK_BF16_MFMA_TFLOPS if precision == "mixed" else PEAK_F32_MFMA_TFLOPS), 4)}},
                  "reference_formulation_gflop_per_frame": round(flops / 1e9, 2),
                  "conv_stack_tflops_reference_formulation": round(flops / (conv_ms * 1e-3) / 1e12, 2),
-                 "precision_mode": precision,
+                 "precision_mode": precision, "sequential_call_cnn": sequential,
                  "other_conv_kernels": [roof(k) for k in ranked[1:4]]}
         for r in extra["other_conv_kernels"]:
             r.pop("traffic_note", None)
-        if args.per_op and precision == "mixed":
-            with open(args.per_op, "w") as f:
+        if args.per_op:
+            with open(args.per_op if precision == "mixed" else args.per_op + ".fp32", "w") as f:
                 for name, ops in ((("frame_program" if args.mode == "interleaved" else "surface_normal"), sn_ops), ("depth_completion", dc_ops)):
                     for n, t in ops:
                         f.write("%s\t%.2f\t%s\n" % (name, t * 1e3, n))
@@ -278,10 +344,29 @@ def measure(args, dev, rank, world, precision):
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))              # nothing below runs in the launching process
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)     # (one rank per GPU; the modulo only matters when
-    torch.cuda.set_device(local)                                                            #  the launch path is tried on a box with fewer GPUs)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    backend = os.environ.get("VIDC_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" to try the N > 1 path on a box with fewer GPUs
+    if args.launcher_selftest:
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        launcher_selftest(args, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
+    if world > n_dev and backend == "nccl":
+        raise SystemExit("bench.py: %d ranks on %d GPU(s): one rank per GPU (set VIDC_DIST_BACKEND=gloo to share GPUs on purpose)" % (world, n_dev))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % n_dev     # (the modulo only matters for the gloo try-out on a smaller box)
+    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.set_grad_enabled(False)
     if world > 1:
@@ -289,7 +374,6 @@ def main():
         # to its share of the cores, so that N pools of spinning OpenMP workers do not slow the N launching threads down
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
         import torch.distributed as dist
-        backend = os.environ.get("VIDC_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" to try the N > 1 path on a 1-GPU box
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     H, W, B = args.height, args.width, args.batch
@@ -329,23 +413,40 @@ def main():
             pipe.rng = np.random.RandomState(77)
             got = pipe._call_cnn({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in hb.items()}).cpu()
             recs[m][2], recs[m][3] = float((got - ref).double().pow(2).sum()), float(ref.numel())
-        tc = time.perf_counter()
-        for j in range(args.cpu_frames if world == 1 else 0):     # the CPU baseline is timed at N=1 only (the other ranks would idle in the gather)
-            hbj = S.synthetic_batch(B, H, W, 1234, frame0=(j + 1) * B)
-            O.call_cnn(cpu_sn, cpu_dc, hbj, plane_masks(hbj), intr, 200, rng=np.random.RandomState(j))
-        cpu_s = time.perf_counter() - tc
-        cpu_baseline = None if world > 1 else {"value": round(args.cpu_frames * B / cpu_s, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
-                        "kind": "port",
-                        "sample": "%d frames of the same %dx%d batch-%d workload through oracle/vidc_oracle.call_cnn "
-                                  "(torch CPU fp32, %d threads of %d host CPUs)" % (args.cpu_frames, W, H, B,
-                                                                                    torch.get_num_threads(), os.cpu_count())}
+        if world == 1:      # the CPU baseline is timed at N=1 only (the other ranks would idle in the gather)
+            # batch-1 convs do not scale to every host thread (0.26 frames/s on 128 threads in round 2 against 0.93 on 8 in the survey
+            # container): one frame per candidate thread count, then --cpu-frames frames at the best one
+            n_cpu = os.cpu_count() or 1
+            cands = sorted({min(int(v), n_cpu) for v in args.cpu_threads.split(",") if v.strip()})
+            sweep = {}
+            for nt in cands:
+                torch.set_num_threads(nt)
+                hbj = S.synthetic_batch(B, H, W, 1234, frame0=B)
+                tc = time.perf_counter()
+                O.call_cnn(cpu_sn, cpu_dc, hbj, plane_masks(hbj), intr, 200, rng=np.random.RandomState(0))
+                sweep[nt] = time.perf_counter() - tc
+            best_nt = min(sweep, key=sweep.get)
+            torch.set_num_threads(best_nt)
+            tc = time.perf_counter()
+            for j in range(args.cpu_frames):
+                hbj = S.synthetic_batch(B, H, W, 1234, frame0=(j + 1) * B)
+                O.call_cnn(cpu_sn, cpu_dc, hbj, plane_masks(hbj), intr, 200, rng=np.random.RandomState(j))
+            cpu_s = time.perf_counter() - tc
+            cpu_baseline = {"value": round(args.cpu_frames * B / cpu_s, 4), "unit": "frames/s", "cores": best_nt, "kind": "port",
+                            "sample": "%d frames of the same %dx%d batch-%d workload through oracle/vidc_oracle.call_cnn (torch CPU fp32) on %d "
+                                      "threads of %d host CPUs -- the best of a one-frame sweep over thread counts" % (
+                                          args.cpu_frames, W, H, B, best_nt, n_cpu),
+                            "thread_sweep_frames_per_s": {str(k): round(B / v, 4) for k, v in sorted(sweep.items())}}
 
-    jobs = {m: sharding.combine(sharding.gather_records(recs[m])) for m in legs}   # the only collective: 4 doubles per rank and leg over RCCL/xGMI
+    gathered = {m: sharding.gather_records(recs[m]) for m in legs}    # the only collective: 4 doubles per rank and leg over RCCL/xGMI
+    for m in legs:
+        assert gathered[m].shape[0] == world, "gathered %d records from a world of %d ranks" % (gathered[m].shape[0], world)
+    jobs = {m: sharding.combine(gathered[m]) for m in legs}
     if rank == 0:
         job = jobs[main_mode]
         frames, t_max = job["frames"], job["seconds"]
         line = {
-            "metric": "frames/sec", "value": round(frames / t_max, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "metric": "frames/sec", "value": round(frames / t_max, 3), "unit": "frames/s", "n_gpus": int(gathered[main_mode].shape[0]), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if main_mode == "fp32" else "f32+bf16x3"), "data": "synthetic",
@@ -371,6 +472,7 @@ def main():
                 "fp32_leg": {"what": "the same %d steps with every conv on v_mfma_f32_32x32x2_f32 (exact fp32 products and sums: the reference's "
                                      "arithmetic), fresh pipeline in this process" % args.steps,
                              "program_ms": r32["extra"].get("program_ms"), "conv_ms_per_frame": r32["extra"].get("conv_ms_per_frame"),
+                             "sequential_call_cnn": r32["extra"].get("sequential_call_cnn"),
                              "conv_stack": r32["extra"].get("conv_stack")}})
         print(json.dumps(line), flush=True)
     if world > 1:

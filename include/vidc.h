@@ -127,7 +127,11 @@ enum vidc_conv_tile { VIDC_TILE_AUTO = 0, VIDC_TILE_128x128 = 1, VIDC_TILE_128x6
                       VIDC_TILE_128x128_D3 = 24, VIDC_TILE_128x128_D3_L = 25,
                       /* 8 waves of 64x64: 128 FLOP per ingested byte (the large layers are bound by the L2 -> LDS DMA rate) */
                       VIDC_TILE_256x128 = 26, VIDC_TILE_128x256 = 27,
-                      VIDC_TILE_COUNT = 28 };
+                      /* _D2: 2-deep rings, 32-48 KB of LDS per workgroup -- three or more workgroups (of this launch or of another
+                       * stream's) per CU: latency is covered by co-resident workgroups instead of a deep ring per workgroup */
+                      VIDC_TILE_32x64_K2_D2 = 28, VIDC_TILE_64x64_D2 = 29, VIDC_TILE_32x32_K4_D2 = 30, VIDC_TILE_64x128_D2 = 31,
+                      VIDC_TILE_64x32_K2_D2 = 32,
+                      VIDC_TILE_COUNT = 33 };
 
 /* Arithmetic of the contraction.  FP32: v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32, the reference mode).
  * BF16X3: every operand is split as x = hi + lo (bf16 each, round-to-nearest-even) and each product is computed as
@@ -276,6 +280,14 @@ int vidc_resize_bilinear_u8_to_chw(const uint8_t* src_hwc, float* dst_chw, int B
  * overwrites an earlier one.  depth float [B][H][W] is zero-filled by the call. */
 int vidc_rasterize_sparse_depth(const double* tracks, const int32_t* offsets, int B, double fx, double fy, double cx, double cy,
                                 float* depth, int H, int W, vidc_stream_t stream);
+/* Ground-truth depth of the training / evaluation streams: KinectAzureDataset / ScanNet loaders, dataset.py:283-286 --
+ *   Image.open(depth).convert('F').resize((320, 240), resample=Image.NEAREST); torch.Tensor(np.array(.)) / 1000.0
+ * vidc_nearest_table (host, no GPU): source index per output coordinate of Pillow's NEAREST resize along one axis (Geometry.c
+ * ImagingScaleAffine).  vidc_resize_nearest_u16_depth: src uint16 [B][H][W] millimetres (device) -> dst float [B][Ho][Wo] = src / divisor
+ * (1000: metres), tables on the device.  Bit-identical to the Pillow + torch sequence above. */
+int vidc_nearest_table(int in_size, int out_size, int32_t* table);
+int vidc_resize_nearest_u16_depth(const uint16_t* src, float* dst, int B, int H, int W, int Ho, int Wo, const int32_t* xtab,
+                                  const int32_t* ytab, float divisor, vidc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * evaluation statistics and output conversion on the device   (network_run.py:42-50, 72-82, 198-225, 387-403)
@@ -485,7 +497,9 @@ int vidc_stem_wgrad(const float* dy, const float* x_nchw, float* dw_oihw, int B,
  * stream in while the previous layer finishes.  Same arithmetic as vidc_conv2d_bn_act with tile VIDC_TILE_64x64_K2_D4, splitk 1
  * (bit-identical).  descs[i] may read what descs[j < i] wrote; inputs produced outside the chain must be complete before the launch.
  * create() uploads the layer table (synchronous); run() enqueues the kernel (capturable; it leaves its counters at zero); status() synchronises
- * and returns in *failed_layer the layer whose dependency wait timed out, or -1. */
+ * and returns in *failed_layer the layer whose dependency wait timed out, VIDC_CHAIN_UNCLAIMED when a group's item list was not walked to its
+ * end (no workgroup of the launch ran on that group's XCD), or -1.  Operands: fp32 or bf16x3 (plain bf16 is refused by create()). */
+#define VIDC_CHAIN_UNCLAIMED 0x7FFFFFFE
 typedef struct vidc_chain vidc_chain;
 int vidc_chain_create(const vidc_conv_desc* descs, int n, vidc_chain** out);
 int vidc_chain_run(vidc_chain* chain, vidc_stream_t stream);

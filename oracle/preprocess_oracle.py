@@ -128,3 +128,24 @@ def demo_frame(image_u8_hwc, gravity_raw, klt_tracks, W=320, H=240):
     g, a = gravity_and_alignment(gravity_raw)
     return {"image": color, "sparse_depth": rasterize_sparse_depth(klt_tracks, H, W), "gravity": g, "aligned_direction": a,
             "homogeneous_coordinates": homogeneous_coordinates(DEMO_FC, DEMO_CC, W, H)}
+
+
+def gt_depth(depth_u16, out_wh=(320, 240)):
+    """dataset.py:283-286, literally: `Image.open(depth_info).convert('F')`, `.resize((320, 240), resample=Image.NEAREST)`,
+    `torch.Tensor(np.array(depth_img)) / 1000.0`, `[None, ...]` -- on an in-memory 16-bit image.  (H,W) uint16 -> (1,Ho,Wo) float32."""
+    from PIL import Image
+    img = Image.fromarray(np.ascontiguousarray(depth_u16).astype(np.uint16)).convert("F")
+    img = img.resize(out_wh, resample=Image.NEAREST)
+    return (torch.Tensor(np.array(img)) / 1000.0)[None, ...]
+
+
+def nearest_table(in_size, out_size):
+    """Source index per output coordinate of Pillow's NEAREST resize along one axis (third-party arithmetic, not vendored in the
+    reference: src/libImaging/Geometry.c ImagingScaleAffine -- xo = a0 * 0.5, xo += a0 per pixel in double, index = xo < 0 ? -1 :
+    int(xo)); pinned against Pillow itself in tests/test_preprocess.py."""
+    a0 = in_size / out_size
+    xo, t = a0 * 0.5, []
+    for _ in range(out_size):
+        t.append(-1 if xo < 0.0 else int(xo))
+        xo += a0
+    return np.asarray(t, np.int32)

@@ -145,7 +145,24 @@ def main():
     cases = [("demo_" + k, {kk: (v.unsqueeze(0) if torch.is_tensor(v) else [v]) for kk, v in items[k].items()},
               1000 + int(k)) for k in DEMO_FRAMES]
     cases.append(("synthetic_f0", S.synthetic_batch(1, 240, 320, SEED), 999))
+    cases.append(("demo_000000_dense", None, 1000))      # built below from demo_000000's own result
     for name, batch, npseed in cases:
+        if name == "demo_000000_dense":
+            # A frame that takes plane_offset_ransac's "> 300 points on the plane" branch (main.py:75-78: the offset hypotheses are a
+            # np.random.permutation subsample, drawn between the normal-hypothesis draws of consecutive planes).  The demo frames
+            # carry 81-161 sparse points, so none of them does.  demo_000000 plus ~1100 extra depths on plane 2's pixels, placed on
+            # the plane the reference itself fitted there (n_bar, offset of the run above; the normals do not depend on the sparse
+            # depth and plane 1's draws come first, so plane 2's normal RANSAC repeats exactly) with 2 cm of seeded noise.
+            f0 = np.load(os.path.join(args.out, "demo_000000.npz"))
+            batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in cases[0][1].items()}
+            homo = batch["homogeneous_coordinates"][0]
+            z = -float(f0["plane2.scalars"][3]) / (homo * torch.from_numpy(f0["plane2.n_bar"])).sum(-1)
+            okpx = torch.nonzero((torch.from_numpy(S.plane_id_map(240, 320) == 2) & (z > 0.3) & (z < 9.0)).reshape(-1))[:, 0]
+            pick = (S.uniform01(SEED, "dense.pick", (1200,)).double() * len(okpx)).long().clamp_(max=len(okpx) - 1)
+            sel = torch.unique(okpx[pick])
+            sd = batch["sparse_depth"].clone()
+            sd.view(-1)[sel] = z.reshape(-1)[sel] + 0.02 * S.normal01(SEED, "dense.noise", (len(sel),)).float()
+            batch["sparse_depth"] = sd
         taps.clear()
         plane_calls.clear()
         np.random.seed(npseed)
@@ -169,6 +186,10 @@ def main():
         rr, cc = torch.nonzero(sd_img, as_tuple=True)
         out["sparse_rc"] = torch.stack([rr, cc], 1).numpy().astype(np.int32)
         out["sparse_val"] = sd_img[rr, cc].numpy()
+        if name == "demo_000000_dense":
+            p2 = [t for t in otaps["plane_trace"] if t["cls"] == 2][0]
+            assert p2["accepted"] and p2["n_off_inl"] > 300, "the dense fixture must take main.py:75-78 (got %d offset inliers)" % p2["n_off_inl"]
+            print("    dense fixture: %d sparse points, plane 2 offset inliers %d, valid %s" % (int((batch["sparse_depth"] > 0).sum()), p2["n_off_inl"], p2["valid"]))
         if name.startswith("demo_"):
             out["image_u8"] = (batch["image"][0] * 255.0).round().permute(1, 2, 0).to(torch.uint8).numpy()
             assert torch.equal(torch.from_numpy(out["image_u8"]).permute(2, 0, 1).float().div(255), batch["image"][0])

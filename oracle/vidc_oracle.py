@@ -303,12 +303,16 @@ def mean_normal(n):
     return F.normalize(n.mean(dim=0), dim=0)
 
 
-def mean_normal_ransac(normals, angle_thr=20.0, num_hyp=300, rng=np.random):
+def mean_normal_ransac(normals, angle_thr=20.0, num_hyp=300, rng=np.random, info=None):
+    """main.py:38-62.  `info` (dict, tests only) receives the row of the winning hypothesis."""
     N = normals.shape[0]
     idx = rng.permutation(np.r_[0:N])[0:min(num_hyp, N)]
     dots = torch.clamp(normals[idx] @ normals.t(), -1.0, 1.0)
     close = torch.acos(dots) * (180.0 / np.pi) < angle_thr
-    best = close[torch.argmax(close.sum(dim=1)).item()]
+    win = torch.argmax(close.sum(dim=1)).item()
+    best = close[win]
+    if info is not None:
+        info["winner_normal"] = normals[idx[win]].clone()
     inl = normals[best]
     m = mean_normal(inl)
     ang = torch.acos(torch.clamp(inl @ m[:, None], -1, 1)) * (180 / np.pi)
@@ -358,10 +362,11 @@ def extract_plane_depth(normal_image, mask, depth, homo, rng=np.random, trace=No
             continue
         m = mask == cls
         normals = nimg[m]
-        n_bar, ang, best, idx = mean_normal_ransac(normals, rng=rng)
+        winfo = {}
+        n_bar, ang, best, idx = mean_normal_ransac(normals, rng=rng, info=winfo)
         m2 = m.clone()
         m2[m] = best
-        rec = {"cls": int(cls), "hyp_idx": np.asarray(idx).copy(), "n_bar": n_bar.clone(), "n_inl": int(best.sum()),
+        rec = {"cls": int(cls), "winner_normal": winfo["winner_normal"], "hyp_idx": np.asarray(idx).copy(), "n_bar": n_bar.clone(), "n_inl": int(best.sum()),
                "mean_angle": float(ang.abs().mean()), "accepted": False, "offset": 0.0, "n_off_inl": 0, "valid": False}
         if trace is not None:
             trace.append(rec)

@@ -1,0 +1,129 @@
+"""`bench.py --gpus N` without a launcher spawns its N ranks itself (replaces network_run.py:97-99's DataParallel
+as the way to use N GPUs).  CPU: the launcher, the gloo rendezvous, the gather and the rank-count checks, with `--launcher-selftest`
+(no GPU work).  GPU (1-GPU box): the real bench under two gloo ranks sharing the GPU, and every collective of the package on a
+world-size-1 `nccl` (= RCCL) group."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def _last_json(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_spawns_its_own_ranks_and_counts_them():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launcher-selftest", "--steps", "7"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["backend"] == "gloo"
+    assert line["frames"] == 14.0 and line["seconds"] == 1.5          # sum over ranks / max over ranks
+    assert sum(1 for ln in r.stdout.splitlines() if ln.startswith("{")) == 1      # ONE line, from rank 0
+
+
+def test_bench_single_rank_needs_no_group():
+    r = subprocess.run([sys.executable, BENCH, "--launcher-selftest", "--steps", "5"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _last_json(r.stdout)["n_gpus"] == 1
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """--gpus 2 on a node with fewer than 2 GPUs fails in the launcher (before any rank starts) unless the backend is gloo."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a node with fewer than 2 GPUs")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1"], env=_env(VIDC_DIST_BACKEND="nccl"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "needs 2 GPUs" in r.stderr
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """A launcher that starts another number of ranks than --gpus says is an error, not a line with the wrong n_gpus."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--launcher-selftest"], env=_env(RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 4 but the launcher started 1" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_two_gloo_ranks_on_one_gpu():
+    """The whole bench (timed region between barriers, parity check, gather) with two ranks sharing the one GPU over gloo."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-fp32-leg",
+                        "--no-sequential-leg"], env=_env(VIDC_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["steps"] == 4 and abs(line["value"] * line["ms_per_step"] * 1e-3 - 2.0) < 1e-2      # 2 ranks x 4 frames / max time
+
+
+def _nccl_world1(port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      VIDC_DIST_WORLD1="1")       # a world of one still goes through RCCL (sharding.collectives_active)
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev)
+    return dist, dev
+
+
+@pytest.mark.gpu
+def test_rccl_world_size_one_runs_every_collective_of_the_package():
+    """RCCL itself executes (a world of one GPU): the metric gather on a device record, the evaluation all-reduce, and the training
+    step's bucketed gradient all-reduce on device buffers incl. the overlapped (two-bucket) path -- same code the 8-GPU job runs."""
+    code = r'''
+import os, sys, socket
+sys.path.insert(0, %r)
+import numpy as np, torch
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+sys.path.insert(0, os.path.join(%r, "tests"))
+from test_bench_launcher import _nccl_world1
+dist, dev = _nccl_world1(port)
+from vi_depth_completion_amd import sharding, evaluation, synthetic as S
+rec = sharding.metric_record(5, 2.0, 1.0, 4.0, device=dev)
+out = [torch.zeros_like(rec)]
+dist.all_gather(out, rec)                      # what gather_records does for world > 1, on the device record
+assert torch.equal(out[0].cpu(), rec.cpu())
+assert sharding.combine(sharding.gather_records(rec))["frames_per_s"] == 2.5
+tot = torch.arange(8, dtype=torch.float64, device=dev)
+evaluation.all_reduce_totals(tot)
+assert torch.equal(tot.cpu(), torch.arange(8, dtype=torch.float64))
+from vi_depth_completion_amd.training import DepthCompletionTrainer
+from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
+torch.manual_seed(0)
+m = ModifiedFPN().to(dev)
+m.load_state_dict(S.seeded_state_dict(m.state_dict(), 7, device=dev))
+ref = ModifiedFPN().to(dev)
+ref.load_state_dict(S.seeded_state_dict(ref.state_dict(), 7, device=dev))
+B, H, W = 2, 64, 96
+img = torch.rand(B, 3, H, W, device=dev); nrm = torch.nn.functional.normalize(torch.randn(B, 3, H, W, device=dev), dim=1)
+dep = torch.rand(B, 1, H, W, device=dev) * (torch.rand(B, 1, H, W, device=dev) < 0.02)
+gt = torch.rand(B, 1, H, W, device=dev) * 4 + 0.5
+m.train(); ref.train()
+t_dist = DepthCompletionTrainer(m, 1e-4)
+assert t_dist._distributed()                   # world of one, collectives forced on
+t_solo = DepthCompletionTrainer(ref, 1e-4)
+t_solo._distributed = lambda: False            # the same steps with no collective at all
+t_solo.buckets.all_reduce_async = lambda *a, **k: []
+for it in range(4):                            # steps 1-2 eager (cut backward + overlapped all-reduce), 3-4 the two captured graphs
+    l1 = t_dist.step(img, nrm, dep, gt)
+    l0 = t_solo.step(img, nrm, dep, gt)
+    assert float(l1) == float(l0), (it, float(l1), float(l0))
+for (k, a), (_, b) in zip(m.state_dict().items(), ref.state_dict().items()):
+    assert torch.equal(a, b), k               # SUM over a world of one = identity: the RCCL path must not change a bit
+torch.cuda.synchronize()
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK")
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=_env(HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout + r.stderr)[-4000:]

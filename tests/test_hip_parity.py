@@ -141,7 +141,7 @@ CONV_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)
-@pytest.mark.parametrize("tile", list(range(28)))       # 14..20, 23, 25: the loader-wave variants; 24..27: 64x64 wave tiles
+@pytest.mark.parametrize("tile", list(range(33)))       # 14..20, 23, 25: the loader-wave variants; 24..27: 64x64 wave tiles; 28..32: 2-deep rings
 def test_conv_tiles(shape, tile):
     from vi_depth_completion_amd import ops
     B, H, W, cin, cout, k, stride, groups = shape
@@ -424,6 +424,26 @@ def pipeline(seeded_weights):
     return p
 
 
+_MODE_PIPES = {}
+
+
+@pytest.fixture(params=["mixed", "fp32"])
+def pipe_mode(request, seeded_weights, monkeypatch):
+    """(pipeline, mode) for both arithmetic modes of the conv stack: "mixed" (default: split-bf16 3-pass MFMA on the layers the measured
+    table selects) and "fp32" (VIDC_PRECISION=fp32: every conv on v_mfma_f32_32x32x2_f32 -- exact fp32 products and sums, the
+    reference's arithmetic, and the second leg bench.py times).  engine.Program reads the mode when a program is recorded, so the
+    variable stays set for the whole test; one pipeline per mode is kept for the module."""
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    mode = request.param
+    monkeypatch.setenv("VIDC_PRECISION", mode)
+    if mode not in _MODE_PIPES:
+        p = DepthCompletionPipeline(enriched_samples=200)
+        p.load_state_dicts(seeded_weights["sn"], seeded_weights["dc"])
+        p.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(240, 320))
+        _MODE_PIPES[mode] = p
+    return _MODE_PIPES[mode], mode
+
+
 def _golden_batch(f, name):
     if name.startswith("demo_"):
         img = torch.from_numpy(f["image_u8"]).permute(2, 0, 1).float().div(255)
@@ -441,22 +461,30 @@ def _intr():
     return O.Intrinsics(202.0, 202.0, 0.5 * 319.87654, 0.5 * 239.87603)
 
 
-GOLDEN_FRAMES = ["demo_000000", "demo_000068", "demo_000085", "synthetic_f0"]
+# (demo_000000_dense: demo_000000 + ~1100 extra sparse depths on plane 2, so that the REFERENCE run that produced the fixture took
+#  plane_offset_ransac's > 300-point branch, main.py:75-78 -- oracle/tools/make_golden.py)
+GOLDEN_FRAMES = ["demo_000000", "demo_000068", "demo_000085", "synthetic_f0", "demo_000000_dense"]
 
 
 @pytest.mark.parametrize("name", GOLDEN_FRAMES)
-def test_surface_normal_net_vs_golden(pipeline, golden_dir, name):
+def test_surface_normal_net_vs_golden(pipe_mode, golden_dir, name):
+    """Unit normals vs the REFERENCE's (golden).  mixed: max 1e-3, mean 2e-5.  fp32 (the reference's arithmetic): max 2e-4, mean 5e-6 --
+    what is left is the warp's sampling-position rounding (module docstring) and fp32 summation order."""
+    pipeline, mode = pipe_mode
     f = np.load(os.path.join(golden_dir, name + ".npz"))
     b = _golden_batch(f, name)
     n = pipeline.surface_normal_cnn(b["image"].to(DEV), b["gravity"].to(DEV), b["aligned_direction"].to(DEV))
     d = np.abs(n[0].cpu().numpy() - f["normals"])
-    assert d.max() < 1e-3 and d.mean() < 2e-5, (d.max(), d.mean())
+    bar_max, bar_mean = (2e-4, 5e-6) if mode == "fp32" else (1e-3, 2e-5)
+    assert d.max() < bar_max and d.mean() < bar_mean, (mode, d.max(), d.mean())
     assert abs(float(n.norm(dim=1).mean()) - 1.0) < 1e-5
 
 
 @pytest.mark.parametrize("name", GOLDEN_FRAMES)
-def test_depth_completion_net_teacher_forced(pipeline, golden_dir, name):
-    """ModifiedFPN fed the reference's own normals and enriched depth: isolates the 337-conv depth network."""
+def test_depth_completion_net_teacher_forced(pipe_mode, golden_dir, name):
+    """ModifiedFPN fed the reference's own normals and enriched depth: isolates the 337-conv depth network.  RMSE vs the reference's
+    depth: mixed < 1e-4, fp32 < 2e-5 (max 2e-4)."""
+    pipeline, mode = pipe_mode
     f = np.load(os.path.join(golden_dir, name + ".npz"))
     b = _golden_batch(f, name)
     en = torch.zeros(240, 320)
@@ -464,7 +492,8 @@ def test_depth_completion_net_teacher_forced(pipeline, golden_dir, name):
     en[rc[:, 0], rc[:, 1]] = torch.from_numpy(f["enriched_val"])
     d = pipeline.cnn(b["image"].to(DEV), torch.from_numpy(f["normals"])[None].to(DEV), en[None, None].to(DEV))[0, 0].cpu().numpy()
     rmse = float(np.sqrt(np.mean((d - f["depth"]) ** 2)))
-    assert rmse < 1e-4 and np.abs(d - f["depth"]).max() < 1e-3, (rmse, np.abs(d - f["depth"]).max())
+    bar_rmse, bar_max = (2e-5, 2e-4) if mode == "fp32" else (1e-4, 1e-3)
+    assert rmse < bar_rmse and np.abs(d - f["depth"]).max() < bar_max, (mode, rmse, np.abs(d - f["depth"]).max())
 
 
 @pytest.mark.parametrize("name", GOLDEN_FRAMES)
@@ -479,7 +508,12 @@ def test_plane_block_vs_golden(pipeline, golden_dir, name):
     normals = torch.from_numpy(f["normals"])[None].to(DEV)
     ds = b["sparse_depth"].to(DEV)
     di, info = pipeline.planes.plane_depth(normals, [S.plane_id_map(240, 320)], ds, b["homogeneous_coordinates"].to(DEV))
-    nnz = [int(info[:-1].sum())]
+    # enrich() first resolves planes with more than 300 sparse points (main.py:75-78; only demo_000000_dense has one: the generator is
+    # rewound, the draws replayed with the offset permutation in place, the plane kernels rerun into the same buffers), then draws
+    en = pipeline.planes.enrich(ds, di, info, 200)                  # same candidate count -> identical draws, same pixels
+    assert bool(pipeline.planes._ctx["dense"]) == (name == "demo_000000_dense")
+    nnz = [int(pipeline.planes.last_nnz[0])]
+    assert nnz[0] == int(info[:-1].sum())
     rec = pipeline.planes.last_records.cpu().numpy()
     for s, slot in enumerate(pipeline.planes.last_slots):
         p = "plane%d" % slot[1]
@@ -494,7 +528,6 @@ def test_plane_block_vs_golden(pipeline, golden_dir, name):
     d = np.abs(di[0, 0].cpu().numpy() - pd)
     assert np.mean(d > 5e-3 * np.maximum(pd, 1.0)) < 1e-3          # fp16 golden copy: 5e-3 relative, <0.1% outliers
     assert abs(float(di.double().sum()) - float(f["plane_depth_sum"])) < 1e-4 * float(f["plane_depth_sum"]) + 20.0
-    en = pipeline.planes.enrich(ds, di, info, 200)                  # same candidate count -> identical draws, same pixels
     assert np.array_equal(pipeline.planes.last_sub[0], f["enrich.sub"])
     rc = f["enriched_rc"]
     e = en[0, 0].cpu().numpy()
@@ -522,6 +555,45 @@ def _plane_scene(seed, H=240, W=320, n_sparse=200, noise=0.02):
     return nrm.permute(2, 0, 1)[None].contiguous(), sd.view(1, 1, H, W), homo[None]
 
 
+def _assert_only_borderline(diff, normals, ids, homo, trace, max_px=5):
+    """`diff` (H,W) bool: pixels that one of (HIP, oracle) wrote a plane depth to and the other did not.  Every such pixel must sit ON
+    one of the two per-pixel decisions of the plane block, evaluated here in fp64 -- the 20-degree inlier test against the winning
+    hypothesis (main.py:47-49) or |homo . n| > 1e-3 (main.py:114-115) -- within fp32 rounding of the compared quantity (angle 2e-3
+    degrees, dot 1e-6); at most `max_px` of them.  A pixel that differs for any other reason fails by name."""
+    px = np.argwhere(diff.numpy())
+    assert len(px) <= max_px, "too many differing pixels: %s" % px[:20].tolist()
+    by_cls = {r["cls"]: r for r in trace}
+    for r_, c_ in px:
+        rec = by_cls.get(int(ids[r_, c_]))
+        assert rec is not None, "pixel (%d,%d) differs outside every plane" % (r_, c_)
+        n_p = normals[0, :, r_, c_].double()
+        ang = float(torch.acos(torch.clamp(n_p @ rec["winner_normal"].double(), -1.0, 1.0)) * (180.0 / np.pi))
+        dot = float(homo[0, r_, c_].double() @ rec["n_bar"].double())
+        assert abs(ang - 20.0) < 2e-3 or abs(abs(dot) - 1e-3) < 1e-6, \
+            "pixel (%d,%d) of plane %d differs but is not borderline: angle to the winning hypothesis %.6f deg, |homo.n| %.3e" % (r_, c_, rec["cls"], ang, abs(dot))
+    return len(px)
+
+
+def _assert_enrichment(planes, ds, di, info, want_di, n_diff, rng_seed_or_rng, rng_w=None):
+    """Enrichment on top of a plane-depth map (main.py:285-294), asserted unconditionally: the HIP draws + scatter on ITS plane depths
+    equal the oracle's enrichment of those same plane depths, pixel set and values exactly; and when the plane depths have no
+    borderline pixel at all (`n_diff == 0`) also the oracle's own end-to-end enrichment."""
+    rng_g = np.random.RandomState(rng_seed_or_rng) if isinstance(rng_seed_or_rng, int) else rng_seed_or_rng
+    state = rng_g.get_state()
+    en = planes.enrich(ds.to(DEV), di, info, 200, rng=rng_g).cpu()
+    replay = np.random.RandomState(0)
+    replay.set_state(state)
+    same_input = O.enrich_sparse_depth(ds, di.cpu(), 200, rng=replay)
+    assert torch.equal(en, same_input), "enrichment of the device's own plane depths differs from the oracle's on the same map"
+    if n_diff == 0:
+        rng_o = rng_w if rng_w is not None else np.random.RandomState(0)
+        if rng_w is None:
+            rng_o.set_state(state)
+        want_en = O.enrich_sparse_depth(ds, want_di[None, None], 200, rng=rng_o)
+        assert torch.equal(en > 0, want_en > 0)
+    return en
+
+
 @pytest.mark.parametrize("case", ["two_planes", "background_only", "plane_without_points", "tiny_plane", "no_sparse_depth", "very_noisy_normals"])
 def test_plane_block_edge_cases_vs_oracle(pipeline, case):
     """The plane block (main.py:130-190) on the shapes of input the reference's loop special-cases: only background (returns its
@@ -542,12 +614,13 @@ def test_plane_block_edge_cases_vs_oracle(pipeline, case):
         ds[0, 0, 101, 55], ds[0, 0, 105, 66] = 2.0, 2.1
     elif case == "no_sparse_depth":
         ds = torch.zeros_like(ds)
-    want = O.extract_plane_depth(normals[0], torch.from_numpy(ids.astype(np.int64)), ds[0, 0], homo[0], rng=np.random.RandomState(3))
+    trace = []
+    want = O.extract_plane_depth(normals[0], torch.from_numpy(ids.astype(np.int64)), ds[0, 0], homo[0], rng=np.random.RandomState(3), trace=trace)
     di, info = pipeline.planes.plane_depth(normals.to(DEV), [ids], ds.to(DEV), homo.to(DEV), rng=np.random.RandomState(3))
     got = di[0, 0].cpu()
     written_w, written_g = (want > 0) & (ds[0, 0] == 0), (got > 0) & (ds[0, 0] == 0)
-    # same planes written (allow a handful of threshold-borderline pixels), same values where both wrote
-    assert int((written_w != written_g).sum()) <= 5, (int(written_w.sum()), int(written_g.sum()))
+    # same planes written; a differing pixel must be one that sits on a per-pixel threshold (checked pixel by pixel in fp64); same values where both wrote
+    n_diff = _assert_only_borderline(written_w != written_g, normals, ids, homo, trace)
     both = written_w & written_g
     if both.any():
         assert ((got - want)[both].abs() / want[both].clamp(min=1.0)).max() < 2e-3
@@ -556,12 +629,8 @@ def test_plane_block_edge_cases_vs_oracle(pipeline, case):
         assert int(written_g.sum()) == 0
     if case == "two_planes":
         assert int(written_g.sum()) > 10000
-    # enrichment on top: same candidate count -> same draws -> same pixels
-    nnz_w = int((want > 0).sum())
-    en = pipeline.planes.enrich(ds.to(DEV), di, info, 200, rng=np.random.RandomState(4))
-    if int(pipeline.planes.last_nnz[0]) == nnz_w:
-        want_en = O.enrich_sparse_depth(ds, want[None, None], 200, rng=np.random.RandomState(4))
-        assert torch.equal((en.cpu() > 0), (want_en > 0))
+    # enrichment on top, unconditionally: same candidates -> same draws -> same pixels and values
+    _assert_enrichment(pipeline.planes, ds, di, info, want, n_diff, 4)
 
 
 @pytest.mark.parametrize("n_sparse,seed", [(3000, 9), (12000, 10), (700, 11)])
@@ -577,6 +646,7 @@ def test_plane_with_more_than_300_points_subsamples_like_the_reference(pipeline,
     want = O.extract_plane_depth(normals[0], torch.from_numpy(ids.astype(np.int64)), ds[0, 0], homo[0], rng=rng_w, trace=trace)
     assert any(r["accepted"] for r in trace)
     di, info = pipeline.planes.plane_depth(normals.to(DEV), [ids], ds.to(DEV), homo.to(DEV), rng=rng_g)
+    # (enrich() resolves the flagged planes -- rewinds rng_g, replays the draws, reruns the plane kernels -- before it draws the samples)
     en = pipeline.planes.enrich(ds.to(DEV), di, info, 200, rng=rng_g).cpu()
     assert pipeline.planes._ctx["dense"], "the scene was built to put > 300 sparse points on a plane"
     got = di[0, 0].cpu()
@@ -587,16 +657,27 @@ def test_plane_with_more_than_300_points_subsamples_like_the_reference(pipeline,
             assert int(rec[k, 9]) == r["n_off_inl"], (k, rec[k], r)
             assert abs(rec[k, 3] - r["offset"]) < 1e-4 * max(1.0, abs(r["offset"]))
     written_w, written_g = (want > 0) & (ds[0, 0] == 0), (got > 0) & (ds[0, 0] == 0)
-    assert int((written_w != written_g).sum()) <= 5, (int(written_w.sum()), int(written_g.sum()))
+    n_diff = _assert_only_borderline(written_w != written_g, normals, ids, homo, trace)
     both = written_w & written_g
     assert both.any()
     assert ((got - want)[both].abs() / want[both].clamp(min=1.0)).max() < 2e-3
     assert torch.equal(got[ds[0, 0] > 0], ds[0, 0][ds[0, 0] > 0])
-    if int(pipeline.planes.last_nnz[0]) == int((want > 0).sum()):
-        want_en = O.enrich_sparse_depth(ds, want[None, None], 200, rng=rng_w)
+    # enrichment, unconditionally: the device's draws on ITS plane depths are the oracle's draws on that same map (the generator stands
+    # where the oracle's stands after the plane block: both consumed the same hypothesis / offset-subsampling draws) ...
+    sub, offs = pipeline.planes.last_sub
+    replay = np.random.RandomState(0)
+    replay.set_state(rng_w.get_state())
+    same_input = O.enrich_sparse_depth(ds, got[None, None], 200, rng=replay)
+    assert torch.equal(en, same_input), "enrichment of the device's own plane depths differs from the oracle's on the same map"
+    # ... and the generator ends where the reference's ends (number and order of ALL host draws), whenever the candidate count is the oracle's
+    want_en = O.enrich_sparse_depth(ds, want[None, None], 200, rng=rng_w)
+    if n_diff == 0:
         assert torch.equal(en > 0, want_en > 0)
+    if int(pipeline.planes.last_nnz[0]) == int((want > 0).sum()):
         sa, sb = rng_w.get_state(), rng_g.get_state()
         assert np.array_equal(sa[1], sb[1]) and sa[2] == sb[2], "host draws diverged from the reference's order"
+    else:
+        assert n_diff > 0      # a different candidate count is only ever explained by borderline pixels, enumerated above
 
 
 def test_dense_depth_input_in_the_pipeline(pipeline, seeded_weights):
@@ -650,15 +731,17 @@ def test_enriched_samples_zero_skips_the_plane_block(pipeline, seeded_weights):
 
 
 @pytest.mark.parametrize("name", GOLDEN_FRAMES)
-def test_full_path_vs_golden(pipeline, golden_dir, name):
-    """The whole _call_cnn (main.py:261-298): RMSE vs the reference's depth <= 1e-3 (north_star bar)."""
+def test_full_path_vs_golden(pipe_mode, golden_dir, name):
+    """The whole _call_cnn (main.py:261-298): RMSE vs the reference's depth <= 1e-3 (north_star bar) in the mixed mode; in the fp32 mode
+    (the reference's arithmetic) < 2e-5."""
+    pipeline, mode = pipe_mode
     f = np.load(os.path.join(golden_dir, name + ".npz"))
     b = _golden_batch(f, name)
     np.random.seed(int(f["np_seed"]))
     taps = {}
     d = pipeline._call_cnn(b, taps=taps)[0, 0].cpu().numpy()
     rmse = float(np.sqrt(np.mean((d - f["depth"]) ** 2)))
-    assert rmse < 1e-3, rmse
+    assert rmse < (2e-5 if mode == "fp32" else 1e-3), (mode, rmse)
     assert d.min() >= 0.0
 
 
@@ -675,11 +758,15 @@ def test_full_path_vs_oracle_batch2(pipeline, seeded_weights):
     assert rmse < 1e-3, rmse
 
 
+@pytest.mark.parametrize("precision", ["mixed", "fp32"])
 @pytest.mark.parametrize("align_corners", [False, True])
-def test_full_path_320x256_batch2_both_modes(seeded_weights, align_corners):
+def test_full_path_320x256_batch2_both_modes(seeded_weights, align_corners, precision, monkeypatch):
     """The bench shape (320x256, SURVEY §0: the reference itself is hard-wired to 320x240, so the resolution-generic oracle is the
-    reference here), batch 2, both grid_sample conventions, sequential _call_cnn and the software-pipelined mode: RMSE <= 1e-3."""
+    reference here), batch 2, both grid_sample conventions, sequential _call_cnn and the software-pipelined mode, both arithmetic
+    modes of the conv stack: RMSE vs the oracle <= 1e-3 (mixed) / 2e-5 (fp32, the leg bench.py reports as value_fp32)."""
     from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    monkeypatch.setenv("VIDC_PRECISION", precision)
+    bar = 2e-5 if precision == "fp32" else 1e-3
     H, W = 256, 320
     cc = (0.5 * 319.87654, 0.5 * 239.87603 * H / 240.0)
     pipe = DepthCompletionPipeline(enriched_samples=200, cc_img=cc, align_corners=align_corners)
@@ -697,7 +784,7 @@ def test_full_path_320x256_batch2_both_modes(seeded_weights, align_corners):
     il = [o.cpu() for o in pipe.run_interleaved(iter(dev_batches))]
     for w_, a, b in zip(want, seq, il):
         assert a.shape == (2, 1, H, W)
-        assert float((a - w_).pow(2).mean().sqrt()) < 1e-3 and float((b - w_).pow(2).mean().sqrt()) < 1e-3
+        assert float((a - w_).pow(2).mean().sqrt()) < bar and float((b - w_).pow(2).mean().sqrt()) < bar, (precision, float((a - w_).pow(2).mean().sqrt()), float((b - w_).pow(2).mean().sqrt()))
 
 
 def test_graph_and_eager_agree(pipeline, monkeypatch):

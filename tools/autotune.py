@@ -26,7 +26,8 @@ from vi_depth_completion_amd.networks.surface_normal import SurfaceNormalPredict
 OUT = os.path.join(ROOT, "vi_depth_completion_amd", "conv_tuning.json")
 TILE_DIMS = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (64, 64), 6: (32, 64), 7: (32, 32), 8: (32, 128), 9: (32, 32),
              10: (32, 64), 11: (32, 32), 12: (32, 128), 13: (64, 64), 14: (32, 64), 15: (32, 64), 16: (32, 32), 17: (64, 64), 18: (64, 64),
-             19: (64, 128), 20: (128, 64), 21: (64, 32), 22: (64, 32), 23: (64, 32), 24: (128, 128), 25: (128, 128), 26: (256, 128), 27: (128, 256)}
+             19: (64, 128), 20: (128, 64), 21: (64, 32), 22: (64, 32), 23: (64, 32), 24: (128, 128), 25: (128, 128), 26: (256, 128), 27: (128, 256),
+             28: (32, 64), 29: (64, 64), 30: (32, 32), 31: (64, 128), 32: (64, 32)}
 
 
 def time_desc(lib, d, st, pool, junk, copies=20):
@@ -93,6 +94,8 @@ def main():
     ap.add_argument("--sigs", default="", help="comma-separated substrings: re-measure only signatures containing one of them (keeps the rest of the table)")
     ap.add_argument("--detector", action="store_true", help="measure the signatures of the plane-mask detector's three programs "
                                                              "(networks/plane_mask_rcnn.py) instead of the depth-completion path's")
+    ap.add_argument("--verbose", action="store_true", help="print every candidate (tile, splitk, us), fastest first, not only the winner")
+    ap.add_argument("--dry", action="store_true", help="measure and print, do not write the table")
     ap.add_argument("--only-missing", action="store_true", help="keep the committed table and measure only signatures it lacks")
     ap.add_argument("--split-charge", type=float, default=0.25,
                     help="fraction of the standalone split-kernel time charged to a bf16x3 conv (most splits are fused into the\n"
@@ -155,6 +158,8 @@ def main():
                                 if us is not None:
                                     cands.append((us, t, sk))
                         cands.sort()
+                        if a.verbose:
+                            print("  %s prec %d: %s" % (sig, prec, "  ".join("%s/sk%d %.1f" % (L.TILE_NAMES[t], sk, us) for us, t, sk in cands[:14])), flush=True)
                         if not cands:
                             raise RuntimeError("no tiling ran for %s (precision %d): %s" % (sig, prec, lib.vidc_last_error().decode()))
                         best[prec] = cands[0]
@@ -171,6 +176,9 @@ def main():
                         sig, L.TILE_NAMES[t32], sk32, us32, L.TILE_NAMES[t16], sk16, us16, t_split, "bf16x3" if prec else "fp32"), flush=True)
             del sn, dc
             torch.cuda.empty_cache()
+    if a.dry:
+        print("dry run: table not written")
+        return
     with open(OUT, "w") as f:
         json.dump(dict(sorted(table.items())), f, indent=0)
     print("wrote %d signatures to %s" % (len(table), OUT))

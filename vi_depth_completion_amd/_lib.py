@@ -24,8 +24,9 @@ OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD,
 TILE_AUTO = 0
 TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "64x64k2", 6: "32x64k2", 7: "32x32k4", 8: "32x128",
               9: "32x32k8", 10: "32x64k2d5", 11: "32x32k4d4", 12: "32x128d6", 13: "64x64k2d4", 14: "32x64k2L", 15: "32x64k2d5L", 16: "32x32k4d4L", 17: "64x64L", 18: "64x64k2d4L",
-              19: "64x128L", 20: "128x64L", 21: "64x32k2", 22: "64x32k2d5", 23: "64x32k2d5L", 24: "128x128d3", 25: "128x128d3L", 26: "256x128", 27: "128x256"}
-TILE_COUNT = 28
+              19: "64x128L", 20: "128x64L", 21: "64x32k2", 22: "64x32k2d5", 23: "64x32k2d5L", 24: "128x128d3", 25: "128x128d3L", 26: "256x128", 27: "128x256",
+              28: "32x64k2d2", 29: "64x64d2", 30: "32x32k4d2", 31: "64x128d2", 32: "64x32k2d2"}
+TILE_COUNT = 33
 PREC_FP32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 SPLITK_COUNTERS = 16384            # VIDC_SPLITK_COUNTERS: ticket counters at the head of a split-K workspace
 
@@ -129,6 +130,8 @@ SIGNATURES = {
     "vidc_resize_coeffs": (C.c_int, [_i, _i, _vp, _vp, _i, C.POINTER(C.c_int)]),
     "vidc_resize_bilinear_u8_to_chw": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "vidc_rasterize_sparse_depth": (C.c_int, [_vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_double, _vp, _i, _i, _vp]),
+    "vidc_nearest_table": (C.c_int, [_i, _i, _vp]),
+    "vidc_resize_nearest_u16_depth": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, C.c_float, _vp]),
     "vidc_depth_metrics_scratch_bytes": (C.c_size_t, [C.c_longlong]),
     "vidc_depth_metrics": (C.c_int, [_vp, _vp, C.c_longlong, _vp, _i, _vp, _vp]),
     "vidc_depth_to_mm_u32": (C.c_int, [_vp, _vp, C.c_longlong, _vp]),

@@ -789,6 +789,11 @@ __global__ void __launch_bounds__(512) conv_chain_kernel(const ChainArgs c) {
     if (tid == 0) {
         const unsigned t = atomicAdd(c.state + 17, 1u);
         if (t == gridDim.x - 1) {
+            // every group's item list must have been walked to its end: a group whose XCD received no workgroup of this launch (CPX
+            // partition, CU mask, fewer than `groups` XCDs) is never claimed and nobody waits on it -- the outputs would be stale with
+            // no time-out anywhere.  Code 0x7FFFFFFF in the sticky error word (vidc_chain_status reports layer 0x7FFFFFFE).
+            for (int gi = 0; gi < c.groups; ++gi)
+                if (__hip_atomic_load(c.state + 8 + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)c.total_items) atomicCAS(c.state + 16, 0u, 0x7FFFFFFFu);      // (a time-out code set earlier stays)
             for (int i = 0; i < 16; ++i) atomicExch(c.state + i, 0u);
             atomicExch(c.state + 17, 0u);
         }
@@ -880,6 +885,12 @@ constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {
     {128, 128, 2, 2, 1, 3},   // VIDC_TILE_128x128_D3_L
     {256, 128, 4, 2, 1, 3},   // VIDC_TILE_256x128   (8 waves, 144 KB of LDS)
     {128, 256, 2, 4, 1, 3},   // VIDC_TILE_128x256
+    // ---- 2-deep rings: 32-48 KB of LDS, so that >= 3 workgroups (of one or of several streams' launches) share a CU ----
+    {32, 64, 1, 2, 2, 2},     // VIDC_TILE_32x64_K2_D2   48 KB
+    {64, 64, 2, 2, 1, 2},     // VIDC_TILE_64x64_D2      32 KB
+    {32, 32, 1, 1, 4, 2},     // VIDC_TILE_32x32_K4_D2   64 KB
+    {64, 128, 2, 2, 1, 2},    // VIDC_TILE_64x128_D2     48 KB
+    {64, 32, 2, 1, 2, 2},     // VIDC_TILE_64x32_K2_D2   48 KB
 };
 constexpr int kFirstLoaderTile = VIDC_TILE_32x64_K2_L;
 
@@ -1050,6 +1061,11 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         case VIDC_TILE_128x128_D3_L:   rc = launch_tile<128, 128, 2, 2, 1, 3, 1>(a, st, dd.precision); break;
         case VIDC_TILE_256x128:        rc = launch_tile<256, 128, 4, 2, 1, 3>(a, st, dd.precision); break;
         case VIDC_TILE_128x256:        rc = launch_tile<128, 256, 2, 4, 1, 3>(a, st, dd.precision); break;
+        case VIDC_TILE_32x64_K2_D2:    rc = launch_tile<32, 64, 1, 2, 2, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_64x64_D2:       rc = launch_tile<64, 64, 2, 2, 1, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_32x32_K4_D2:    rc = launch_tile<32, 32, 1, 1, 4, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_64x128_D2:      rc = launch_tile<64, 128, 2, 2, 1, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_64x32_K2_D2:    rc = launch_tile<64, 32, 2, 1, 2, 2>(a, st, dd.precision); break;
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
     return rc;
@@ -1100,6 +1116,8 @@ extern "C" int vidc_chain_create(const vidc_conv_desc* descs, int n, vidc_chain*
         vidc_conv_desc dd = descs[i];
         VIDC_REQUIRE(dd.groups == descs[0].groups && dd.groups <= 8, VIDC_ERR_SHAPE, "vidc_chain_create: every conv needs the same <= 8 groups (one XCD each)");
         VIDC_REQUIRE(dd.precision == descs[0].precision, VIDC_ERR_SHAPE, "vidc_chain_create: one arithmetic mode per chain");
+        VIDC_REQUIRE(dd.precision == VIDC_PREC_FP32 || dd.precision == VIDC_PREC_BF16X3, VIDC_ERR_SHAPE,
+                     "vidc_chain_create: the chain kernel is instantiated for fp32 and bf16x3 operands only (plain bf16 would run the fp32 kernel on packed bf16 data)");
         dd.tile = kChainTile;
         dd.splitk = 1;
         rc = make_args(dd, layers[i].a);

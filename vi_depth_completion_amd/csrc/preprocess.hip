@@ -79,7 +79,46 @@ rasterize_sparse_kernel(const double* __restrict__ tracks, const int32_t* __rest
     }
 }
 
+// Ground-truth depth of the training / evaluation streams (dataset.py:283-286: 16-bit millimetre PNG -> convert('F') -> Image.resize(...,
+// NEAREST) -> / 1000.0): one gather per output pixel through the two index tables of vidc_nearest_table, IEEE fp32 division.
+__global__ void __launch_bounds__(256)
+nearest_u16_depth_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, int H, int W, int Ho, int Wo,
+                         const int32_t* __restrict__ xtab, const int32_t* __restrict__ ytab, float divisor) {
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Ho * Wo) return;
+    const int yo = idx / Wo, xo = idx - yo * Wo;
+    const int ys = ytab[yo], xs = xtab[xo];
+    // (a table entry outside the image is Pillow's "fill" case: the output pixel stays 0; it cannot occur for a whole-image box)
+    const float v = (ys >= 0 && ys < H && xs >= 0 && xs < W) ? (float)src[((size_t)b * H + ys) * W + xs] : 0.f;
+    dst[(size_t)b * Ho * Wo + idx] = __fdiv_rn(v, divisor);
+}
+
 }  // namespace
+
+// Host function (no GPU): the source index of every output coordinate of Pillow's Image.resize(..., NEAREST) along one axis
+// (src/libImaging/Geometry.c ImagingScaleAffine: xo = a0 * 0.5, then xo += a0 per output pixel IN DOUBLE -- the accumulated sum, not
+// (x + 0.5) * a0 --, index = xo < 0 ? -1 : (int)xo).
+extern "C" int vidc_nearest_table(int in_size, int out_size, int32_t* table) {
+    VIDC_REQUIRE(in_size > 0 && out_size > 0 && table, VIDC_ERR_SHAPE, "vidc_nearest_table: bad arguments");
+    const double a0 = (double)in_size / (double)out_size;
+    double xo = a0 * 0.5;
+    for (int x = 0; x < out_size; ++x) {
+        table[x] = xo < 0.0 ? -1 : (int)xo;
+        xo += a0;
+    }
+    return VIDC_OK;
+}
+
+extern "C" int vidc_resize_nearest_u16_depth(const uint16_t* src, float* dst, int B, int H, int W, int Ho, int Wo, const int32_t* xtab,
+                                             const int32_t* ytab, float divisor, vidc_stream_t stream) {
+    VIDC_REQUIRE(src && dst && xtab && ytab, VIDC_ERR_NULL, "vidc_resize_nearest_u16_depth: null pointer");
+    VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && divisor != 0.f, VIDC_ERR_SHAPE, "vidc_resize_nearest_u16_depth: bad shape");
+    dim3 grid((Ho * Wo + 255) / 256, B, 1);
+    hipLaunchKernelGGL(nearest_u16_depth_kernel, grid, dim3(256), 0, vidc::as_stream(stream), src, dst, H, W, Ho, Wo, xtab, ytab, divisor);
+    VIDC_CHECK_LAUNCH("nearest_u16_depth_kernel");
+    return VIDC_OK;
+}
 
 // Host function (no GPU): Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bilinear filter over the full input range.
 extern "C" int vidc_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* coeffs, int coeffs_capacity, int* ksize_out) {

@@ -158,7 +158,7 @@ def default_precision(flops):
 
 
 # LDS bytes of the tilings (NS * (BM + BN) * 32 floats * WKW) and, for the co-residency experiment, the nearest tiling of at most 80 KB
-_TILE_LDS_KB = {1: 64, 2: 72, 3: 72, 4: 64, 5: 96, 6: 72, 7: 96, 8: 80, 9: 128, 10: 120, 11: 128, 12: 120, 13: 128, 14: 72, 15: 120, 16: 128, 17: 64,
+_TILE_LDS_KB = {28: 48, 29: 32, 30: 64, 31: 48, 32: 48, 1: 64, 2: 72, 3: 72, 4: 64, 5: 96, 6: 72, 7: 96, 8: 80, 9: 128, 10: 120, 11: 128, 12: 120, 13: 128, 14: 72, 15: 120, 16: 128, 17: 64,
                 18: 128, 19: 72, 20: 72, 21: 72, 22: 120, 23: 120, 24: 96, 25: 96, 26: 144, 27: 144}
 _TILE_SMALL = {5: 4, 13: 4, 18: 4, 7: 6, 9: 6, 10: 6, 11: 6, 15: 6, 16: 6, 12: 8, 22: 21, 23: 21, 24: 1, 25: 1, 26: 1, 27: 1}
 
@@ -515,6 +515,9 @@ class Program:
                 d.tile, d.splitk = ent[3], ent[4]
             else:
                 L.check(lib.vidc_conv2d_plan(C.byref(d)), "conv plan")
+        if os.environ.get("VIDC_TILE_REMAP"):          # experiment knob: "6:28,10:28" replaces tile 6 and 10 by 28 wherever the table picked them
+            remap = dict((int(a), int(b)) for a, b in (kv.split(":") for kv in os.environ["VIDC_TILE_REMAP"].split(",") if kv))
+            d.tile = remap.get(d.tile, d.tile)
         if os.environ.get("VIDC_LDS_CAP_KB"):          # experiment knob (tools/dual_stream_bench.py): tilings that leave room for a second
             d.tile = _capped_tile(d.tile, int(os.environ["VIDC_LDS_CAP_KB"]))      # workgroup of another stream on the CU
         self._keep += [wp, s1, b1]
@@ -835,6 +838,9 @@ class Program:
         for h in self._chains:
             failed = C.c_int(-1)
             L.check(L.lib().vidc_chain_status(h, C.byref(failed)), "chain_status")
+            if failed.value == 0x7FFFFFFE:
+                raise RuntimeError("persistent conv chain: a group's items were never claimed (no workgroup of the launch ran on its XCD: "
+                                   "partitioned device or CU mask?) -- its outputs are stale")
             if failed.value >= 0:
                 raise RuntimeError("persistent conv chain: the wait for layer %d timed out (no workgroup on the group's XCD?)" % failed.value)
 

@@ -121,7 +121,8 @@ class NormalErrorStats:
 def all_reduce_totals(totals):
     """In-place SUM of the 8 running totals over ranks: the whole cross-GPU traffic of a frame-sharded evaluation (64 bytes)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    from .sharding import collectives_active
+    if collectives_active():
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
     return totals
 

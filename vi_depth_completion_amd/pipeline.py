@@ -255,9 +255,11 @@ class DepthCompletionPipeline:
 
         Data movement per tick: the frame is copied into the program's input buffer once (and from there to the depth
         network's image input one tick later, device to device); the normals and the enriched sparse depth are WRITTEN where the
-        next tick reads them (no copies).  The caller's tensors are not referenced after the call that consumed them.
-        copy_outputs=False hands out the program's own output buffer: valid until the next item is requested (with L lanes: until
-        L more items have been requested)."""
+        next tick reads them (no copies).  The caller's tensors are not referenced after the call that consumed them (with L > 1 a
+        device-resident `sparse_depth` is copied once: its enrichment is finished one visit later, when the caller may have refilled
+        the buffer).
+        copy_outputs=False hands out the program's own output buffer: valid ONLY until the next item is requested, for every L (the
+        yielding lane's next visit relaunches its depth decoder into that buffer)."""
         import os
         if not self.use_gravity:
             raise NotImplementedError("run_interleaved pipelines the gravity-aligned surface-normal network; use _call_cnn with use_gravity=False")
@@ -368,6 +370,7 @@ class _Lane:
     def __init__(self, pipe, index, own_stream):
         self.pipe, self.index = pipe, index
         self.prog, self.shape0, self.have_prev, self.pending_out, self.pending_enrich, self._frame = None, None, False, None, None, None
+        self._ds_own = None
         self._stage = pipe.__dict__.setdefault("_lane_stagers", {}).setdefault(index, _Stager())
         cache = pipe.__dict__.setdefault("_lane_cache", {})
         ent = cache.setdefault(index, {})
@@ -409,6 +412,11 @@ class _Lane:
             pipe, dev = self.pipe, self.pipe.device
             rgb = self._stage("image", batch["image"], dev)
             ds = self._stage("sparse_depth", batch["sparse_depth"], dev)
+            if ds is batch["sparse_depth"]:               # the caller's own device tensor: finish_enrich reads it one visit later, by when a
+                if self._ds_own is None or self._ds_own.shape != ds.shape:      # caller that refills a fixed input buffer holds the NEXT frame
+                    self._ds_own = torch.empty_like(ds)
+                self._ds_own.copy_(ds, non_blocking=True)
+                ds = self._ds_own
             self._prepare(rgb)
             prog = self.prog
             if self.have_prev:

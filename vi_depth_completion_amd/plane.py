@@ -202,7 +202,8 @@ class PlaneBlock:
         if not normals.is_cuda:
             raise RuntimeError("PlaneBlock runs on the GPU only (no CPU fallback)")
         self._ctx = {"normals": normals.contiguous(), "ids": id_maps, "ds": sparse_depth.contiguous(), "homo": homo.contiguous(),
-                     "rng": rng, "state0": rng.get_state(), "dense": {}}
+                     "rng": rng, "state0": (rng.get_state() if hasattr(rng, "get_state") else None), "dense": {}}      # (np.random.Generator
+        #                                                 and stub generators have no legacy state: fine until a plane needs the rewind below)
         return self._launch(self._ctx)
 
     def _launch(self, ctx):
@@ -266,6 +267,9 @@ class PlaneBlock:
         until no slot is flagged.  The draws before the first flagged plane are reproduced bit for bit."""
         ctx = self._ctx
         di = info = None
+        if ctx["state0"] is None:
+            raise RuntimeError("plane block: a plane carries more than 300 sparse-depth points (main.py:75-78) and the draws of this batch have "
+                               "to be replayed, which needs a generator with get_state()/set_state() (np.random or np.random.RandomState)")
         while info_h[-1] != 0:
             rec = self.last_records.cpu().numpy()
             flagged = [k for k in np.flatnonzero(rec[:, 10] < 0) if k not in ctx["dense"]]

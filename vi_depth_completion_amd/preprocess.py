@@ -31,6 +31,13 @@ def resize_tables(in_size, out_size):
     return bounds, coeffs
 
 
+def nearest_table(in_size, out_size):
+    """int32 [out]: source index of every output coordinate of Pillow's NEAREST resize along one axis (host computation in libvidc)."""
+    t = np.zeros(out_size, np.int32)
+    L.check(L.lib().vidc_nearest_table(in_size, out_size, t.ctypes.data), "nearest_table")
+    return t
+
+
 def gravity_and_alignment(gravity_raw):
     """dataset.py:472-483, host, torch CPU fp32 like the reference."""
     g = torch.tensor(np.asarray(gravity_raw, dtype=np.float64), dtype=torch.float)
@@ -70,6 +77,7 @@ class FramePreprocessor:
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
         self.bx, self.kx, self.by, self.ky = up(bx), up(kx), up(by), up(ky)
         self.homogeneous = homogeneous_coordinates(fc, cc, out_hw[1], out_hw[0]).to(self.device)
+        self.nx, self.ny = up(nearest_table(in_hw[1], out_hw[1])), up(nearest_table(in_hw[0], out_hw[0]))
 
     def resize(self, image_u8):
         """(B,H,W,C) uint8 on the device -> (B,C,Ho,Wo) float32 = ToTensor(PIL bilinear resize)."""
@@ -82,6 +90,21 @@ class FramePreprocessor:
         y = torch.empty((B, Cc, Ho, Wo), dtype=torch.float32, device=x.device)
         L.check(L.lib().vidc_resize_bilinear_u8_to_chw(L.ptr(x), L.ptr(y), B, H, W, Cc, Ho, Wo, L.ptr(self.bx), L.ptr(self.kx), self.ksx,
                                                        L.ptr(self.by), L.ptr(self.ky), self.ksy, L.current_stream()), "resize")
+        return y
+
+    def gt_depth(self, depth_u16, millimetres_per_metre=1000.0):
+        """(B,H,W) uint16 millimetre depth maps on the device -> (B,1,Ho,Wo) float32 metres: the ground truth of the training and
+        evaluation streams, `Image.open(d).convert('F').resize((320, 240), resample=Image.NEAREST)` then `/ 1000.0`
+        (dataset.py:283-286), bit for bit -- `sample['depth']` of network_run.py:165-172, 216-225 without a PIL pass per frame."""
+        if not depth_u16.is_cuda or depth_u16.dtype not in (torch.uint16, torch.int16):
+            raise RuntimeError("gt_depth() takes a uint16 GPU tensor (B,H,W) (a 16-bit depth PNG as the camera driver delivers it)")
+        x = depth_u16.contiguous()
+        B, H, W = x.shape
+        assert (H, W) == self.in_hw, "tables were built for %s input, got %s" % (self.in_hw, (H, W))
+        Ho, Wo = self.out_hw
+        y = torch.empty((B, 1, Ho, Wo), dtype=torch.float32, device=x.device)
+        L.check(L.lib().vidc_resize_nearest_u16_depth(L.ptr(x), L.ptr(y), B, H, W, Ho, Wo, L.ptr(self.nx), L.ptr(self.ny), float(millimetres_per_metre),
+                                                      L.current_stream()), "gt_depth")
         return y
 
     def _upload(self, t):
@@ -107,12 +130,17 @@ class FramePreprocessor:
         self._keep = (tr, of)
         return d
 
-    def __call__(self, image_u8, gravity_raw, klt_tracks):
-        """The collated batch dictionary of DemoDataset (dataset.py:515-520), on the device."""
+    def __call__(self, image_u8, gravity_raw, klt_tracks, depth_u16=None):
+        """The collated batch dictionary of DemoDataset (dataset.py:515-520), on the device; with `depth_u16` also the 'depth' entry of
+        the Azure / ScanNet loaders (dataset.py:283-286, 349)."""
         img = image_u8 if torch.is_tensor(image_u8) else torch.from_numpy(np.ascontiguousarray(image_u8))
         img = img.to(self.device, non_blocking=True)
         B = img.shape[0]
         ga = [gravity_and_alignment(g) for g in np.asarray(gravity_raw, dtype=np.float64).reshape(B, 3)]
-        return {"image": self.resize(img), "sparse_depth": self.rasterize(klt_tracks),
-                "gravity": self._upload(torch.stack([g for g, _ in ga])), "aligned_direction": self._upload(torch.stack([a for _, a in ga])),
-                "homogeneous_coordinates": self.homogeneous.unsqueeze(0).expand(B, -1, -1, -1)}
+        out = {"image": self.resize(img), "sparse_depth": self.rasterize(klt_tracks),
+               "gravity": self._upload(torch.stack([g for g, _ in ga])), "aligned_direction": self._upload(torch.stack([a for _, a in ga])),
+               "homogeneous_coordinates": self.homogeneous.unsqueeze(0).expand(B, -1, -1, -1)}
+        if depth_u16 is not None:
+            d16 = depth_u16 if torch.is_tensor(depth_u16) else torch.from_numpy(np.ascontiguousarray(depth_u16))
+            out["depth"] = self.gt_depth(d16.to(self.device, non_blocking=True))
+        return out

@@ -4,8 +4,19 @@ of a run (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).  Th
 `torch.nn.DataParallel` (network_run.py:97-99), which re-broadcasts 1.24 GB of parameters on every forward and wraps
 only the depth network."""
 import math
+import os
 
 import torch
+
+
+def collectives_active():
+    """True when this process is one rank of a job whose collectives must run: a process group of more than one rank -- or of exactly
+    one rank with VIDC_DIST_WORLD1=1, which sends every collective of the package through the backend anyway (a 1-GPU box can then
+    execute the RCCL code paths the 8-GPU job uses: tests/test_bench_launcher.py)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("VIDC_DIST_WORLD1", "0") == "1"
 
 
 def frames_of_rank(rank, world, n_frames_total):
@@ -20,7 +31,7 @@ def metric_record(n_frames, seconds, sum_sq_err=0.0, n_px=0.0, device="cpu"):
 def gather_records(rec):
     """all_gather of the 4-double record of every rank -> (world, 4) CPU tensor.  Single-process: (1, 4)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return rec.detach().cpu()[None]
     if dist.get_backend() == "gloo":
         rec = rec.detach().cpu()

@@ -87,7 +87,8 @@ class GradientBuckets:
         stream, and overlap whatever is enqueued next -- the decoder's gradients travel while the pyramids' backward runs
         (DepthCompletionTrainer.step).  gloo (trying the N > 1 path on a box without a second GPU): through the host, synchronous."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        from .sharding import collectives_active
+        if not collectives_active():
             return []
         hi = flat.numel() if hi is None else hi
         stage = dist.get_backend() == "gloo" and flat.is_cuda
@@ -146,6 +147,8 @@ class DepthCompletionTrainer:
         self._pack_items, self._pack_table, self._packed_fresh = [], None, False
         self.use_graph = os.environ.get("VIDC_TRAIN_GRAPH", "1") != "0"
         self._graphs, self._graph_seen = {}, {}
+        self._retired = []          # outgrown scratch / workspace buffers that captured graphs still address (see _retire)
+        self._keepalive = []        # backward closures already run in the current _run_tape, kept until the stream lanes have joined
         self.tune_hook = None      # tools/autotune_train.py: called with every conv descriptor before it is planned
         self.precision = {"fp32": L.PREC_FP32, "bf16x3": L.PREC_BF16X3, "bf16": L.PREC_BF16}[os.environ.get("VIDC_TRAIN_PRECISION", "fp32")]
         self.last_loss = None
@@ -160,8 +163,17 @@ class DepthCompletionTrainer:
     def _scratch_bytes(self, nbytes):
         sc = self._scratch.get(self._cur)                 # one scratch per stream lane: the lanes run concurrently
         if sc is None or sc.numel() < nbytes:
+            self._retire(sc)
             sc = self._scratch[self._cur] = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
         return sc
+
+    def _retire(self, t):
+        """A scratch / split-K workspace that is being replaced by a larger one.  Captured step graphs of OTHER input shapes hold its raw
+        address (BN / column-sum partials, split-K partial tiles and their ticket counters), so it must never go back to the allocator
+        while such a graph can still be replayed: it is parked for the lifetime of the trainer (the graphs keep using it; new eager
+        steps and new captures use the larger buffer)."""
+        if t is not None and self._graphs:
+            self._retired.append(t)
 
     def _record(self, fn):
         fn._lane = self._cur
@@ -228,6 +240,7 @@ class DepthCompletionTrainer:
         if need:
             ws = self._gemm_ws.get(self._cur)
             if ws is None or ws.numel() * 4 < need:
+                self._retire(ws)
                 ws = self._gemm_ws[self._cur] = torch.zeros(int(need // 4 * 1.5) + 16, dtype=torch.float32, device=self.device)
             d.workspace = L.ptr(ws)
 
@@ -604,10 +617,17 @@ class DepthCompletionTrainer:
         """Runs the recorded backward closures, last first, each on the stream lane it was recorded on.  stop_after_decoder: return once
         the decoder's part is done (its last closure hands the level gradients to the pyramids), leaving the pyramids' closures in
         self.tape for a second call -- the caller starts the all-reduce of the decoder's gradients in between."""
+        # Lifetime of cross-lane tensors: a closure owns the last references to activations / gradients that OTHER lanes still read or
+        # write (levels[l].grad is allocated by a decoder branch on lane 1 and its channel slices are accumulated into by the pyramids on
+        # lanes 2 and 3).  Dropping a closure right after it ran would hand such a block back to the allocating lane's pool while the
+        # other lanes' kernels are still queued -- and inside a captured graph, where the three pyramids are parallel branches and a
+        # freed block is reusable at once, the allocating lane's next temporary could overwrite it.  So every closure that has run is
+        # kept until all lanes have joined the main stream at the end of the tape.
         main = torch.cuda.current_stream()
         forked = []
         while self.tape:
             fn = self.tape.pop()
+            self._keepalive.append(fn)
             lane = getattr(fn, "_lane", 0)
             if lane == 0 or self.n_lanes <= 1:
                 for side in forked:
@@ -615,7 +635,7 @@ class DepthCompletionTrainer:
                 forked = []
                 fn()
                 if stop_after_decoder and getattr(fn, "_decoder_done", False):
-                    return
+                    return                                # (closures stay parked: the second call releases them after its join)
                 continue
             side = self._lane_streams()[lane - 1]
             if side not in forked:
@@ -627,6 +647,7 @@ class DepthCompletionTrainer:
             self._cur = 0
         for side in forked:
             main.wait_stream(side)
+        self._keepalive = []                              # every lane has joined: nothing queued anywhere still touches these tensors
 
     @torch.no_grad()
     def forward_backward(self, image, normal, depth_in, depth_gt):
@@ -652,8 +673,8 @@ class DepthCompletionTrainer:
         self.cnn._invalidate()          # the inference programs' packed / BN-folded copies are stale now
 
     def _distributed(self):
-        import torch.distributed as dist
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        from .sharding import collectives_active
+        return collectives_active()
 
     def step(self, image, normal, depth_in, depth_gt):
         """One `_run_training_iteration`: returns the loss (0-dim fp64 GPU tensor, this rank's frames).
