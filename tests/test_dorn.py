@@ -120,5 +120,37 @@ def test_pipeline_without_gravity_uses_dorn(dorn_weights, seeded_weights):
     enriched = O.enrich_sparse_depth(batch["sparse_depth"], di[None, None], 200, rng=rng)
     want = O.depth_completion_forward(seeded_weights["dc"], batch["image"], normals, enriched)
     assert float((got - want).pow(2).mean().sqrt()) < 1e-3
-    with pytest.raises(NotImplementedError):
-        next(pipe.run_interleaved(iter([batch])))
+
+
+@gpu
+def test_run_interleaved_without_gravity_equals_sequential(dorn_weights, seeded_weights):
+    """`run_interleaved` with use_gravity=False: the DORN network + plane block of frame t on one HIP stream beside the enrichment and
+    depth network of frame t-1 on another (pipeline._run_interleaved_two_programs).  Same programs and the same order of random
+    draws as back-to-back `_call_cnn` calls: every depth map bit-identical, also with a sparse-depth input dense enough for the
+    > 300-point branch (main.py:75-78) and with enriched_samples = 0."""
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    pipe = DepthCompletionPipeline(enriched_samples=200, use_gravity=False)
+    pipe.load_state_dicts(dorn_weights, seeded_weights["dc"])
+    pipe.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(240, 320))
+    frames = [S.synthetic_batch(1, 240, 320, 1234, frame0=300 + i) for i in range(4)]
+    g = torch.Generator().manual_seed(3)
+    pix = torch.randperm(240 * 320, generator=g)[:4000]
+    frames[2]["sparse_depth"] = frames[2]["sparse_depth"].clone()
+    frames[2]["sparse_depth"].view(-1)[pix] = 1.0 + 3.0 * torch.rand(4000, generator=g)
+    dev_frames = [{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in f.items()} for f in frames]
+    for es in (200, 0):
+        pipe.args.enriched_samples = es
+        pipe.rng = np.random.RandomState(11)
+        seq = [pipe._call_cnn(f).cpu() for f in dev_frames]
+        pipe.rng = np.random.RandomState(11)
+        il = [o.cpu() for o in pipe.run_interleaved(iter(dev_frames))]
+        assert len(il) == len(seq) == 4
+        for i, (a, b) in enumerate(zip(seq, il)):
+            assert torch.equal(a, b), "frame %d differs (enriched_samples=%d)" % (i, es)
+        assert not torch.equal(seq[0], seq[1])
+    pipe.rng = np.random.RandomState(11)
+    pipe.args.enriched_samples = 200
+    host = [o.cpu() for o in pipe.run_interleaved(iter(frames), copy_outputs=False)]       # host-resident batches, program-owned outputs
+    pipe.rng = np.random.RandomState(11)
+    again = [pipe._call_cnn(f).cpu() for f in dev_frames]
+    assert all(torch.equal(a, b) for a, b in zip(again, host))

@@ -903,6 +903,33 @@ def test_run_interleaved_lanes_are_bit_identical(pipeline):
         pipeline.rng = saved
 
 
+@pytest.mark.parametrize("precision", ["mixed", "fp32"])
+def test_first_and_drain_tick_variants_are_bit_identical(seeded_weights, precision, monkeypatch):
+    """The first tick of a stream runs only the surface-normal side of segment 0 and the drain tick only the three depth-completion
+    pyramids (engine.Program.group_variant: the 4-group pyramid launches restricted to group 0 / groups 1..3 with the grouped launch's
+    tile, split-K and K order).  Against the same stream with full 4-group ticks everywhere (VIDC_TICK_VARIANTS=0): every frame's
+    depth map identical bit for bit, one and two lanes, both arithmetic modes."""
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    monkeypatch.setenv("VIDC_PRECISION", precision)
+    frames = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in S.synthetic_batch(1, 240, 320, 1234, frame0=130 + i).items()} for i in range(5)]
+    runs = {}
+    for variants in ("1", "0"):
+        monkeypatch.setenv("VIDC_TICK_VARIANTS", variants)
+        p = DepthCompletionPipeline(enriched_samples=200)
+        p.load_state_dicts(seeded_weights["sn"], seeded_weights["dc"])
+        p.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(240, 320))
+        for lanes in (1, 2):
+            p.rng = np.random.RandomState(5)
+            runs[(variants, lanes)] = [o.cpu() for o in p.run_interleaved(iter(frames), lanes=lanes)]
+        assert p.frame_program(1, 240, 320).has_variant("head") == (variants == "1")
+        del p
+    for lanes in (1, 2):
+        for f, (a, b) in enumerate(zip(runs[("1", lanes)], runs[("0", lanes)])):
+            assert torch.equal(a, b), "frame %d differs between trimmed and full first/drain ticks (%d lanes, %s)" % (f, lanes, precision)
+    assert all(torch.equal(a, b) for a, b in zip(runs[("1", 1)], runs[("1", 2)]))
+    assert not torch.equal(runs[("1", 1)][0], runs[("1", 1)][1])
+
+
 def test_run_interleaved_golden(pipeline, golden_dir):
     """The reference's golden depth for a demo frame, reached through the software-pipelined mode (RMSE <= 1e-3)."""
     name = GOLDEN_FRAMES[0]

@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--sigs", default="", help="comma-separated substrings: re-measure only signatures containing one of them (keeps the rest of the table)")
     ap.add_argument("--detector", action="store_true", help="measure the signatures of the plane-mask detector's three programs "
                                                              "(networks/plane_mask_rcnn.py) instead of the depth-completion path's")
+    ap.add_argument("--fp32-only", action="store_true", help="re-measure only the exact-fp32 configuration of every signature (entries [3], [4] of the "
+                                                              "table, and [0], [1] where the mixed mode runs the layer in fp32 too); the bf16x3 choice stays")
+    ap.add_argument("--frame-only", action="store_true", help="only the signatures of the software-pipelined frame program (what bench.py times)")
     ap.add_argument("--verbose", action="store_true", help="print every candidate (tile, splitk, us), fastest first, not only the winner")
     ap.add_argument("--dry", action="store_true", help="measure and print, do not write the table")
     ap.add_argument("--only-missing", action="store_true", help="keep the committed table and measure only signatures it lacks")
@@ -106,8 +109,11 @@ def main():
     engine._TUNING = {}                      # measure against the cost-model plan, not an older table
     os.environ["VIDC_PRECISION"] = "fp32"      # record the programs with fp32 inputs (no split ops); both modes are timed below
     table, report = {}, []
-    if (a.only_missing or a.sigs) and os.path.exists(OUT):
+    if (a.only_missing or a.sigs or a.fp32_only) and os.path.exists(OUT):
         table = json.load(open(OUT))
+    old_table = dict(table)
+    if a.fp32_only:
+        table = {}
     if a.sigs:
         pats = [v for v in a.sigs.split(",") if v]
         table = {k: v for k, v in table.items() if not any(pt in k for pt in pats)}
@@ -129,7 +135,8 @@ def main():
                 det = GeneralizedRCNN().to(dev).eval()
                 progs = det.programs(B, H, 320, dev)
             else:
-                progs = (sn.program(B, dev), dc.program(B, H, 320, dev), build_frame_program(sn, dc, B, H, 320, dev))
+                progs = (build_frame_program(sn, dc, B, H, 320, dev),) if a.frame_only else \
+                    (sn.program(B, dev), dc.program(B, H, 320, dev), build_frame_program(sn, dc, B, H, 320, dev))
             for prog in progs:
                 for op, name in zip(prog.c_ops, prog.op_names):
                     if op.kind != L.OP_CONV:
@@ -142,7 +149,7 @@ def main():
                     d.flags &= ~L.ACCUM                     # timing launches must not accumulate into live data forever
                     M = d.B * d.Ho * d.Wo
                     best = {}
-                    for prec in (0, 1):
+                    for prec in ((0,) if a.fp32_only else (0, 1)):
                         d.precision = prec
                         cands = []
                         for t, (bm, bn) in TILE_DIMS.items():
@@ -163,6 +170,18 @@ def main():
                         if not cands:
                             raise RuntimeError("no tiling ran for %s (precision %d): %s" % (sig, prec, lib.vidc_last_error().decode()))
                         best[prec] = cands[0]
+                    if a.fp32_only:
+                        us32, t32, sk32 = best[0]
+                        ent = list(old_table.get(sig, [t32, sk32, 0, t32, sk32]))
+                        if len(ent) < 5:
+                            ent = ent[:3] + [t32, sk32] if len(ent) == 3 else [ent[0], ent[1], 1, t32, sk32]
+                        was = (L.TILE_NAMES[ent[3]], ent[4])
+                        ent[3], ent[4] = t32, sk32
+                        if ent[2] == 0:
+                            ent[0], ent[1] = t32, sk32
+                        table[sig] = ent
+                        print("%-40s fp32 %-10s sk%-2d %8.1f us   (was %s sk%d)" % (sig, L.TILE_NAMES[t32], sk32, us32, was[0], was[1]), flush=True)
+                        continue
                     # a bf16x3 conv needs its input split first (shared between consumers at best; charged in full here)
                     rows = d.B * d.H * d.W
                     if rows * d.Cin * d.groups > split_dst.numel():          # (the detector's mask head at batch 8: 80 M floats)
@@ -176,6 +195,10 @@ def main():
                         sig, L.TILE_NAMES[t32], sk32, us32, L.TILE_NAMES[t16], sk16, us16, t_split, "bf16x3" if prec else "fp32"), flush=True)
             del sn, dc
             torch.cuda.empty_cache()
+    if a.fp32_only:
+        merged = dict(old_table)
+        merged.update(table)
+        table = merged
     if a.dry:
         print("dry run: table not written")
         return

@@ -824,6 +824,73 @@ class Program:
     def launch(self, stream=None):
         L.check(L.lib().vidc_program_launch(self.handle, stream if stream is not None else L.current_stream()), "program_launch")
 
+    # ---- group-restricted variants of a segment ---------------------------------------------------------------------------
+    def group_variant(self, name, segment, g_lo, g_hi, groups, keep_ungrouped):
+        """A second native program over the SAME buffers, packed weights and tile choices: the ops of `segment` with every
+        `groups`-group launch (fused convs, the max-pool over the grouped stem output, the per-group stem kernels) restricted to groups
+        [g_lo, g_hi), and the segment's other ops kept or dropped.  pipeline.build_frame_program's tick runs the surface-normal pyramid
+        (group 0) and the three depth-completion pyramids (groups 1..3) as 4-group launches; the first tick of a frame stream has no
+        previous frame to complete and the drain tick no new one to start, so they run the variants (0, 1, keep) / (1, 4, drop) and the
+        chip does the work of exactly n frames for n frames.  Per output element nothing changes: a group only selects base pointers
+        (csrc/conv_mfma.hip: `a.x + g * a.x_gs` ...), while tile, split-K partition and K order -- which fix the fp32 summation order --
+        are copied from the grouped launch.  So a frame's result is bit-identical whichever variant computed its pyramids
+        (tests/test_hip_parity.py::test_run_interleaved_lanes_are_bit_identical)."""
+        assert self.handle is not None and 0 <= g_lo < g_hi <= groups
+        b, e = self.segments()[segment]
+        picked = []
+        for i in range(b, e):
+            kind, _r, _w, kw = self.ops[i]
+            if kind == "stem":
+                if g_lo <= kw["g"] < g_hi:
+                    picked.append(i)
+                continue
+            grouped = (kind == "conv" and len(kw["keys"]) == groups) or (kind == "maxpool" and kw["x"].G == groups)
+            if grouped or keep_ungrouped:
+                picked.append(i)
+        ops = (L.Op * len(picked))()
+        for j, i in enumerate(picked):
+            C.memmove(C.byref(ops[j]), C.byref(self.c_ops[i]), C.sizeof(L.Op))
+            kind, _r, _w, kw = self.ops[i]
+            if kind == "conv" and len(kw["keys"]) == groups:
+                d = ops[j].u.conv
+                for field, gs in (("x", d.x_gs), ("w", d.w_gs), ("y", d.y_gs), ("scale1", d.p_gs), ("shift1", d.p_gs), ("scale2", d.p_gs),
+                                  ("shift2", d.p_gs), ("residual", d.r_gs), ("y_split", d.y_gs)):     # every operand is 4 bytes per element
+                    v = getattr(d, field)                                                              # (a split-bf16 unit = 32 x (hi, lo))
+                    if v:
+                        setattr(d, field, v + 4 * g_lo * gs)
+                d.groups = g_hi - g_lo
+            elif kind == "maxpool" and kw["x"].G == groups:
+                g = ops[j].u.g
+                cg = kw["x"].C
+                for k in range(3):                            # x, y, split image: group g sits at channel offset g * C of every pixel row
+                    if g.p[k]:
+                        g.p[k] = g.p[k] + 4 * g_lo * cg
+                g.i[3] = cg * (g_hi - g_lo)
+        h = C.c_void_p()
+        L.check(L.lib().vidc_program_create(ops, len(ops), C.byref(h)), "program_create (variant)")
+        self._variants = getattr(self, "_variants", {})
+        self._variants[name] = {"handle": h, "ops": ops, "captured": False, "indices": picked}
+        return self._variants[name]
+
+    def has_variant(self, name):
+        return name in getattr(self, "_variants", {})
+
+    def run_variant(self, name, stream=None):
+        L.check(L.lib().vidc_program_run(self._variants[name]["handle"], stream if stream is not None else L.current_stream()), "variant_run")
+
+    def capture_variant(self, name, stream=None):
+        v = self._variants[name]
+        L.check(L.lib().vidc_program_capture(v["handle"], stream if stream is not None else L.current_stream()), "variant_capture")
+        v["captured"] = True
+
+    def launch_variant(self, name, stream=None):
+        v = self._variants[name]
+        st = stream if stream is not None else L.current_stream()
+        if v["captured"]:
+            L.check(L.lib().vidc_program_launch(v["handle"], st), "variant_launch")
+        else:
+            L.check(L.lib().vidc_program_run(v["handle"], st), "variant_run")
+
     def time(self, iters=20, use_graph=False, per_op=False, stream=None):
         ms = (C.c_float * 1)()
         per = (C.c_float * len(self.ops))() if per_op else None
@@ -850,5 +917,7 @@ class Program:
                 L.lib().vidc_program_destroy(self.handle)
             for h in getattr(self, "_chains", []):
                 L.lib().vidc_chain_destroy(h)
+            for v in getattr(self, "_variants", {}).values():
+                L.lib().vidc_program_destroy(v["handle"])
         except Exception:
             pass

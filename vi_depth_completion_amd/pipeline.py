@@ -106,6 +106,12 @@ def build_frame_program(sn, dc, B, H, W, device, dry_run=False, weights=None):
     prog.finalize(dry_run)
     if not dry_run:
         prog.storage[kinv.buf][:9].copy_(wp.kinv(device))
+        import os
+        if os.environ.get("VIDC_TICK_VARIANTS", "1") == "1" and not prog.n_chains:
+            # first tick of a stream: only the surface-normal side of segment 0 (pyramid group 0 + decoder + warps); drain tick: only the
+            # depth-completion pyramids (groups 1..3) -- engine.Program.group_variant: same buffers, weights, tiles, bit-identical results
+            prog.group_variant("head", 0, 0, 1, 4, keep_ungrouped=True)
+            prog.group_variant("tail", 0, 1, 4, 4, keep_ungrouped=False)
     return prog
 
 
@@ -262,7 +268,8 @@ class DepthCompletionPipeline:
         yielding lane's next visit relaunches its depth decoder into that buffer)."""
         import os
         if not self.use_gravity:
-            raise NotImplementedError("run_interleaved pipelines the gravity-aligned surface-normal network; use _call_cnn with use_gravity=False")
+            yield from self._run_interleaved_two_programs(batches, copy_outputs)
+            return
         n = int(lanes if lanes is not None else os.environ.get("VIDC_LANES", "1"))
         if n < 1:
             raise ValueError("run_interleaved: lanes must be >= 1")
@@ -310,6 +317,56 @@ class DepthCompletionPipeline:
             out = lane_objs[(k + j) % n].collect()
             if out is not None:
                 yield out
+
+    def _run_interleaved_two_programs(self, batches, copy_outputs):
+        """run_interleaved for `use_gravity=False` (main.py:244-245, 270-271: SurfaceNormalDORN, no warp).  The DORN backbone shares no
+        layer shapes with the depth network's pyramids, so there is no joint 4-group program; the two networks of consecutive frames
+        overlap on two HIP streams instead: stream A runs the normals network + plane block of frame t, stream B the enrichment and
+        the depth network of frame t-1.  Host order per visit: launch normals(t) [no random numbers], wait for frame t-1's candidate
+        counts, draw enrichment(t-1), launch depth(t-1), draw hypotheses(t), launch planes(t) -- the generator is consumed in the order
+        hypotheses(0), enrichment(0), hypotheses(1), ... of back-to-back `_call_cnn` calls, and the programs are `_call_cnn`'s own, so
+        every frame's depth map is bit-identical to the sequential path's (tests/test_dorn.py)."""
+        dev = self.device
+        if getattr(self, "_two", None) is None:
+            self._two = {"a": torch.cuda.Stream(device=dev), "b": torch.cuda.Stream(device=dev), "planes": [PlaneBlock(), PlaneBlock()]}
+        sa, sb, blocks = self._two["a"], self._two["b"], self._two["planes"]
+        main = torch.cuda.current_stream(dev)
+        prev, t = None, 0
+
+        def finish(st):
+            """enrichment + depth network of a frame on stream B; returns its output (the caller's stream waits for it)."""
+            sb.wait_stream(sa)                                    # (normals + plane kernels of this frame; also orders B behind A's copies)
+            with torch.cuda.stream(sb):
+                depth_in = st["ds"]
+                if st["di"] is not None:
+                    depth_in = st["planes"].enrich(st["ds"], st["di"], st["nnz"], self.args.enriched_samples, rng=self.rng, info_host=st["info_host"])
+                out = self.cnn.enqueue(st["rgb"], st["normals"], depth_in, 0)
+                out = out.clone() if copy_outputs else out
+            main.wait_stream(sb)
+            return out
+
+        for batch in batches:
+            sa.wait_stream(main)                                  # the batch comes from the caller's stream
+            sa.wait_stream(sb)                                    # ... and depth(t-2) has consumed what this visit overwrites
+            with torch.cuda.stream(sa):
+                ds = self._stage("sparse_depth", batch["sparse_depth"], dev)
+                rgb = self._stage("image", batch["image"], dev)
+                ds, rgb = ds.clone(), rgb.clone()                 # live until frame t's depth network has run, one visit later
+                mh = self._masks_begin(rgb) if self.args.enriched_samples != 0 else None
+                normals = self.surface_normal_cnn(rgb)            # (a fresh tensor per call: surface_normal_dorn.forward clones)
+            out = finish(prev) if prev is not None else None
+            st = {"ds": ds, "rgb": rgb, "normals": normals, "di": None, "nnz": None, "info_host": None, "planes": blocks[t % 2]}
+            if self.args.enriched_samples != 0:
+                with torch.cuda.stream(sa):
+                    homo = self._stage("homogeneous_coordinates", batch["homogeneous_coordinates"], dev)
+                    masks = self._masks_end(mh, batch["image"], ds.shape[-2], ds.shape[-1])
+                    st["di"], st["nnz"] = st["planes"].plane_depth(normals, masks, ds, homo, rng=self.rng)
+                    st["info_host"] = st["planes"].read_info_async(st["nnz"])
+            prev, t = st, t + 1
+            if out is not None:
+                yield out
+        if prev is not None:
+            yield finish(prev)
 
     @torch.no_grad()
     def run_stream(self, batches, in_flight=2, frame_rng=None):
@@ -425,7 +482,7 @@ class _Lane:
             self.sn_image.copy_(rgb, non_blocking=True)
             self.grav.copy_(self._stage("gravity", batch["gravity"], dev).reshape(-1), non_blocking=True)
             self.algn.copy_(self._stage("aligned_direction", batch["aligned_direction"], dev).reshape(-1), non_blocking=True)
-            prog.launch_segment(0) if prog.captured else prog.run_segment(0)
+            self._segment0(new_frame=True)
             self._frame = (batch, rgb, ds, mh)
 
     def phase_b(self, copy_outputs):
@@ -483,11 +540,26 @@ class _Lane:
                 prog.run()            # warm-up outside capture (sets kernel attributes)
                 prog.check_chains()
                 prog.capture_segments()
+                for vname in ("head", "tail"):
+                    if prog.has_variant(vname):
+                        prog.capture_variant(vname)
             torch.cuda.current_stream().wait_stream(side)
         self.sn_image, self.dc_image = prog.tensor(prog.inputs["sn_image"]), prog.tensor(prog.inputs["dc_image"])
         self.dc_depth = prog.tensor(prog.inputs["dc_depth"])
         self.grav = prog.storage[prog.inputs["gravity"].buf][: B * 3]
         self.algn = prog.storage[prog.inputs["aligned"].buf][: B * 3]
+
+    def _segment0(self, new_frame):
+        """Segment 0 of the tick on the current stream: all four pyramids + the surface-normal decoder -- or, at the two ends of a
+        stream, only the part that has work: the surface-normal side when no previous frame waits for its depth network (first tick),
+        the three depth-completion pyramids when no new frame came (drain tick).  Bit-identical per frame (engine.group_variant)."""
+        prog = self.prog
+        if new_frame and not self.have_prev and prog.has_variant("head"):
+            prog.launch_variant("head") if prog.captured else prog.run_variant("head")
+        elif not new_frame and prog.has_variant("tail"):
+            prog.launch_variant("tail") if prog.captured else prog.run_variant("tail")
+        else:
+            prog.launch_segment(0) if prog.captured else prog.run_segment(0)
 
     def collect(self):
         if self.pending_out is None:
@@ -519,7 +591,7 @@ class _Lane:
             self.sn_image.copy_(rgb, non_blocking=True)
             self.grav.copy_(self._stage("gravity", batch["gravity"], dev).reshape(-1), non_blocking=True)
             self.algn.copy_(self._stage("aligned_direction", batch["aligned_direction"], dev).reshape(-1), non_blocking=True)
-            prog.launch_segment(0) if graph else prog.run_segment(0)
+            self._segment0(new_frame=True)
             normals = prog.tensor(prog.outputs["normals"])
             if pipe.args.enriched_samples != 0:
                 homo = self._stage("homogeneous_coordinates", batch["homogeneous_coordinates"], dev)
@@ -529,8 +601,8 @@ class _Lane:
             else:
                 self.dc_depth.copy_(ds, non_blocking=True)     # (segment 0 above has read the previous frame's depth input)
         elif have_prev:
-            # drain tick: no new frame; the pyramids still run 4 groups (group 0 recomputes the last frame's features)
-            prog.launch_segment(0) if graph else prog.run_segment(0)
+            # drain tick: no new frame; only the three depth-completion pyramids of segment 0 run (the "tail" variant)
+            self._segment0(new_frame=False)
         if have_prev:
             prog.launch_segment(1) if graph else prog.run_segment(1)
         if pending is not None:
