@@ -62,6 +62,11 @@ def parse():
                                                                        "rate of the operator the reference's harness calls, network_run.py:294-296)")
     ap.add_argument("--sequential-frames", type=int, default=20)
     ap.add_argument("--cpu-threads", default="8,16,32,64,128", help="thread counts tried for the CPU baseline (one frame each); the best one runs --cpu-frames")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE configs[4] instead of the inference path: one step = one `_run_training_iteration` (network_run.py:231-254) of "
+                         "ModifiedFPN on --batch frames per GPU (train-mode BatchNorm, masked L1 / (H*W), Adam; fwd + dgrad + wgrad on the MFMA conv "
+                         "kernel; VIDC_TRAIN_PRECISION=bf16 is the arithmetic the configuration names), gradients summed over ranks with a "
+                         "bucketed RCCL all-reduce overlapped with the backward")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no GPU work: every rank only joins the process group and gathers a fake record (tests/test_bench_launcher.py runs "
                          "`bench.py --gpus 2 --launcher-selftest` under gloo on the CPU: spawn, rendezvous, gather, the n_gpus check)")
@@ -342,6 +347,59 @@ def measure(args, dev, rank, world, precision):
             "frames": frames, "pre": pre}
 
 
+def train_leg(args, dev, rank, world):
+    """`--train`: the training step of BASELINE configs[4] under the same contract (W untimed + K timed steps between barriers, max over
+    ranks, ONE line from rank 0).  Weak scaling: every rank trains on --batch of its own frames; the data-path collective is the
+    gradient all-reduce (vi_depth_completion_amd/training.py)."""
+    import torch.distributed as dist
+    from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
+    from vi_depth_completion_amd.training import DepthCompletionTrainer
+    B, H, W = args.batch, args.height, args.width
+    cnn = ModifiedFPN().to(dev)
+    cnn.load_state_dict(S.seeded_state_dict(cnn.state_dict(), 1234, device=dev))
+    cnn.train()
+    tr = DepthCompletionTrainer(cnn, 1e-4)
+    b = S.synthetic_batch(B, H, W, 1234, frame0=rank * B)
+    image = b["image"].to(dev)
+    normal = torch.nn.functional.normalize(image - 0.5, dim=1)
+    depth_in = b["sparse_depth"].to(dev)
+    gt = S.synthetic_ground_truth_depth(b["image"], 1234).to(dev)
+    losses = [tr.step(image, normal, depth_in, gt) for _ in range(max(args.warmup, 3))]      # (steps 1-2 eager, 3rd captures the hipGraphs)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(tr.step(image, normal, depth_in, gt))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    rec = sharding.metric_record(args.steps * B, time.perf_counter() - t0, device=dev)
+    got = sharding.gather_records(rec)
+    assert got.shape[0] == world
+    job = sharding.combine(got)
+    if rank == 0:
+        mode = os.environ.get("VIDC_TRAIN_PRECISION", "fp32")
+        # forward + data gradient + weight gradient of every conv: 3 x the forward MACs of ModifiedFPN (247.58 GFLOP at 320x240, SURVEY 8d)
+        gflop = 3.0 * 247.58 * (H * W) / (240.0 * 320.0) * B
+        tf = gflop / 1e3 / (job["seconds"] / args.steps)
+        peak = PEAK_F32_MFMA_TFLOPS if mode == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        print(json.dumps({
+            "metric": "training frames/sec", "value": round(job["frames_per_s"], 3), "unit": "frames/s", "n_gpus": int(got.shape[0]), "steps": args.steps,
+            "warmup": max(args.warmup, 3), "ms_per_step": round(1e3 * job["seconds"] / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32+bf16x3", "bf16": "bf16"}[mode], "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: ModifiedFPN training step (train-mode BatchNorm, masked L1 / (H*W), Adam), %dx%d, batch %d per "
+                                   "GPU, seeded weights and ground truth" % (W, H, B), "height": H, "width": W, "batch_per_gpu": B,
+                       "sharding": "frames over %d rank(s); gradients summed by a bucketed all-reduce overlapped with the backward" % world},
+            "roofline": {"bound": "mfma", "achieved": round(tf * (3 if mode == "bf16x3" else 1), 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(tf * (3 if mode == "bf16x3" else 1) / peak, 4), "traffic": None,
+                         "note": "whole step: 3 x forward conv FLOPs per frame / step time (fwd + dgrad + wgrad launches of the conv kernel; "
+                                 "BatchNorm, pooling, loss and Adam are HBM-bound and inside the same time)"},
+            "cpu_baseline": None, "losses": [round(float(x), 6) for x in losses[-min(len(losses), 6):]]}), flush=True)
+
+
 def main():
     args = parse()
     if "RANK" not in os.environ and args.gpus > 1:
@@ -376,6 +434,14 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
+    if args.train:
+        if args.height == 256 and "--height" not in " ".join(sys.argv):
+            args.height = 240                      # the training fixtures and BASELINE configs[4] use the reference's own 320x240
+        train_leg(args, dev, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     H, W, B = args.height, args.width, args.batch
     # Two legs over the same steps, both inside this process (no re-exec): the default mixed mode (bf16x3 MFMA on the layers the
     # measured table selects) is the headline; the second leg runs EVERY conv in the reference's own arithmetic (fp32 MFMA, exact

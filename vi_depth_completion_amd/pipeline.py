@@ -294,6 +294,24 @@ class DepthCompletionPipeline:
         # order -- hypotheses(i), enrichment(i), hypotheses(i+1), ... -- because enrichment(i) is drawn before hypotheses(i+1) in that
         # visit; the enrichment kernel only has to precede frame i+L's segment on its own lane, which is launched L - 1 visits later.
         waiting = None                          # the lane whose last frame still needs its enrichment
+        # Start of the stream: the first frame of EVERY lane is taken at once and its first segment launched (no random numbers, no host
+        # wait in phase_a) before the host turns to the hypothesis draws of frame 0 -- otherwise lane 1 would sit idle through them.
+        batches = iter(batches)
+        first = []
+        for _ in range(n):
+            try:
+                first.append(next(batches))
+            except StopIteration:
+                break
+        for j, batch in enumerate(first):
+            lane_objs[j].phase_a(batch)
+        for j in range(len(first)):
+            lane = lane_objs[j]
+            k += 1
+            if waiting is not None:
+                waiting.finish_enrich()
+            lane.phase_b(copy_outputs)
+            waiting = lane if lane.pending_enrich is not None else None
         for batch in batches:
             lane = lane_objs[k % n]
             k += 1
@@ -305,14 +323,17 @@ class DepthCompletionPipeline:
                 waiting.finish_enrich()
             lane.phase_b(copy_outputs)
             waiting = lane if lane.pending_enrich is not None else None
-        if waiting is not None:
-            waiting.finish_enrich()
         for j in range(n):                      # drain ticks, oldest pending frame first
             lane = lane_objs[(k + j) % n]
+            if lane is waiting:                 # (the lane of the LAST frame, drained last: the other lanes' drain ticks -- which draw
+                waiting.finish_enrich()         #  nothing and whose frames are already enriched -- are queued before the host waits for
+                waiting = None                  #  that frame's counts, so its surface-normal segment does not run alone)
             out = lane.collect()
             if out is not None:
                 yield out
             lane.launch(None, copy_outputs)
+        if waiting is not None:
+            waiting.finish_enrich()
         for j in range(n):
             out = lane_objs[(k + j) % n].collect()
             if out is not None:

@@ -192,7 +192,7 @@ class PlaneMaskDetector:
                 self._run_stages(images)                       # warm-up outside capture: kernel attributes, every buffer allocated
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # (RCCL's watchdog thread polls events while this thread captures)
                     self._run_stages(inp)
             finally:
                 self._eager = False

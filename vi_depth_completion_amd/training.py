@@ -717,7 +717,7 @@ class DepthCompletionTrainer:
             static = [t.clone() for t in ins]
             torch.cuda.synchronize()
             graph, rest = torch.cuda.CUDAGraph(), None
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # (RCCL's watchdog thread polls events while this thread captures)
                 if multi:
                     pred = self.forward(static[0].float(), static[1].float(), static[2].float())
                     loss = self.loss_and_backward(pred, static[3], stop_after_decoder=True)
@@ -725,7 +725,7 @@ class DepthCompletionTrainer:
                     loss, pred = self.forward_backward(*static)
             if multi:                         # second graph: the pyramids' backward (same memory pool: it reads the first one's tensors)
                 rest = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(rest, pool=graph.pool()):
+                with torch.cuda.graph(rest, pool=graph.pool(), capture_error_mode="thread_local"):
                     self._run_tape()
             ent = self._graphs[key] = (graph, rest, static, loss, pred)
         graph, rest, static, loss, pred = ent
