@@ -53,6 +53,15 @@ def detector(detector_weights):
     return det
 
 
+def _has_match(box, score, boxes, scores):
+    x0, y0 = np.maximum(box[0], boxes[:, 0]), np.maximum(box[1], boxes[:, 1])
+    x1, y1 = np.minimum(box[2], boxes[:, 2]), np.minimum(box[3], boxes[:, 3])
+    inter = np.clip(x1 - x0 + 1, 0, None) * np.clip(y1 - y0 + 1, 0, None)
+    area = (box[2] - box[0] + 1) * (box[3] - box[1] + 1) + (boxes[:, 2] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 1] + 1) - inter
+    iou = inter / area
+    return bool(np.any((iou > 0.98) & (np.abs(scores - score) < 1e-3)))
+
+
 def _check_preprocessing(dev_batch, ref_batch):
     assert torch.equal(dev_batch["image"].cpu(), ref_batch["image"]), "resize + ToTensor must be Pillow's, bit for bit"
     assert torch.equal(dev_batch["sparse_depth"].cpu(), ref_batch["sparse_depth"])
@@ -82,12 +91,33 @@ def test_config2_640x480_batch8_with_plane_head(pipe, detector, detector_weights
         pipe.rng = np.random.RandomState(21)
         got = pipe._call_cnn(dev_batch).cpu()
         ids_dev = [m.copy() for m in pipe._ids_host.numpy()]
-        ids_or = [PM.run_on_tensor(detector_weights, ref_batch["image"][i]) for i in range(B)]
-        same = [bool(np.array_equal(a, b)) for a, b in zip(ids_dev, ids_or)]
-        flipped = [int((a != b).sum()) for a, b in zip(ids_dev, ids_or)]
-        print("configs[2]: id maps identical to the oracle's on %d of %d images; differing pixels per image %s; planes per image %s"
-              % (sum(same), B, flipped, [int(m.max()) for m in ids_dev]))
-        assert sum(same) >= B - 2 and all(f <= 0.03 * 240 * 320 for f in flipped)
+        bf, _ = detector._ctx(B, 240, 320)
+        n_det = bf.n_det.cpu().numpy()
+        dev_scores, dev_boxes = bf.det_scores.cpu().numpy(), bf.det_boxes.cpu().numpy()
+        ids_or, agree, flipped, unmatched = [], [], [], []
+        for i in range(B):
+            taps = {}
+            ids_or.append(PM.run_on_tensor(detector_weights, ref_batch["image"][i], taps=taps))
+            so, bo = taps["det_scores"].numpy(), taps["det_boxes"].numpy()
+            sd, bd = dev_scores[i][:n_det[i]], dev_boxes[i][:n_det[i]]
+            # a detection of one side is "matched" when the other side holds the same box (IoU > 0.98) with the same score (1e-3)
+            miss = sum(1 for k in range(len(so)) if not len(sd) or not _has_match(bo[k], so[k], bd, sd)) + \
+                sum(1 for k in range(len(sd)) if not len(so) or not _has_match(bd[k], sd[k], bo, so))
+            unmatched.append(miss)
+            agree.append(miss == 0 and len(so) == len(sd))
+            flipped.append(int((ids_dev[i] != ids_or[i]).sum()))
+        print("configs[2]: per image -- detections (device / oracle lists agree) %s, unmatched detections %s, differing id pixels %s, planes %s"
+              % ([int(a) for a in agree], unmatched, flipped, [int(m.max()) for m in ids_dev]))
+        # Integer work, asserted exactly: wherever the two detection lists agree (every box and score; the decisions that follow --
+        # score > 0.9, mask > 0.5 per pixel, biggest component, >= 5 % of the image, ids by size -- are then taken on the same numbers)
+        # the id maps must be identical pixel for pixel.  Where a detection decision upstream flipped (random-noise frames put NMS IoUs
+        # within 1e-2 of their thresholds: round 3 found one box pair at IoU 0.4987 / 0.4951 against the 0.5 bar on frame 40) the maps may
+        # differ, but only on ONE image of the eight, by at most two detections, and on at most 3 % of its pixels.
+        for i in range(B):
+            if agree[i]:
+                assert flipped[i] == 0, "image %d: same detections as the oracle but %d id pixels differ" % (i, flipped[i])
+        assert sum(agree) >= B - 1, (agree, unmatched)
+        assert all(u <= 4 for u in unmatched) and all(f <= 0.03 * 240 * 320 for f in flipped), (unmatched, flipped)
         assert max(int(m.max()) for m in ids_dev) >= 2, "the seeded detector finds planes on these frames"
         ref = O.call_cnn(seeded_weights["sn"], seeded_weights["dc"], ref_batch, ids_dev, INTR, 200, rng=np.random.RandomState(21))
         rmse = float((got - ref).pow(2).mean().sqrt())

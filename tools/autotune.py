@@ -109,11 +109,11 @@ def main():
     engine._TUNING = {}                      # measure against the cost-model plan, not an older table
     os.environ["VIDC_PRECISION"] = "fp32"      # record the programs with fp32 inputs (no split ops); both modes are timed below
     table, report = {}, []
-    if (a.only_missing or a.sigs or a.fp32_only) and os.path.exists(OUT):
+    if (a.only_missing or a.sigs or a.fp32_only or a.frame_only) and os.path.exists(OUT):
         table = json.load(open(OUT))
     old_table = dict(table)
-    if a.fp32_only:
-        table = {}
+    if a.fp32_only or (a.frame_only and not a.only_missing):
+        table = {}                               # re-measure; everything not measured in this run is merged back before writing
     if a.sigs:
         pats = [v for v in a.sigs.split(",") if v]
         table = {k: v for k, v in table.items() if not any(pt in k for pt in pats)}
@@ -195,7 +195,7 @@ def main():
                         sig, L.TILE_NAMES[t32], sk32, us32, L.TILE_NAMES[t16], sk16, us16, t_split, "bf16x3" if prec else "fp32"), flush=True)
             del sn, dc
             torch.cuda.empty_cache()
-    if a.fp32_only:
+    if a.fp32_only or a.frame_only:
         merged = dict(old_table)
         merged.update(table)
         table = merged

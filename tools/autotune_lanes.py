@@ -30,7 +30,13 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--iters", type=int, default=24)
     ap.add_argument("--budget-s", type=float, default=1500.0)
+    ap.add_argument("--precision", choices=("mixed", "fp32"), default="mixed",
+                    help="fp32: tune the exact-fp32 configuration of a signature (entries [3], [4] of the table; VIDC_PRECISION=fp32 programs)")
+    ap.add_argument("--max-bm", type=int, default=0, help="only tiles whose BM is at most this (0: the default M-based bound)")
+    ap.add_argument("--out", default=OUT)
     a = ap.parse_args()
+    os.environ["VIDC_PRECISION"] = a.precision
+    fp32 = a.precision == "fp32"
     H, W, B = a.height, 320, a.batch
     dev = torch.device("cuda")
     cc = (0.5 * 319.87654, 0.5 * 239.87603 * H / 240.0)
@@ -82,20 +88,28 @@ def main():
             print("time budget used up; stopping", flush=True)
             break
         ent = list(table[sig])
-        best = (base, ent[0], ent[1])
+        if fp32 and len(ent) < 5:
+            ent = [ent[0], ent[1], ent[2] if len(ent) > 2 else 0, ent[0], ent[1]]
+        cur = (ent[3], ent[4]) if fp32 else (ent[0], ent[1])
+        best = (base, cur[0], cur[1])
+
+        def entry(t, sk):
+            if not fp32:
+                return [t, sk, 1, ent[3], ent[4]] if len(ent) >= 5 else [t, sk, 1]
+            return ([t, sk, 0, t, sk] if ent[2] == 0 else [ent[0], ent[1], ent[2], t, sk])
         M = int(sig.split("_")[0][1:])
         K = int(sig.split("_")[2][1:])
-        sks = sorted({1, max(1, ent[1] - 1), ent[1], ent[1] + 1, 2 * ent[1]})
+        sks = sorted({1, max(1, cur[1] - 1), cur[1], cur[1] + 1, 2 * cur[1]})
         for t in range(1, L.TILE_COUNT):
             bm = int(L.TILE_NAMES[t].split("x")[0])
-            if bm >= 4 * max(32, M):
+            if bm >= 4 * max(32, M) or (a.max_bm and bm > a.max_bm):
                 continue
             for sk in sks:
                 if sk > 1 and (K // 32) // sk < 2:
                     continue
-                if (t, sk) == (ent[0], ent[1]):
+                if (t, sk) == cur:
                     continue
-                table[sig] = [t, sk, 1, ent[3], ent[4]] if len(ent) >= 5 else [t, sk, 1]
+                table[sig] = entry(t, sk)
                 try:
                     ps = build()
                     ms = pair_ms(ps, 12)
@@ -106,13 +120,13 @@ def main():
                     if ms2 < best[0] * 0.995:
                         best = (ms2, t, sk)
                 del ps
-        table[sig] = ([best[1], best[2], 1, ent[3], ent[4]] if len(ent) >= 5 else [best[1], best[2], 1])
-        print("%-34s %6.1f us/tick: %-10s sk%-2d -> %-10s sk%-2d   %.3f -> %.3f ms per frame" % (sig, by_sig[sig] * 1e3, L.TILE_NAMES[ent[0]], ent[1],
+        table[sig] = entry(best[1], best[2])
+        print("%-34s %6.1f us/tick: %-10s sk%-2d -> %-10s sk%-2d   %.3f -> %.3f ms per frame" % (sig, by_sig[sig] * 1e3, L.TILE_NAMES[cur[0]], cur[1],
               L.TILE_NAMES[best[1]], best[2], base, best[0]), flush=True)
         base = best[0]
-    with open(OUT, "w") as f:
+    with open(a.out, "w") as f:
         json.dump(dict(sorted(table.items())), f, indent=0)
-    print("wrote %s; %.3f ms per frame" % (OUT, base))
+    print("wrote %s; %.3f ms per frame" % (a.out, base))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,223 @@
+// Micro-benchmark: the stage loop of the large bf16x3 conv tile (128x128, four compute waves of 64x64, one per SIMD) with the DMA taken
+// out -- what does ONE wave per SIMD sustain when every stage is  s_barrier -> 16 ds_read_b128 -> 24 v_mfma_f32_32x32x16_bf16 ?
+// Variants of the same work (same reads, same MFMAs, same barrier count per stage):
+//   0  as the kernel does it: all 16 reads after the barrier, wait for the first 8, 12 MFMAs, wait for the rest, 12 MFMAs
+//   1  cross-barrier prefetch: the 8 reads of the NEXT stage's first half are issued between the two MFMA groups of this stage
+//      (legal in the real kernel when the barrier of stage s also guarantees stage s+1 has landed: ring one deeper)
+//   2  like 1, and the 8 reads of this stage's second half are issued one per MFMA inside the first MFMA group
+//   3  like 0 with s_setprio 1 around the MFMA groups
+//   4  like 2 with 8 waves (two per SIMD, 64x32 wave tiles: 12 MFMAs per wave and stage) -- the occupancy reference
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_loop mfma_loop.hip && ./mfma_loop
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 lds_read(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+#define MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0)
+
+// one half stage = k 16 of the 32-channel unit: fragments ah/al[2], bh/bl[2] (8 b128) and 12 MFMAs on 4 accumulators
+struct Half { f32x4 ah[2], al[2], bh[2], bl[2]; };
+
+__device__ __forceinline__ void read_half(Half& h, unsigned a_addr, unsigned b_addr, unsigned ch, unsigned cl) {
+    h.ah[0] = lds_read(a_addr + ch); h.al[0] = lds_read(a_addr + cl);
+    h.ah[1] = lds_read(a_addr + ch + 4096); h.al[1] = lds_read(a_addr + cl + 4096);
+    h.bh[0] = lds_read(b_addr + ch); h.bl[0] = lds_read(b_addr + cl);
+    h.bh[1] = lds_read(b_addr + ch + 4096); h.bl[1] = lds_read(b_addr + cl + 4096);
+}
+__device__ __forceinline__ void mfma_half(const Half& h, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            MFMA(acc[i][j], h.al[i], h.bh[j]);
+            MFMA(acc[i][j], h.ah[i], h.bl[j]);
+            MFMA(acc[i][j], h.ah[i], h.bh[j]);
+        }
+}
+
+template <int VAR>
+__global__ void __launch_bounds__(256) loop4(int stages, long long* out, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 3 * 8192; i += 256) smem[i] = 0.001f * (float)(i & 255);      // 3 ring slots of 32 KB
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) float*)smem);
+    const int li = lane & 31, lh = lane >> 5, sw = (li >> 1) & 7;
+    const unsigned a_base = lds0 + 4u * (unsigned)(((wave >> 1) * 64 + li) * 32);
+    const unsigned b_base = lds0 + 4u * (unsigned)((128 + (wave & 1) * 64 + li) * 32);
+    unsigned ch[2], cl[2];
+    for (int t = 0; t < 2; ++t) { ch[t] = (unsigned)(((2 * t + lh) ^ sw) * 16); cl[t] = (unsigned)(((4 + 2 * t + lh) ^ sw) * 16); }
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    Half h0, h1;
+    int slot = 0;
+    const long long t0 = __builtin_readcyclecounter();
+    if (VAR == 1 || VAR == 2) read_half(h0, a_base, b_base, ch[0], cl[0]);
+    for (int s = 0; s < stages; ++s) {
+        const unsigned off = (unsigned)(slot * 32768);
+        int nslot = slot + 1; if (nslot == 3) nslot = 0;
+        const unsigned noff = (unsigned)(nslot * 32768);
+        __builtin_amdgcn_s_barrier();
+        if (VAR == 0 || VAR == 3) {
+            read_half(h0, a_base + off, b_base + off, ch[0], cl[0]);
+            read_half(h1, a_base + off, b_base + off, ch[1], cl[1]);
+            wait_lgkm<8>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (VAR == 3) __builtin_amdgcn_s_setprio(1);
+            mfma_half(h0, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(h1, acc);
+            if (VAR == 3) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (VAR == 1) {
+            read_half(h1, a_base + off, b_base + off, ch[1], cl[1]);
+            wait_lgkm<8>();                              // h0 (issued during the previous stage) has landed
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(h0, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            read_half(h0, a_base + noff, b_base + noff, ch[0], cl[0]);      // next stage's first half
+            wait_lgkm<8>();                              // h1 has landed
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(h1, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {   // VAR == 2: second-half reads interleaved with the first MFMA group, next stage's first half with the second
+            wait_lgkm<0>();                              // h0 complete
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const unsigned A = a_base + off, B = b_base + off;
+                MFMA(acc[0][0], h0.al[0], h0.bh[0]); h1.ah[0] = lds_read(A + ch[1]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][1], h0.al[0], h0.bh[1]); h1.al[0] = lds_read(A + cl[1]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][0], h0.al[1], h0.bh[0]); h1.ah[1] = lds_read(A + ch[1] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][1], h0.al[1], h0.bh[1]); h1.al[1] = lds_read(A + cl[1] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][0], h0.ah[0], h0.bl[0]); h1.bh[0] = lds_read(B + ch[1]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][1], h0.ah[0], h0.bl[1]); h1.bl[0] = lds_read(B + cl[1]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][0], h0.ah[1], h0.bl[0]); h1.bh[1] = lds_read(B + ch[1] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][1], h0.ah[1], h0.bl[1]); h1.bl[1] = lds_read(B + cl[1] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][0], h0.ah[0], h0.bh[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][1], h0.ah[0], h0.bh[1]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][0], h0.ah[1], h0.bh[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][1], h0.ah[1], h0.bh[1]); __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const unsigned A = a_base + noff, B = b_base + noff;
+                MFMA(acc[0][0], h1.al[0], h1.bh[0]); h0.ah[0] = lds_read(A + ch[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][1], h1.al[0], h1.bh[1]); h0.al[0] = lds_read(A + cl[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][0], h1.al[1], h1.bh[0]); h0.ah[1] = lds_read(A + ch[0] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][1], h1.al[1], h1.bh[1]); h0.al[1] = lds_read(A + cl[0] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][0], h1.ah[0], h1.bl[0]); h0.bh[0] = lds_read(B + ch[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][1], h1.ah[0], h1.bl[1]); h0.bl[0] = lds_read(B + cl[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][0], h1.ah[1], h1.bl[0]); h0.bh[1] = lds_read(B + ch[0] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][1], h1.ah[1], h1.bl[1]); h0.bl[1] = lds_read(B + cl[0] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][0], h1.ah[0], h1.bh[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][1], h1.ah[0], h1.bh[1]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][0], h1.ah[1], h1.bh[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][1], h1.ah[1], h1.bh[1]); __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        slot = nslot;
+    }
+    wait_lgkm<0>();
+    const long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (s == 123.456f) sink[0] = s + h0.ah[0].x + h1.ah[0].x;
+}
+
+// eight waves, two per SIMD, 64x32 wave tiles (TM = 2, TN = 1): 6 reads and 6 MFMAs per half stage and wave, reads interleaved
+__global__ void __launch_bounds__(512) loop8(int stages, long long* out, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 3 * 8192; i += 512) smem[i] = 0.001f * (float)(i & 255);
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) float*)smem);
+    const int li = lane & 31, lh = lane >> 5, sw = (li >> 1) & 7;
+    const unsigned a_base = lds0 + 4u * (unsigned)(((wave >> 2) * 64 + li) * 32);
+    const unsigned b_base = lds0 + 4u * (unsigned)((128 + (wave & 3) * 32 + li) * 32);
+    unsigned ch[2], cl[2];
+    for (int t = 0; t < 2; ++t) { ch[t] = (unsigned)(((2 * t + lh) ^ sw) * 16); cl[t] = (unsigned)(((4 + 2 * t + lh) ^ sw) * 16); }
+    f32x16 acc[2];
+    for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    int slot = 0;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int s = 0; s < stages; ++s) {
+        const unsigned off = (unsigned)(slot * 32768);
+        __builtin_amdgcn_s_barrier();
+        f32x4 ah[2][2], al[2][2], bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            ah[t][0] = lds_read(a_base + off + ch[t]); al[t][0] = lds_read(a_base + off + cl[t]);
+            ah[t][1] = lds_read(a_base + off + ch[t] + 4096); al[t][1] = lds_read(a_base + off + cl[t] + 4096);
+            bh[t] = lds_read(b_base + off + ch[t]); bl[t] = lds_read(b_base + off + cl[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t == 0) wait_lgkm<6>(); else wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                MFMA(acc[i], al[t][i], bh[t]);
+                MFMA(acc[i], ah[t][i], bl[t]);
+                MFMA(acc[i], ah[t][i], bh[t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (++slot == 3) slot = 0;
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 123.456f) sink[0] = s;
+}
+
+template <typename K>
+int run(const char* name, K kernel, int threads, int stages, long long* out, float* sink, double mfma_per_simd_stage) {
+    const int wgs = 256;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    hipLaunchKernelGGL(kernel, dim3(wgs), dim3(threads), 96 * 1024, 0, stages, out, sink);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kernel, dim3(wgs), dim3(threads), 96 * 1024, 0, stages, out, sink);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<long long> h(wgs);
+    CK(hipMemcpy(h.data(), out, wgs * sizeof(long long), hipMemcpyDeviceToHost));
+    double cyc = 0; for (auto v : h) cyc += v; cyc /= wgs;
+    const double clk_stage = cyc / stages;
+    printf("%-58s %8.1f clk per stage  (%5.1f clk per MFMA and SIMD, pipe %5.1f %% busy)   kernel %.1f us -> %.2f GHz\n", name, clk_stage,
+           clk_stage / mfma_per_simd_stage, 100.0 * mfma_per_simd_stage * 32.0 / clk_stage, ms * 1e3, cyc / (ms * 1e-3) / 1e9);
+    return 0;
+}
+
+int main() {
+    long long* out; float* sink;
+    CK(hipMalloc(&out, 256 * sizeof(long long))); CK(hipMalloc(&sink, 64));
+    const int stages = 2000;
+    if (run("0: 16 reads after the barrier, 12 + 12 MFMAs", loop4<0>, 256, stages, out, sink, 24)) return 1;
+    if (run("1: next stage's first half prefetched across the barrier", loop4<1>, 256, stages, out, sink, 24)) return 1;
+    if (run("2: every read in the shadow of an MFMA", loop4<2>, 256, stages, out, sink, 24)) return 1;
+    if (run("3: as 0 with s_setprio 1 around the MFMAs", loop4<3>, 256, stages, out, sink, 24)) return 1;
+    if (run("4: eight waves (two per SIMD), 64x32 wave tiles", loop8, 512, stages, out, sink, 24)) return 1;
+    return 0;
+}
