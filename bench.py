@@ -146,13 +146,15 @@ TILE_TEMPLATE = {"128x128": (128, 128, 2, 2, 1, 2), "128x64": (128, 64, 2, 2, 1,
                  "128x128d3": (128, 128, 2, 2, 1, 3), "128x128d3L": (128, 128, 2, 2, 1, 3), "256x128": (256, 128, 4, 2, 1, 3),
                  "128x256": (128, 256, 2, 4, 1, 3),
                  "32x64k2d2": (32, 64, 1, 2, 2, 2), "64x64d2": (64, 64, 2, 2, 1, 2), "32x32k4d2": (32, 32, 1, 1, 4, 2), "64x128d2": (64, 128, 2, 2, 1, 2),
-                 "64x32k2d2": (64, 32, 2, 1, 2, 2)}
+                 "64x32k2d2": (64, 32, 2, 1, 2, 2),
+                 # loader waves + pipelined fragment reads: conv_igemm_f32<..., PREC, 2>
+                 "128x128d4P": (128, 128, 2, 2, 1, 4), "128x128d3P": (128, 128, 2, 2, 1, 3), "64x64d4P": (64, 64, 2, 2, 1, 4), "128x64d4P": (128, 64, 2, 2, 1, 4)}
 
 
 def kernel_name(tile, prec):
     if tile == "chain64x64k2d4":
         return "conv_chain_kernel<4, %d>" % prec
-    return "conv_igemm_f32<%s, %d, %d>" % (", ".join(str(v) for v in TILE_TEMPLATE[tile]), prec, int(tile.endswith("L")))
+    return "conv_igemm_f32<%s, %d, %d>" % (", ".join(str(v) for v in TILE_TEMPLATE[tile]), prec, 2 if tile.endswith("P") else int(tile.endswith("L")))
 
 
 def conv_stack_times(prog, iters=5):
@@ -314,6 +316,7 @@ def measure(args, dev, rank, world, precision):
             pmc = None
         if pmc:
             roofline["traffic"] = pmc["traffic_bytes"]
+            roofline["mfma_busy_pmc"] = pmc.get("mfma_busy_fraction")       # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs), same passes
             roofline["traffic_note"] = ("bytes per launch = FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE from rocprofv3 --pmc passes: %s; %s; "
                                         "algorithmic bytes of that launch %d (profiles/pmc_traffic.json; --pmc on the whole bench process "
                                         "segfaults in rocprofv3 on this pool)" % (pmc["command"], pmc["shape"], pmc["algorithmic_bytes"]))

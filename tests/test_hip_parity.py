@@ -141,7 +141,7 @@ CONV_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)
-@pytest.mark.parametrize("tile", list(range(33)))       # 14..20, 23, 25: the loader-wave variants; 24..27: 64x64 wave tiles; 28..32: 2-deep rings
+@pytest.mark.parametrize("tile", list(range(37)))       # 14..20, 23, 25: the loader-wave variants; 24..27: 64x64 wave tiles; 28..32: 2-deep rings; 33..36: pipelined fragment reads
 def test_conv_tiles(shape, tile):
     from vi_depth_completion_amd import ops
     B, H, W, cin, cout, k, stride, groups = shape
@@ -181,7 +181,7 @@ def _split_bf16(t):
 
 
 @pytest.mark.parametrize("shape", [CONV_SHAPES[1], CONV_SHAPES[2], CONV_SHAPES[4], CONV_SHAPES[5], CONV_SHAPES[7], CONV_SHAPES[8]])
-@pytest.mark.parametrize("tile", [0, 1, 4, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27])
+@pytest.mark.parametrize("tile", [0, 1, 4, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 33, 34, 35, 36])
 def test_conv_bf16x3(shape, tile):
     """Split-bf16 3-pass mode vs an exact CPU emulation of the same arithmetic (hi*hi + hi*lo + lo*hi in fp32:
     bf16 x bf16 products are exact in fp32, so only the summation order differs) and vs true fp32 (2^-16 class)."""
@@ -203,6 +203,24 @@ def test_conv_bf16x3(shape, tile):
     got = nchw(y).cpu()
     assert (got - emu).abs().max().item() < 2e-4
     assert (got - ref).abs().max().item() < 5e-4          # |x|~1, |w|~sqrt(2/K): 2^-16 * sum|x w| stays far below this
+
+
+@pytest.mark.parametrize("shape", [CONV_SHAPES[2], CONV_SHAPES[5], CONV_SHAPES[8]])
+@pytest.mark.parametrize("pair", [(25, 34), (25, 33), (17, 35), (20, 36)])
+def test_pipelined_fragment_reads_are_bit_identical(shape, pair):
+    """SPEC 2 tilings (every fragment read behind an MFMA, the next stage's first k-half read across the stage barrier, ring one slot
+    deeper) against the loader-wave tiling of the same BM x BN: same K order and, per accumulator, the same MFMA order (lo*hi, hi*lo,
+    hi*hi of k-half 0, then of k-half 1) -> identical bits, also with split-K and in the fp32 mode (which runs the loader-wave loop)."""
+    from vi_depth_completion_amd import ops
+    B, H, W, cin, cout, k, stride, groups = shape
+    x, w, s1, b1 = _conv_case(17, B, H, W, cin, cout, k, stride, groups)
+    pad = k // 2
+    for prec, packer in ((1, ops.pack_conv_weight_bf16x3), (0, ops.pack_conv_weight)):
+        wp = torch.stack([packer(wg.to(DEV)) for wg in w])
+        for sk in (1, 3):
+            ys = [ops.conv2d_bn_act(nhwc(x).to(DEV), wp, s1.to(DEV), b1.to(DEV), k, k, stride, pad, relu1=True, tile=t, groups=groups, precision=prec,
+                                    splitk=sk).cpu() for t in pair]
+            assert torch.equal(ys[0], ys[1]), (pair, prec, sk)
 
 
 @pytest.mark.parametrize("cfg", [(0, 1, 1), (1, 1, 1), (0, 4, 3), (1, 2, 3)])

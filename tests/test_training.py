@@ -283,7 +283,9 @@ def _bf16_round(t):
 
 
 @gpu
-@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,tile", [(64, 64, 3, 1, 1, 12, 20, 4), (128, 128, 1, 1, 0, 9, 7, 6), (192, 64, 3, 2, 1, 11, 13, 0), (64, 128, 3, 1, 1, 16, 16, 3)])
+@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,tile", [(64, 64, 3, 1, 1, 12, 20, 4), (128, 128, 1, 1, 0, 9, 7, 6), (192, 64, 3, 2, 1, 11, 13, 0), (64, 128, 3, 1, 1, 16, 16, 3),
+                                                            # the pipelined-fragment-read tilings (SPEC 2): plain bf16 runs two MFMA passes per k-half there
+                                                            (128, 128, 3, 1, 1, 17, 19, 33), (64, 192, 3, 1, 1, 16, 16, 34), (128, 64, 1, 1, 0, 9, 7, 35), (192, 128, 3, 2, 1, 21, 13, 36)])
 def test_plain_bf16_conv_mode(cin, cout, k, stride, pad, H, W, tile):
     """VIDC_PREC_BF16 (the arithmetic BASELINE configs[4] names): operands rounded to bf16 by vidc_cast_bf16 / pack kinds 4, 5, products
     exact (bf16 x bf16 fits fp32), fp32 accumulation -- so the result equals F.conv2d of the bf16-ROUNDED operands in fp32 up to

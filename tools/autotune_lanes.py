@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--precision", choices=("mixed", "fp32"), default="mixed",
                     help="fp32: tune the exact-fp32 configuration of a signature (entries [3], [4] of the table; VIDC_PRECISION=fp32 programs)")
     ap.add_argument("--max-bm", type=int, default=0, help="only tiles whose BM is at most this (0: the default M-based bound)")
+    ap.add_argument("--tiles", default="", help="comma-separated tile ids: only these are tried (default: all)")
     ap.add_argument("--out", default=OUT)
     a = ap.parse_args()
     os.environ["VIDC_PRECISION"] = a.precision
@@ -100,7 +101,8 @@ def main():
         M = int(sig.split("_")[0][1:])
         K = int(sig.split("_")[2][1:])
         sks = sorted({1, max(1, cur[1] - 1), cur[1], cur[1] + 1, 2 * cur[1]})
-        for t in range(1, L.TILE_COUNT):
+        only = [int(v) for v in a.tiles.split(",") if v]
+        for t in (only if only else range(1, L.TILE_COUNT)):
             bm = int(L.TILE_NAMES[t].split("x")[0])
             if bm >= 4 * max(32, M) or (a.max_bm and bm > a.max_bm):
                 continue

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Folds the in-frame counter tables (tools/frame_pmc_summary.py output) and the per-op table of bench.py into profiles/pmc_traffic.json:
+for every conv kernel instantiation of a leg -- per-launch FETCH_SIZE x 2 + WRITE_SIZE (HBM-side bytes), the matrix-pipe busy fraction, and
+the ALGORITHMIC bytes of its average launch (activations in + weights + output, 4 bytes per element, from the signatures of the ops that
+run on it).  bench.py reports the entry of a leg's dominant kernel as roofline.traffic.
+
+    python tools/pmc_to_json.py profiles/r3_frame_pmc_mixed.txt profiles/r3_per_op.tsv 1 "rocprofv3 ... frame_replay.py 20" [--out profiles/pmc_traffic.json]
+"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    pmc_txt, per_op, prec, command = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    import bench
+    alg, cnt, shapes = {}, {}, {}
+    for ln in open(per_op):
+        _prog, _us, name = ln.rstrip("\n").split("\t")
+        if not name.startswith("conv:"):
+            continue
+        _c, _key, tile, _sk, rest = name.split(":", 4)
+        if (1 if rest.startswith("bf16x3 ") else 0) != prec:
+            continue
+        m = re.search(r"M(\d+)_N(\d+)_K(\d+)_k(\d)s(\d)_G(\d+)", name)
+        M, N, K, k, s, G = (int(v) for v in m.groups())
+        kern = bench.kernel_name(tile, prec)
+        alg[kern] = alg.get(kern, 0) + 4 * G * (M * s * s * (K // (k * k)) + N * K + M * N)
+        cnt[kern] = cnt.get(kern, 0) + 1
+        shapes.setdefault(kern, {})
+        shapes[kern][m.group(0)] = shapes[kern].get(m.group(0), 0) + 1
+    table = json.load(open(out)) if os.path.exists(out) else {}
+    table["_comment"] = ("HBM-side traffic per launch of conv kernel instantiations IN THE FRAME (tools/frame_replay.py: the frame program replayed 20 "
+                         "times, every layer's weights HBM-cold), from separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES "
+                         "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) with --kernel-trace only; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies wide "
+                         "coalesced reads at half).  algorithmic_bytes = activations in + weights + output of the kernel's average launch.  bench.py "
+                         "reports the entry of a leg's dominant kernel as roofline.traffic.")
+    for ln in open(pmc_txt):
+        m = re.match(r"(conv_igemm_f32<[^>]*>)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.naN]+)\s+([\d.]+)\s+([\d.naN]+)%", ln)
+        if not m:
+            continue
+        kern, calls, us, fk, wk, _tbs, busy = m.group(1), float(m.group(2)), float(m.group(3)), float(m.group(4)), m.group(5), m.group(6), m.group(7)
+        if kern not in alg:
+            continue
+        wkb = float(wk) if wk.lower() != "nan" else 0.0
+        table[kern] = {"round": 3, "launches_per_tick": calls, "avg_us_under_counter_collection": us,
+                       "fetch_bytes": int(fk * 1024), "write_bytes": int(wkb * 1024), "traffic_bytes": int((fk + wkb) * 1024),
+                       "algorithmic_bytes": int(alg[kern] / cnt[kern]), "traffic_over_algorithmic": round((fk + wkb) * 1024 / (alg[kern] / cnt[kern]), 3),
+                       "mfma_busy_fraction": (round(float(busy) / 100.0, 4) if busy.lower() != "nan" else None),
+                       "shape": "the %d launches per tick of this instantiation: %s" % (cnt[kern], ", ".join("%d x %s" % (v, k) for k, v in sorted(shapes[kern].items(), key=lambda kv: -kv[1])[:4])),
+                       "command": command}
+    with open(out, "w") as f:
+        json.dump(table, f, indent=1)
+    print("wrote", out, "with", len(table) - 1, "kernels")
+
+
+if __name__ == "__main__":
+    main()

@@ -188,6 +188,116 @@ __global__ void __launch_bounds__(512) loop8(int stages, long long* out, float* 
     if (s == 123.456f) sink[0] = s;
 }
 
+
+// ---- the same compute loops with LOADER waves beside them: NL extra waves issue the stage's 32 LDS-DMA instructions (1 KiB each, 32 KB per
+// stage = a 128x128 tile's A and B rows) out of an L2-resident buffer, 32 / NL each, wait until the stage issued one iteration earlier has
+// landed, and meet the compute waves at the stage barrier -- the structure of the conv kernel's loader-wave tilings.
+typedef __attribute__((address_space(3))) void lds_void_t;
+template <int VAR, int NL>
+__global__ void __launch_bounds__(256 + 64 * NL) loopL(const float* src, int span_bytes, int stages, long long* out, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 4 * 8192; i += 256 + 64 * NL) smem[i] = 0.001f * (float)(i & 255);      // 4 ring slots of 32 KB
+    __syncthreads();
+    if (wave >= 4) {      // ---- loader
+        const int l = wave - 4;
+        constexpr int PER = 32 / NL;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
+        unsigned off = (unsigned)((((long long)blockIdx.x * 7919 + l * PER) * 1024) % span_bytes) + lane * 16;
+        int slot = 0;
+        for (int s = 0; s < stages; ++s) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                float* dst = smem + slot * 8192 + (l * PER + j) * 256;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)dst, 16, (int)off, 0, 0, 0);
+                off += 1024;
+                if (off >= (unsigned)span_bytes) off -= span_bytes;
+            }
+            off += (32 - PER) * 1024;
+            if (off >= (unsigned)span_bytes) off -= span_bytes;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");      // everything but the stage just issued has landed
+            __builtin_amdgcn_s_barrier();
+            if (++slot == 4) slot = 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) float*)smem);
+    const int li = lane & 31, lh = lane >> 5, sw = (li >> 1) & 7;
+    const unsigned a_base = lds0 + 4u * (unsigned)(((wave >> 1) * 64 + li) * 32);
+    const unsigned b_base = lds0 + 4u * (unsigned)((128 + (wave & 1) * 64 + li) * 32);
+    unsigned ch[2], cl[2];
+    for (int t = 0; t < 2; ++t) { ch[t] = (unsigned)(((2 * t + lh) ^ sw) * 16); cl[t] = (unsigned)(((4 + 2 * t + lh) ^ sw) * 16); }
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    Half h0, h1;
+    int slot = 2;      // (read slots the loaders are not writing: two behind)
+    const long long t0 = __builtin_readcyclecounter();
+    if (VAR == 2) read_half(h0, a_base + slot * 32768, b_base + slot * 32768, ch[0], cl[0]);
+    for (int s = 0; s < stages; ++s) {
+        const unsigned off = (unsigned)(slot * 32768);
+        int nslot = slot + 1; if (nslot == 4) nslot = 0;
+        const unsigned noff = (unsigned)(nslot * 32768);
+        __builtin_amdgcn_s_barrier();
+        if (VAR == 0) {
+            read_half(h0, a_base + off, b_base + off, ch[0], cl[0]);
+            read_half(h1, a_base + off, b_base + off, ch[1], cl[1]);
+            wait_lgkm<8>();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(h0, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(h1, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const unsigned A = a_base + off, B = b_base + off;
+                MFMA(acc[0][0], h0.al[0], h0.bh[0]); h1.ah[0] = lds_read(A + ch[1]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][1], h0.al[0], h0.bh[1]); h1.al[0] = lds_read(A + cl[1]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][0], h0.al[1], h0.bh[0]); h1.ah[1] = lds_read(A + ch[1] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][1], h0.al[1], h0.bh[1]); h1.al[1] = lds_read(A + cl[1] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][0], h0.ah[0], h0.bl[0]); h1.bh[0] = lds_read(B + ch[1]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][1], h0.ah[0], h0.bl[1]); h1.bl[0] = lds_read(B + cl[1]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][0], h0.ah[1], h0.bl[0]); h1.bh[1] = lds_read(B + ch[1] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][1], h0.ah[1], h0.bl[1]); h1.bl[1] = lds_read(B + cl[1] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][0], h0.ah[0], h0.bh[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][1], h0.ah[0], h0.bh[1]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][0], h0.ah[1], h0.bh[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][1], h0.ah[1], h0.bh[1]); __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const unsigned A = a_base + noff, B = b_base + noff;
+                MFMA(acc[0][0], h1.al[0], h1.bh[0]); h0.ah[0] = lds_read(A + ch[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][1], h1.al[0], h1.bh[1]); h0.al[0] = lds_read(A + cl[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][0], h1.al[1], h1.bh[0]); h0.ah[1] = lds_read(A + ch[0] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][1], h1.al[1], h1.bh[1]); h0.al[1] = lds_read(A + cl[0] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][0], h1.ah[0], h1.bl[0]); h0.bh[0] = lds_read(B + ch[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][1], h1.ah[0], h1.bl[1]); h0.bl[0] = lds_read(B + cl[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][0], h1.ah[1], h1.bl[0]); h0.bh[1] = lds_read(B + ch[0] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][1], h1.ah[1], h1.bl[1]); h0.bl[1] = lds_read(B + cl[0] + 4096); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][0], h1.ah[0], h1.bh[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[0][1], h1.ah[0], h1.bh[1]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][0], h1.ah[1], h1.bh[0]); __builtin_amdgcn_sched_barrier(0);
+                MFMA(acc[1][1], h1.ah[1], h1.bh[1]); __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        slot = nslot;
+    }
+    wait_lgkm<0>();
+    const long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    float sum = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    if (sum == 123.456f) sink[0] = sum + h0.ah[0].x + h1.ah[0].x;
+}
+
 template <typename K>
 int run(const char* name, K kernel, int threads, int stages, long long* out, float* sink, double mfma_per_simd_stage) {
     const int wgs = 256;
@@ -210,6 +320,28 @@ int run(const char* name, K kernel, int threads, int stages, long long* out, flo
     return 0;
 }
 
+template <int VAR, int NL>
+int runL(const char* name, const float* src, int span, int stages, long long* out, float* sink) {
+    const int wgs = 256;
+    auto kernel = loopL<VAR, NL>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    hipLaunchKernelGGL(kernel, dim3(wgs), dim3(256 + 64 * NL), 128 * 1024, 0, src, span, stages, out, sink);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kernel, dim3(wgs), dim3(256 + 64 * NL), 128 * 1024, 0, src, span, stages, out, sink);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<long long> h(wgs);
+    CK(hipMemcpy(h.data(), out, wgs * sizeof(long long), hipMemcpyDeviceToHost));
+    double cyc = 0; for (auto v : h) cyc += v; cyc /= wgs;
+    printf("%-58s %8.1f clk per stage  (pipe %5.1f %% busy, %5.1f B/clk/CU of LDS-DMA)   kernel %.1f us\n", name, cyc / stages, 100.0 * 768.0 / (cyc / stages),
+           32768.0 / (cyc / stages), ms * 1e3);
+    return 0;
+}
+
 int main() {
     long long* out; float* sink;
     CK(hipMalloc(&out, 256 * sizeof(long long))); CK(hipMalloc(&sink, 64));
@@ -219,5 +351,13 @@ int main() {
     if (run("2: every read in the shadow of an MFMA", loop4<2>, 256, stages, out, sink, 24)) return 1;
     if (run("3: as 0 with s_setprio 1 around the MFMAs", loop4<3>, 256, stages, out, sink, 24)) return 1;
     if (run("4: eight waves (two per SIMD), 64x32 wave tiles", loop8, 512, stages, out, sink, 24)) return 1;
+    float* src;
+    const int span = 16 << 20;      // 16 MB: L2 / Infinity-Cache resident after the first pass
+    CK(hipMalloc(&src, span)); CK(hipMemset(src, 0, span));
+    if (runL<0, 4>("0 + 4 loader waves (8 DMAs each per stage): the _L kernel", src, span, stages, out, sink)) return 1;
+    if (runL<2, 4>("2 + 4 loader waves (8 DMAs each per stage): the _P kernel", src, span, stages, out, sink)) return 1;
+    if (runL<0, 8>("0 + 8 loader waves (4 DMAs each per stage)", src, span, stages, out, sink)) return 1;
+    if (runL<2, 8>("2 + 8 loader waves (4 DMAs each per stage)", src, span, stages, out, sink)) return 1;
+    if (runL<2, 2>("2 + 2 loader waves (16 DMAs each per stage)", src, span, stages, out, sink)) return 1;
     return 0;
 }

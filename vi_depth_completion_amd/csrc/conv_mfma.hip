@@ -94,6 +94,17 @@ __device__ __forceinline__ void wait_stage(int s, int nst) {
     else         younger = (loop_issued - (s - PRO) - 1) * LPS;         // stage s was issued by loop iteration s-PRO
     wait_vmcnt_dyn<(NS - 2) * LPS>(younger);      // younger <= (NS-2)*LPS always (A_J <= LPS)
 }
+// The same count for a wait that is not taken in the iteration that consumes the stage: stage q has landed, seen from loop iteration `it`
+// (which has issued min(it, n_main) (A, B) pairs so far).  SPEC 2 loaders wait for stage it + 1 before the barrier of iteration it.
+template <int NS, int A_J, int LPS>
+__device__ __forceinline__ void wait_landed(int q, int it, int nst) {
+    constexpr int PRO = NS - 1;
+    const int n_main = nst > PRO ? nst - PRO : 0;
+    const int loop_issued = it < n_main ? it : n_main;
+    int younger = q < PRO ? (PRO - 1 - q) * A_J + loop_issued * LPS : (loop_issued - (q - PRO) - 1) * LPS;
+    if (younger < 0) younger = 0;
+    wait_vmcnt_dyn<(NS - 2) * LPS>(younger);      // (a count above the template bound waits for more than necessary: safe)
+}
 template <int N>
 __device__ __forceinline__ void wait_lgkmcnt() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
@@ -126,6 +137,15 @@ __device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
 // the compute waves' critical path (in-kernel stamps, M=320 layer-3 shapes: 853 clk per stage, 521 clk without the refills,
 // 829 clk without the MFMAs).  One loader and one compute wave share each SIMD; the per-stage s_barrier is the only hand-off:
 // a loader passes it after ITS loads of stage s have landed (its own vmcnt), a compute wave after it has read stage s-1.
+// SPEC 2 ("pipelined fragment reads", round 3; bf16 modes only, fp32 falls back to SPEC 1): loader waves as in SPEC 1, and the compute
+// waves never wait for LDS in front of an idle matrix pipe.  With one compute wave per SIMD (all a batch-1 layer has: 960 wave tiles of
+// 64x64 for 1024 SIMDs) the SPEC 1 loop -- barrier, 16 ds_read_b128, wait, 12 MFMAs, wait, 12 MFMAs -- runs the pipe at 67 %
+// (tools/ubench/mfma_loop.hip: 1143 clk per 768 clk of MFMA; priorities and a second wave per SIMD do not change that).  Here every
+// fragment read sits behind an MFMA: the reads of a stage's second k-half are interleaved with the MFMAs of its first half, and the reads
+// of the NEXT stage's first half with the MFMAs of the second half, ACROSS the stage barrier (849 clk per stage in the micro-benchmark,
+// 90 %).  For that the barrier of iteration s must also guarantee that stage s + 1 has landed: the loaders wait one stage further
+// ahead (wait_landed(s + 1)), which costs one stage of DMA look-ahead -- the ring is one slot deeper (NS = 4 for the 128x128 tile).
+// Per accumulator the MFMA order is unchanged (lo*hi, hi*lo, hi*hi of k-half 0, then of k-half 1), so results are bit-identical to SPEC 1.
 struct NoDep {
     __device__ __forceinline__ void operator()() const {}
     __device__ __forceinline__ void mark(int) const {}
@@ -159,6 +179,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
 
     const int tid = threadIdx.x;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    constexpr int SPEC_EFF = (SPEC == 2 && PREC == 0) ? 1 : SPEC;      // the pipelined loop exists for the 16-k bf16 MFMAs only
     const bool is_loader = SPEC && wave_all >= NW;              // wave-uniform
     const bool loads = !SPEC || is_loader;                      // this wave issues DMA
     const int wave = is_loader ? wave_all - NW : wave_all;      // role-local index: loader l feeds what compute wave l would load
@@ -357,7 +378,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
             for (int s = 0; s < PRO; ++s) { issue_a(s); advance(); }
             int slot = 0;
             for (int s = 0; s < nst; ++s) {
-                wait_stage<NS, A_J, LPS>(s, nst);
+                if constexpr (SPEC_EFF == 2) wait_landed<NS, A_J, LPS>(s + 1 < nst ? s + 1 : nst - 1, s, nst);      // ... and stage s + 1
+                else wait_stage<NS, A_J, LPS>(s, nst);
                 __builtin_amdgcn_s_barrier();     // stage s is in LDS (every loader waited for its pieces); stage s-1 has been read
                 int fill = slot + NS - 1; if (fill >= NS) fill -= NS;
                 if (s < n_main) { issue_a(fill); issue_b(fill); advance(); }
@@ -479,8 +501,63 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
         }
         if (++slot == NS) slot = 0;
     };
-    for (int s = 0; s < n_main; ++s) iteration(s, std::true_type{});
-    for (int s = n_main; s < nst; ++s) iteration(s, std::false_type{});
+    if constexpr (SPEC_EFF == 2) {
+        static_assert(PREC != 0 && NS >= 3, "pipelined fragment reads: bf16 modes, ring of at least 3");
+        constexpr int NP = PREC == 1 ? 3 : 2;                      // MFMA passes per k-half: lo*hi, hi*lo, hi*hi | hi*hi, lo*lo (plain bf16: channels 0-31, 32-63)
+        constexpr int NM = NP * TM * TN, NR = 2 * (TM + TN);       // MFMAs and b128 fragment reads per k-half
+        struct Frag { f32x4 ah[TM], al[TM], bh[TN], bl[TN]; };
+        Frag fr[2];
+        // read r of k-half t of the stage whose A / B rows start at Ab / Bb
+        auto read_one = [&](Frag& f, int r, unsigned Ab, unsigned Bb, int t) {
+            const unsigned ch = (unsigned)(((2 * t + lh) ^ sw) * 16), cl = (unsigned)(((4 + 2 * t + lh) ^ sw) * 16);
+            if (r < TM) f.al[r] = lds_read_b128<0>(Ab + cl + r * 32 * BK * 4);
+            else if (r < TM + TN) f.bh[r - TM] = lds_read_b128<0>(Bb + ch + (r - TM) * 32 * BK * 4);
+            else if (r < 2 * TM + TN) f.ah[r - TM - TN] = lds_read_b128<0>(Ab + ch + (r - TM - TN) * 32 * BK * 4);
+            else f.bl[r - 2 * TM - TN] = lds_read_b128<0>(Bb + cl + (r - 2 * TM - TN) * 32 * BK * 4);
+        };
+        // the NM MFMAs of a k-half in accumulator-rotating order (no two consecutive ones on one accumulator), one fragment read of the
+        // next k-half behind each of the first NR; sched_barrier pins the interleave (hipcc would group the reads otherwise)
+        auto half = [&](const Frag& cur, Frag& nxt, auto prefetch_tag, unsigned Ab, unsigned Bb, int t_next) {
+            constexpr bool prefetch = decltype(prefetch_tag)::value;      // compile time: a run-time test would put a branch behind every MFMA
+#pragma unroll
+            for (int m = 0; m < (NM > NR ? NM : NR); ++m) {
+                if (m < NM) {
+                    const int p_ = m / (TM * TN), i = (m % (TM * TN)) / TN, j = m % TN;
+                    const bool a_lo = PREC == 1 ? p_ == 0 : p_ == 1, b_lo = PREC == 1 ? p_ == 1 : p_ == 1;
+                    const bf16x8 xa = __builtin_bit_cast(bf16x8, a_lo ? cur.al[i] : cur.ah[i]);
+                    const bf16x8 xb = __builtin_bit_cast(bf16x8, b_lo ? cur.bl[j] : cur.bh[j]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, xb, acc[i][j], 0, 0, 0);
+                }
+                if (m < NR && prefetch) read_one(nxt, m, Ab, Bb, t_next);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        __builtin_amdgcn_s_barrier();                                     // #0: stages 0 and 1 are in LDS
+        {
+            const unsigned Ab = a_base, Bb = b_base;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) read_one(fr[0], r, Ab, Bb, 0);  // the only exposed fragment reads of the tile
+        }
+        int nslot = 1;
+        auto stage = [&](int s, auto more_tag) {
+            if (s > 0) __builtin_amdgcn_s_barrier();                      // #s: stage s + 1 is in LDS; everyone has finished reading stage s - 1
+            const unsigned Ab = a_base + (unsigned)(slot * STAGE * 4), Bb = b_base + (unsigned)(slot * STAGE * 4);
+            const unsigned An = a_base + (unsigned)(nslot * STAGE * 4), Bn = b_base + (unsigned)(nslot * STAGE * 4);
+            wait_lgkmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            half(fr[0], fr[1], std::true_type{}, Ab, Bb, 1);              // k-half 0 of stage s | reads of its k-half 1
+            wait_lgkmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            half(fr[1], fr[0], more_tag, An, Bn, 0);                      // k-half 1 of stage s | reads of k-half 0 of stage s + 1
+            slot = nslot;
+            if (++nslot == NS) nslot = 0;
+        };
+        for (int s = 0; s + 1 < nst; ++s) stage(s, std::true_type{});
+        if (nst > 0) stage(nst - 1, std::false_type{});                   // the last stage has nothing to prefetch
+    } else {
+        for (int s = 0; s < n_main; ++s) iteration(s, std::true_type{});
+        for (int s = n_main; s < nst; ++s) iteration(s, std::false_type{});
+    }
 
     VIDC_STAMP(3);      // main loop done
     dep.mark(3);
@@ -891,6 +968,11 @@ constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {
     {32, 32, 1, 1, 4, 2},     // VIDC_TILE_32x32_K4_D2   64 KB
     {64, 128, 2, 2, 1, 2},    // VIDC_TILE_64x128_D2     48 KB
     {64, 32, 2, 1, 2, 2},     // VIDC_TILE_64x32_K2_D2   48 KB
+    // ---- loader waves + pipelined fragment reads (SPEC = 2): every ds_read in the shadow of an MFMA, across the stage barrier ----
+    {128, 128, 2, 2, 1, 4},   // VIDC_TILE_128x128_D4_P  128 KB
+    {128, 128, 2, 2, 1, 3},   // VIDC_TILE_128x128_D3_P   96 KB
+    {64, 64, 2, 2, 1, 4},     // VIDC_TILE_64x64_D4_P     64 KB (32x32 wave tiles)
+    {128, 64, 2, 2, 1, 4},    // VIDC_TILE_128x64_D4_P    96 KB (64x32 wave tiles)
 };
 constexpr int kFirstLoaderTile = VIDC_TILE_32x64_K2_L;
 
@@ -1066,6 +1148,10 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         case VIDC_TILE_32x32_K4_D2:    rc = launch_tile<32, 32, 1, 1, 4, 2>(a, st, dd.precision); break;
         case VIDC_TILE_64x128_D2:      rc = launch_tile<64, 128, 2, 2, 1, 2>(a, st, dd.precision); break;
         case VIDC_TILE_64x32_K2_D2:    rc = launch_tile<64, 32, 2, 1, 2, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_128x128_D4_P:   rc = launch_tile<128, 128, 2, 2, 1, 4, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_128x128_D3_P:   rc = launch_tile<128, 128, 2, 2, 1, 3, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_64x64_D4_P:     rc = launch_tile<64, 64, 2, 2, 1, 4, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_128x64_D4_P:    rc = launch_tile<128, 64, 2, 2, 1, 4, 2>(a, st, dd.precision); break;
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
     return rc;
