@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvidc.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("VIDC_LIB_NAME", "libvidc.so"))      # (VIDC_LIB_NAME: A/B builds of tools/, never set in production)
 CSRC = os.path.join(_HERE, "csrc")
 
 WARP_PARAMS = 32

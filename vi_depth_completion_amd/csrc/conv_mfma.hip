@@ -22,6 +22,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;       // K-step (floats)
+#ifndef VIDC_FP32_XB
+#define VIDC_FP32_XB 0       // fp32 mode: read the first fragment set of stage s + 1 under the last MFMAs of stage s (see conv_tile).  Built,
+#endif                       // bit-identical, measured SLOWER (round 3, same box: tick 3.62 vs 3.57 ms, 321.6 vs 325.0 frames/s): off.
 constexpr int LDS_LD = 36;   // padded LDS row (floats): 144 B keeps b128 reads of 16 consecutive rows conflict-free
 
 struct ConvArgs {
@@ -180,6 +183,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
     const int tid = threadIdx.x;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     constexpr int SPEC_EFF = (SPEC == 2 && PREC == 0) ? 1 : SPEC;      // the pipelined loop exists for the 16-k bf16 MFMAs only
+    // fp32 mode, "cross-barrier" fragment prefetch: a stage is 4 sub-steps of TM*TN*4 MFMAs of 64 clk, whose fragments are double-buffered
+    // from one sub-step to the next -- but the first set used to be read AFTER the stage barrier, in front of an idle matrix pipe
+    // (~150-200 clk per stage, 5-10 % of an MFMA-bound kernel).  Now the last sub-step of stage s reads the first set of stage s + 1, so
+    // the barrier of stage s must also cover stage s + 1's DMA: every wave waits one stage further ahead (wait_landed).  fp32 stages
+    // last 1000-4000 clk; needs NS >= 3 (a 2-deep ring refills the slot it would read).  Same MFMA order per accumulator: bit-identical.
+    // Measured: 1.4 % SLOWER in the frame -- with the 3-deep rings of the fp32 tilings the wait one stage further ahead drains the wave's
+    // whole DMA queue every stage, and an HBM-cold weight stage takes longer to land (~2500 clk under load) than the 3/4 stage it is now
+    // given; a 4-deep ring would cost the second workgroup per CU.  Compiled out (VIDC_FP32_XB=0); `make xb` / VIDC_LIB_NAME=libvidc_xb.so for A/B.
+    constexpr bool XB = VIDC_FP32_XB && PREC == 0 && NS >= 3 && !CHAIN;
     const bool is_loader = SPEC && wave_all >= NW;              // wave-uniform
     const bool loads = !SPEC || is_loader;                      // this wave issues DMA
     const int wave = is_loader ? wave_all - NW : wave_all;      // role-local index: loader l feeds what compute wave l would load
@@ -378,7 +390,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
             for (int s = 0; s < PRO; ++s) { issue_a(s); advance(); }
             int slot = 0;
             for (int s = 0; s < nst; ++s) {
-                if constexpr (SPEC_EFF == 2) wait_landed<NS, A_J, LPS>(s + 1 < nst ? s + 1 : nst - 1, s, nst);      // ... and stage s + 1
+                if constexpr (SPEC_EFF == 2 || XB) wait_landed<NS, A_J, LPS>(s + 1 < nst ? s + 1 : nst - 1, s, nst);      // ... and stage s + 1
                 else wait_stage<NS, A_J, LPS>(s, nst);
                 __builtin_amdgcn_s_barrier();     // stage s is in LDS (every loader waited for its pieces); stage s-1 has been read
                 int fill = slot + NS - 1; if (fill >= NS) fill -= NS;
@@ -408,11 +420,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
     // between MFMAs); false_type: the last NS-1 iterations, which consume what is already in flight and issue nothing --
     // so no DMA is outstanding when the loop ends and the epilogue does not have to drain any.
     int slot = 0;
+    f32x4 fa[2][TM], fb[2][TN];            // fp32 fragments (live across stages with XB)
     auto iteration = [&](int s, auto issue_tag) {
         // DMA issue order: prologue B_0..B_{PRO-1}, A_0..A_{PRO-1}, then per iteration A, B.  Stage s < PRO has landed when
         // only the (PRO-1-s) younger prologue A groups and the s stages issued by the loop remain; from s = PRO on, when at
         // most NS-2 whole stages remain.
-        if constexpr (!SPEC) wait_stage<NS, A_J, LPS>(s, nst);      // SPEC: the loader waves wait for their DMA before this barrier
+        if constexpr (!SPEC) {      // SPEC: the loader waves wait for their DMA before this barrier
+            if constexpr (XB) wait_landed<NS, A_J, LPS>(s + 1 < nst ? s + 1 : nst - 1, s, nst);
+            else wait_stage<NS, A_J, LPS>(s, nst);
+        }
         __builtin_amdgcn_s_barrier();     // every wave's pieces of stage s are in LDS; everyone finished stage s-1
         if (s == 0) VIDC_STAMP(2);      // first stage landed
         int fill = slot + NS - 1; if (fill >= NS) fill -= NS;     // the slot read in iteration s-1: free since the barrier
@@ -465,11 +481,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            f32x4 fa[2][TM], fb[2][TN];
+            if (!XB || s == 0) {           // (XB: the previous stage's last sub-step has read this set already)
     #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = lds_read_b128<0>(Ab + coff[0] + i * 32 * BK * 4);
+                for (int i = 0; i < TM; ++i) fa[0][i] = lds_read_b128<0>(Ab + coff[0] + i * 32 * BK * 4);
     #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[0][j] = lds_read_b128<0>(Bb + coff[0] + j * 32 * BK * 4);
+                for (int j = 0; j < TN; ++j) fb[0][j] = lds_read_b128<0>(Bb + coff[0] + j * 32 * BK * 4);
+            }
     #pragma unroll
             for (int sub = 0; sub < BK / 8; ++sub) {
                 const int cur = sub & 1, nxt = cur ^ 1;
@@ -479,6 +496,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
     #pragma unroll
                     for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read_b128<0>(Bb + coff[sub + 1] + j * 32 * BK * 4);
                     wait_lgkmcnt<TM + TN>();      // the reads of `cur` are complete (LDS returns in order)
+                } else if (XB && s + 1 < nst) {   // first set of the NEXT stage (its DMA is covered by this stage's barrier), into fa[0] / fb[0]
+                    int ns_ = slot + 1; if (ns_ == NS) ns_ = 0;
+                    const unsigned An = a_base + (unsigned)(ns_ * STAGE * 4), Bn = b_base + (unsigned)(ns_ * STAGE * 4);
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[nxt][i] = lds_read_b128<0>(An + coff[0] + i * 32 * BK * 4);
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read_b128<0>(Bn + coff[0] + j * 32 * BK * 4);
+                    wait_lgkmcnt<TM + TN>();
                 } else {
                     wait_lgkmcnt<0>();
                 }
