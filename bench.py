@@ -148,7 +148,8 @@ TILE_TEMPLATE = {"128x128": (128, 128, 2, 2, 1, 2), "128x64": (128, 64, 2, 2, 1,
                  "32x64k2d2": (32, 64, 1, 2, 2, 2), "64x64d2": (64, 64, 2, 2, 1, 2), "32x32k4d2": (32, 32, 1, 1, 4, 2), "64x128d2": (64, 128, 2, 2, 1, 2),
                  "64x32k2d2": (64, 32, 2, 1, 2, 2),
                  # loader waves + pipelined fragment reads: conv_igemm_f32<..., PREC, 2>
-                 "128x128d4P": (128, 128, 2, 2, 1, 4), "128x128d3P": (128, 128, 2, 2, 1, 3), "64x64d4P": (64, 64, 2, 2, 1, 4), "128x64d4P": (128, 64, 2, 2, 1, 4)}
+                 "128x128d4P": (128, 128, 2, 2, 1, 4), "128x128d3P": (128, 128, 2, 2, 1, 3), "64x64d4P": (64, 64, 2, 2, 1, 4), "128x64d4P": (128, 64, 2, 2, 1, 4),
+                 "64x64k2d4P": (64, 64, 2, 2, 2, 4), "64x32k2d5P": (64, 32, 2, 1, 2, 5), "32x64k2d5P": (32, 64, 1, 2, 2, 5)}
 
 
 def kernel_name(tile, prec):

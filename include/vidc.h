@@ -134,7 +134,8 @@ enum vidc_conv_tile { VIDC_TILE_AUTO = 0, VIDC_TILE_128x128 = 1, VIDC_TILE_128x6
                       /* _P: loader waves + pipelined fragment reads -- every ds_read of the compute waves is issued behind an MFMA, the
                        * first k-half of the next stage across the stage barrier (bf16x3 / bf16; fp32 operands run the _L form) */
                       VIDC_TILE_128x128_D4_P = 33, VIDC_TILE_128x128_D3_P = 34, VIDC_TILE_64x64_D4_P = 35, VIDC_TILE_128x64_D4_P = 36,
-                      VIDC_TILE_COUNT = 37 };
+                      VIDC_TILE_64x64_K2_D4_P = 37, VIDC_TILE_64x32_K2_D5_P = 38, VIDC_TILE_32x64_K2_D5_P = 39,
+                      VIDC_TILE_COUNT = 40 };
 
 /* Arithmetic of the contraction.  FP32: v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32, the reference mode).
  * BF16X3: every operand is split as x = hi + lo (bf16 each, round-to-nearest-even) and each product is computed as

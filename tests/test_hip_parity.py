@@ -141,7 +141,7 @@ CONV_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)
-@pytest.mark.parametrize("tile", list(range(37)))       # 14..20, 23, 25: the loader-wave variants; 24..27: 64x64 wave tiles; 28..32: 2-deep rings; 33..36: pipelined fragment reads
+@pytest.mark.parametrize("tile", list(range(40)))       # 14..20, 23, 25: the loader-wave variants; 24..27: 64x64 wave tiles; 28..32: 2-deep rings; 33..36: pipelined fragment reads
 def test_conv_tiles(shape, tile):
     from vi_depth_completion_amd import ops
     B, H, W, cin, cout, k, stride, groups = shape
@@ -181,7 +181,7 @@ def _split_bf16(t):
 
 
 @pytest.mark.parametrize("shape", [CONV_SHAPES[1], CONV_SHAPES[2], CONV_SHAPES[4], CONV_SHAPES[5], CONV_SHAPES[7], CONV_SHAPES[8]])
-@pytest.mark.parametrize("tile", [0, 1, 4, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 33, 34, 35, 36])
+@pytest.mark.parametrize("tile", [0, 1, 4, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 33, 34, 35, 36, 37, 38, 39])
 def test_conv_bf16x3(shape, tile):
     """Split-bf16 3-pass mode vs an exact CPU emulation of the same arithmetic (hi*hi + hi*lo + lo*hi in fp32:
     bf16 x bf16 products are exact in fp32, so only the summation order differs) and vs true fp32 (2^-16 class)."""
@@ -206,7 +206,7 @@ def test_conv_bf16x3(shape, tile):
 
 
 @pytest.mark.parametrize("shape", [CONV_SHAPES[2], CONV_SHAPES[5], CONV_SHAPES[8]])
-@pytest.mark.parametrize("pair", [(25, 34), (25, 33), (17, 35), (20, 36)])
+@pytest.mark.parametrize("pair", [(25, 34), (25, 33), (17, 35), (20, 36), (18, 37), (23, 38), (15, 39)])
 def test_pipelined_fragment_reads_are_bit_identical(shape, pair):
     """SPEC 2 tilings (every fragment read behind an MFMA, the next stage's first k-half read across the stage barrier, ring one slot
     deeper) against the loader-wave tiling of the same BM x BN: same K order and, per accumulator, the same MFMA order (lo*hi, hi*lo,

@@ -27,7 +27,8 @@ OUT = os.path.join(ROOT, "vi_depth_completion_amd", "conv_tuning.json")
 TILE_DIMS = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (64, 64), 6: (32, 64), 7: (32, 32), 8: (32, 128), 9: (32, 32),
              10: (32, 64), 11: (32, 32), 12: (32, 128), 13: (64, 64), 14: (32, 64), 15: (32, 64), 16: (32, 32), 17: (64, 64), 18: (64, 64),
              19: (64, 128), 20: (128, 64), 21: (64, 32), 22: (64, 32), 23: (64, 32), 24: (128, 128), 25: (128, 128), 26: (256, 128), 27: (128, 256),
-             28: (32, 64), 29: (64, 64), 30: (32, 32), 31: (64, 128), 32: (64, 32), 33: (128, 128), 34: (128, 128), 35: (64, 64), 36: (128, 64)}
+             28: (32, 64), 29: (64, 64), 30: (32, 32), 31: (64, 128), 32: (64, 32), 33: (128, 128), 34: (128, 128), 35: (64, 64), 36: (128, 64),
+             37: (64, 64), 38: (64, 32), 39: (32, 64)}
 
 
 def time_desc(lib, d, st, pool, junk, copies=20):

@@ -998,6 +998,9 @@ constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {
     {128, 128, 2, 2, 1, 3},   // VIDC_TILE_128x128_D3_P   96 KB
     {64, 64, 2, 2, 1, 4},     // VIDC_TILE_64x64_D4_P     64 KB (32x32 wave tiles)
     {128, 64, 2, 2, 1, 4},    // VIDC_TILE_128x64_D4_P    96 KB (64x32 wave tiles)
+    {64, 64, 2, 2, 2, 4},     // VIDC_TILE_64x64_K2_D4_P 128 KB (16 waves)
+    {64, 32, 2, 1, 2, 5},     // VIDC_TILE_64x32_K2_D5_P 120 KB
+    {32, 64, 1, 2, 2, 5},     // VIDC_TILE_32x64_K2_D5_P 120 KB
 };
 constexpr int kFirstLoaderTile = VIDC_TILE_32x64_K2_L;
 
@@ -1177,6 +1180,9 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         case VIDC_TILE_128x128_D3_P:   rc = launch_tile<128, 128, 2, 2, 1, 3, 2>(a, st, dd.precision); break;
         case VIDC_TILE_64x64_D4_P:     rc = launch_tile<64, 64, 2, 2, 1, 4, 2>(a, st, dd.precision); break;
         case VIDC_TILE_128x64_D4_P:    rc = launch_tile<128, 64, 2, 2, 1, 4, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_64x64_K2_D4_P:  rc = launch_tile<64, 64, 2, 2, 2, 4, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_64x32_K2_D5_P:  rc = launch_tile<64, 32, 2, 1, 2, 5, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_32x64_K2_D5_P:  rc = launch_tile<32, 64, 1, 2, 2, 5, 2>(a, st, dd.precision); break;
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
     return rc;

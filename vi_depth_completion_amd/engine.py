@@ -158,7 +158,7 @@ def default_precision(flops):
 
 
 # LDS bytes of the tilings (NS * (BM + BN) * 32 floats * WKW) and, for the co-residency experiment, the nearest tiling of at most 80 KB
-_TILE_LDS_KB = {33: 128, 34: 96, 35: 64, 36: 96, 28: 48, 29: 32, 30: 64, 31: 48, 32: 48, 1: 64, 2: 72, 3: 72, 4: 64, 5: 96, 6: 72, 7: 96, 8: 80, 9: 128, 10: 120, 11: 128, 12: 120, 13: 128, 14: 72, 15: 120, 16: 128, 17: 64,
+_TILE_LDS_KB = {33: 128, 34: 96, 35: 64, 36: 96, 37: 128, 38: 120, 39: 120, 28: 48, 29: 32, 30: 64, 31: 48, 32: 48, 1: 64, 2: 72, 3: 72, 4: 64, 5: 96, 6: 72, 7: 96, 8: 80, 9: 128, 10: 120, 11: 128, 12: 120, 13: 128, 14: 72, 15: 120, 16: 128, 17: 64,
                 18: 128, 19: 72, 20: 72, 21: 72, 22: 120, 23: 120, 24: 96, 25: 96, 26: 144, 27: 144}
 _TILE_SMALL = {5: 4, 13: 4, 18: 4, 7: 6, 9: 6, 10: 6, 11: 6, 15: 6, 16: 6, 12: 8, 22: 21, 23: 21, 24: 1, 25: 1, 26: 1, 27: 1}
 
