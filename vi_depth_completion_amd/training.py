@@ -147,6 +147,12 @@ class DepthCompletionTrainer:
         self._pack_items, self._pack_table, self._packed_fresh = [], None, False
         self.use_graph = os.environ.get("VIDC_TRAIN_GRAPH", "1") != "0"
         self._graphs, self._graph_seen = {}, {}
+        # Weight gradients off the backward's critical path: dW of a conv (two operand transposes, a GEMM, a permute, the bias column sum --
+        # 4-5 launches) depends on dY only and nothing downstream depends on it until Adam, so it runs on a side stream of its lane while
+        # the lane goes on with the data gradient (in the captured graph: a parallel branch per conv).  The chain of a pyramid's ~100
+        # layers is what bounds the step (three pyramids already run side by side), and this takes a third of the launches out of it.
+        self.wgrad_side = os.environ.get("VIDC_TRAIN_WGRAD_STREAM", "1") != "0"
+        self._wgrad_streams, self._wgrad_used = {}, []
         self._retired = []          # outgrown scratch / workspace buffers that captured graphs still address (see _retire)
         self._keepalive = []        # backward closures already run in the current _run_tape, kept until the stream lanes have joined
         self.tune_hook = None      # tools/autotune_train.py: called with every conv descriptor before it is planned
@@ -178,6 +184,33 @@ class DepthCompletionTrainer:
     def _record(self, fn):
         fn._lane = self._cur
         self.tape.append(fn)
+
+    def _beside(self, fn):
+        """Runs `fn` (launches that nothing on the current lane waits for before the end of the backward) on the lane's side stream, with
+        its own scratch / split-K workspace key; `_join_wgrad` makes the main stream wait for all of them."""
+        if not (self.wgrad_side and self.n_lanes > 1):
+            fn()
+            return
+        lane = self._cur
+        cur = torch.cuda.current_stream()
+        side = self._wgrad_streams.get(lane)
+        if side is None:
+            side = self._wgrad_streams[lane] = torch.cuda.Stream(device=self.device)
+        side.wait_stream(cur)                     # dY (and its ReLU mask) are complete on the lane
+        self._keepalive.append(fn)                # fn owns tensors of the LANE's allocator pool (the masked dY): alive until the join
+        self._cur = lane + 8
+        try:
+            with torch.cuda.stream(side):
+                fn()
+        finally:
+            self._cur = lane
+        if side not in self._wgrad_used:
+            self._wgrad_used.append(side)
+
+    def _join_wgrad(self, main):
+        for side in self._wgrad_used:
+            main.wait_stream(side)
+        self._wgrad_used = []
 
     def _lane_streams(self):
         if self._lanes is None:
@@ -339,14 +372,17 @@ class DepthCompletionTrainer:
                 L.check(L.lib().vidc_relu_backward(L.ptr(g), L.ptr(y.t), L.ptr(gm), y.rows, co, _ld(g), y.ld, co, 0, L.current_stream()), "relu_bwd")
                 g, g_bf = gm, None
             lib = L.lib()
-            # weight gradient and bias gradient (column sums)
-            if not self._wgrad_gemm(g, x, key, (B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad)):
-                sc = self._scratch_bytes(lib.vidc_conv_wgrad_scratch_bytes(B, Ho, Wo, co, ci, kh, kw))
-                L.check(lib.vidc_conv_wgrad(L.ptr(g), L.ptr(x.t), L.ptr(self.grad[key + ".weight"]), B, H, W, ci, x.ld, Ho, Wo, co, _ld(g), kh, kw, stride,
-                                            pad, L.ptr(sc), L.current_stream()), "wgrad")
-            if bias is not None:
-                L.check(lib.vidc_colsum(L.ptr(g), y.rows, co, _ld(g), L.ptr(self.grad[key + ".bias"]), L.ptr(self._train_scratch(y.rows, co)),
-                                        L.current_stream()), "colsum")
+
+            def weight_and_bias_gradient(g=g):     # (column sums for the bias); on the lane's side stream: see __init__
+                if not self._wgrad_gemm(g, x, key, (B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad)):
+                    sc = self._scratch_bytes(lib.vidc_conv_wgrad_scratch_bytes(B, Ho, Wo, co, ci, kh, kw))
+                    L.check(lib.vidc_conv_wgrad(L.ptr(g), L.ptr(x.t), L.ptr(self.grad[key + ".weight"]), B, H, W, ci, x.ld, Ho, Wo, co, _ld(g), kh, kw, stride,
+                                                pad, L.ptr(sc), L.current_stream()), "wgrad")
+                if bias is not None:
+                    L.check(lib.vidc_colsum(L.ptr(g), y.rows, co, _ld(g), L.ptr(self.grad[key + ".bias"]), L.ptr(self._train_scratch(y.rows, co)),
+                                            L.current_stream()), "colsum")
+
+            self._beside(weight_and_bias_gradient)
             if x.grad is False:                              # network input: no data gradient wanted
                 return
             # data gradient: the conv kernel on flipped / transposed weights; a strided conv spreads dY over the input grid first
@@ -635,6 +671,7 @@ class DepthCompletionTrainer:
                 forked = []
                 fn()
                 if stop_after_decoder and getattr(fn, "_decoder_done", False):
+                    self._join_wgrad(main)                # the decoder's weight gradients are complete before their all-reduce starts
                     return                                # (closures stay parked: the second call releases them after its join)
                 continue
             side = self._lane_streams()[lane - 1]
@@ -647,6 +684,7 @@ class DepthCompletionTrainer:
             self._cur = 0
         for side in forked:
             main.wait_stream(side)
+        self._join_wgrad(main)
         self._keepalive = []                              # every lane has joined: nothing queued anywhere still touches these tensors
 
     @torch.no_grad()
