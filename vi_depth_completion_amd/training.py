@@ -147,11 +147,13 @@ class DepthCompletionTrainer:
         self._pack_items, self._pack_table, self._packed_fresh = [], None, False
         self.use_graph = os.environ.get("VIDC_TRAIN_GRAPH", "1") != "0"
         self._graphs, self._graph_seen = {}, {}
-        # Weight gradients off the backward's critical path: dW of a conv (two operand transposes, a GEMM, a permute, the bias column sum --
-        # 4-5 launches) depends on dY only and nothing downstream depends on it until Adam, so it runs on a side stream of its lane while
-        # the lane goes on with the data gradient (in the captured graph: a parallel branch per conv).  The chain of a pyramid's ~100
-        # layers is what bounds the step (three pyramids already run side by side), and this takes a third of the launches out of it.
-        self.wgrad_side = os.environ.get("VIDC_TRAIN_WGRAD_STREAM", "1") != "0"
+        # Opt-in experiment (VIDC_TRAIN_WGRAD_STREAM=1), measured SLOWER and therefore off: dW of a conv (two operand transposes, a GEMM, a
+        # permute, the bias column sum -- 4-5 launches) depends on dY only and nothing depends on it until Adam, so it can run on a side
+        # stream of its lane while the lane goes on with the data gradient (in the captured graph: a parallel branch per conv), taking a
+        # third of the launches out of a pyramid's dependency chain.  Round 3, batch 8, same box, identical losses: 41.6 ms per step
+        # against 32.6 in bf16, 80.4 against 71.6 in fp32 -- ~340 extra fork / join edges per step cost more than the shorter chain
+        # saves (the same finding as for side streams inside the inference graphs).
+        self.wgrad_side = os.environ.get("VIDC_TRAIN_WGRAD_STREAM", "0") == "1"
         self._wgrad_streams, self._wgrad_used = {}, []
         self._retired = []          # outgrown scratch / workspace buffers that captured graphs still address (see _retire)
         self._keepalive = []        # backward closures already run in the current _run_tape, kept until the stream lanes have joined
