@@ -30,8 +30,8 @@ done
 cd $R
 CMD="rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE> -- python3 tools/frame_replay.py 20 (VIDC_EXEC=eager"
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
-python tools/pmc_to_json.py $O/frame_pmc_mixed.txt $O/per_op.tsv 1 "$CMD, VIDC_PRECISION=mixed; profiles/r3_frame_pmc_mixed.txt)" --out $O/pmc_traffic.json
-python tools/pmc_to_json.py $O/frame_pmc_fp32.txt $O/per_op.tsv.fp32 0 "$CMD, VIDC_PRECISION=fp32; profiles/r3_frame_pmc_fp32.txt)" --out $O/pmc_traffic.json
+python tools/pmc_to_json.py $O/frame_pmc_mixed.txt mixed "$CMD, VIDC_PRECISION=mixed; profiles/r3_frame_pmc_mixed.txt)" --out $O/pmc_traffic.json
+python tools/pmc_to_json.py $O/frame_pmc_fp32.txt fp32 "$CMD, VIDC_PRECISION=fp32; profiles/r3_frame_pmc_fp32.txt)" --out $O/pmc_traffic.json
 python bench.py --batch 2 --steps 100 --warmup 10 --no-cpu-baseline --no-sequential-leg 2>/dev/null | tail -1 > $O/bench_line_batch2.json
 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/pytest_gpu.log
 head -4 $O/frame_pmc_mixed.txt $O/frame_pmc_fp32.txt; cut -c1-200 $O/bench_line.json; cat $O/pytest_gpu.log

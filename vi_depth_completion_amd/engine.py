@@ -521,7 +521,7 @@ class Program:
         if os.environ.get("VIDC_LDS_CAP_KB"):          # experiment knob (tools/dual_stream_bench.py): tilings that leave room for a second
             d.tile = _capped_tile(d.tile, int(os.environ["VIDC_LDS_CAP_KB"]))      # workgroup of another stream on the CU
         self._keep += [wp, s1, b1]
-        return "conv:%s:%s:sk%d:%s %s" % (keys[0], L.TILE_NAMES[d.tile], d.splitk, "bf16x3" if prec else "fp32", sig)
+        return "conv:%s:%s:sk%d:%s %s flags=0x%x" % (keys[0], L.TILE_NAMES[d.tile], d.splitk, "bf16x3" if prec else "fp32", sig, d.flags)
 
     def _fuse_chains(self):
         """Runs of consecutive small convs (M <= VIDC_CHAIN_MAX_M, same groups <= 8, same arithmetic mode, one stream) become ONE
