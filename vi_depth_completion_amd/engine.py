@@ -614,7 +614,7 @@ class Program:
             self._fuse_splits()
         self._chains, self._chain_descs, self.n_chains = [], [], 0
         # Opt-in (VIDC_CHAIN=1): measured on MI355X the XCD-local persistent chain is SLOWER than the per-layer launches it replaces
-        # (1.69 ms vs 1.1 ms for the 79 layer3/4 convs of a tick: half the chip, LDS-DMA-latency-bound stages).
+        # (1.69 ms vs 1.1 ms for the 79 layer3/4 convs of a tick: half the chip, LDS-DMA-latency-bound stages; round-2 DESIGN.md, git history).
         if os.environ.get("VIDC_CHAIN", "0") == "1":
             self._fuse_chains()
         self.cuts = [next(i for i, op in enumerate(self.ops) if op is mk) + 1 for mk in self._cut_markers]
