@@ -301,9 +301,9 @@ def measure(args, dev, rank, world, precision):
                  "ms_per_frame": round(ms, 3),
                  "timing_note": "per-launch durations are taken on ONE stream (the frame program alone, HIP events between ops, rescaled to its graph replay time); "
                                 "with --lanes 2 launches of the two streams overlap and a kernel trace of the run shows longer per-kernel durations: "
-                                "profiles/r2_kernel_stats_lanes1.csv (--lanes 1) is the trace these numbers agree with",
-                 "traffic_note": "PMC FETCH_SIZE/WRITE_SIZE of this kernel class: profiles/ (rocprofv3 --pmc on the whole "
-                                 "bench process segfaults in rocprofv3 on this pool, so counters are collected on tools/conv_bench.py)"}
+                                "profiles/r3_kernel_stats_mixed.csv / r3_kernel_stats_fp32.csv (--lanes 1) are the traces these numbers agree with",
+                 "traffic_note": "no PMC pass on file for this instantiation in profiles/pmc_traffic.json (tools/evidence_r3.sh collects them on "
+                                 "tools/frame_replay.py: rocprofv3 --pmc on the whole bench process segfaults in rocprofv3 on this pool)"}
             if prec:
                 r.update(executed_tflops=round(3 * ach, 2), frac_executed=round(3 * ach / peak, 4))
             return r

@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--fp32-only", action="store_true", help="re-measure only the exact-fp32 configuration of every signature (entries [3], [4] of the "
                                                               "table, and [0], [1] where the mixed mode runs the layer in fp32 too); the bf16x3 choice stays")
     ap.add_argument("--frame-only", action="store_true", help="only the signatures of the software-pipelined frame program (what bench.py times)")
+    ap.add_argument("--merge", action="store_true", help="re-measure every signature of the chosen programs and merge the result over the committed table "
+                                                          "(without it a plain run writes only what it measured)")
+    ap.add_argument("--out", default=OUT, help="where the table is written (default: the package's conv_tuning.json)")
     ap.add_argument("--verbose", action="store_true", help="print every candidate (tile, splitk, us), fastest first, not only the winner")
     ap.add_argument("--dry", action="store_true", help="measure and print, do not write the table")
     ap.add_argument("--only-missing", action="store_true", help="keep the committed table and measure only signatures it lacks")
@@ -110,10 +113,10 @@ def main():
     engine._TUNING = {}                      # measure against the cost-model plan, not an older table
     os.environ["VIDC_PRECISION"] = "fp32"      # record the programs with fp32 inputs (no split ops); both modes are timed below
     table, report = {}, []
-    if (a.only_missing or a.sigs or a.fp32_only or a.frame_only) and os.path.exists(OUT):
+    if (a.only_missing or a.sigs or a.fp32_only or a.frame_only or a.merge) and os.path.exists(OUT):
         table = json.load(open(OUT))
     old_table = dict(table)
-    if a.fp32_only or (a.frame_only and not a.only_missing):
+    if a.fp32_only or ((a.frame_only or a.merge) and not a.only_missing):
         table = {}                               # re-measure; everything not measured in this run is merged back before writing
     if a.sigs:
         pats = [v for v in a.sigs.split(",") if v]
@@ -196,16 +199,16 @@ def main():
                         sig, L.TILE_NAMES[t32], sk32, us32, L.TILE_NAMES[t16], sk16, us16, t_split, "bf16x3" if prec else "fp32"), flush=True)
             del sn, dc
             torch.cuda.empty_cache()
-    if a.fp32_only or a.frame_only:
+    if a.fp32_only or a.frame_only or a.merge:
         merged = dict(old_table)
         merged.update(table)
         table = merged
     if a.dry:
         print("dry run: table not written")
         return
-    with open(OUT, "w") as f:
+    with open(a.out, "w") as f:
         json.dump(dict(sorted(table.items())), f, indent=0)
-    print("wrote %d signatures to %s" % (len(table), OUT))
+    print("wrote %d signatures to %s" % (len(table), a.out))
 
 
 if __name__ == "__main__":

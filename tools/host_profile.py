@@ -2,7 +2,7 @@
 """Where the HOST's time goes per frame in the two-lane stream mode (the mode bench.py times): cProfile over N frames of
 pipeline.run_interleaved on device-resident synthetic frames, plus the wall time per frame and the time the host spends blocked in the
 one wait per frame (PlaneBlock.enrich -> event.synchronize).
-    python tools/host_profile.py [frames] [lanes]"""
+    python tools/host_profile.py [frames] [lanes] [batch] [plane-head: 0|1]      (batch > 1: 320x240 frames, BASELINE configs[2] / [3] shapes)"""
 import cProfile
 import io
 import os
@@ -22,14 +22,14 @@ from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlane
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-    H, W = 256, 320
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    head = len(sys.argv) > 4 and sys.argv[4] == "1"
+    H, W = (256 if B == 1 else 240), 320
     dev = torch.device("cuda")
     torch.set_grad_enabled(False)
-    cc = (0.5 * 319.87654, 0.5 * 239.87603 * H / 240.0)
-    pipe = DepthCompletionPipeline(enriched_samples=200, cc_img=cc, device=dev, rng=np.random.RandomState(1234))
-    pipe.load_state_dicts(S.seeded_state_dict(pipe.surface_normal_cnn.state_dict(), 1234, device=dev), S.seeded_state_dict(pipe.cnn.state_dict(), 1234, device=dev))
-    pipe.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(H, W))
-    pool = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in S.synthetic_batch(1, H, W, 1234, frame0=j).items()} for j in range(4)]
+    import bench
+    pipe, _sn, _dc, _cc, _det = bench.build_pipeline(H, W, dev, head)
+    pool = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in S.synthetic_batch(B, H, W, 1234, frame0=j * B).items()} for j in range(4)]
 
     def run(k):
         for _ in pipe.run_interleaved((pool[i % 4] for i in range(k)), copy_outputs=False, lanes=lanes):
@@ -40,7 +40,7 @@ def main():
     t0 = time.perf_counter()
     run(n)
     wall = time.perf_counter() - t0
-    print("%d frames, %d lanes: %.3f ms per frame wall" % (n, lanes, 1e3 * wall / n))
+    print("%d batches of %d, %d lanes, plane head %s: %.3f ms per batch wall (%.1f frames/s)" % (n, B, lanes, head, 1e3 * wall / n, n * B / wall))
     pr = cProfile.Profile()
     pr.enable()
     run(n)
