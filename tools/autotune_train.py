@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--precisions", default="0,1")
     ap.add_argument("--bf16", action="store_true", help="run the step in the plain-bf16 mode (VIDC_TRAIN_PRECISION=bf16) and measure its launches\n"
                                                         "(K counted in 64-channel units, so they are signatures of their own): fills slots 4, 5 of the entries")
+    ap.add_argument("--remeasure", action="store_true", help="with --bf16: measure every bf16 launch again (e.g. after new tilings were added) instead of "
+                                                             "only the signatures without a bf16 entry; the fp32 / bf16x3 slots are kept")
+    ap.add_argument("--out", default=OUT)
     a = ap.parse_args()
     if a.bf16:
         os.environ["VIDC_TRAIN_PRECISION"] = "bf16"
@@ -86,7 +89,7 @@ def main():
     pool = torch.randn(64 << 20, dtype=torch.float32, device=dev) * 0.05
     junk = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
     precs = [int(v) for v in a.precisions.split(",")]
-    seen, total = {}, {"plan": 0.0, "best": 0.0}
+    seen, total, remeasured = {}, {"plan": 0.0, "best": 0.0}, set()
 
     def hook(d0, role):
         sig = engine.conv_signature(d0)
@@ -141,8 +144,9 @@ def main():
 
     def hook_bf16(d0, role, sig):
         ent = table.get(sig, [0, 0, 0, 0])
-        if len(ent) >= 6 and ent[4]:
+        if len(ent) >= 6 and ent[4] and not (a.remeasure and sig not in remeasured):
             return
+        remeasured.add(sig)
         d = L.ConvDesc.from_buffer_copy(d0)
         d.flags &= ~L.ACCUM
         d.workspace = ws.data_ptr()
@@ -174,8 +178,12 @@ def main():
         us, t, sk = cands[0]
         table[sig] = (list(ent) + [0, 0, 0, 0])[:4] + [t, sk]
         table[sig + "#us"] = [us_plan, us]
-        print("%-5s %-36s bf16   plan %-12s sk%-2d %8.1f us -> %-12s sk%-2d %8.1f us" % (role, sig, L.TILE_NAMES[p.tile], p.splitk, us_plan or -1,
-                                                                                     L.TILE_NAMES[t], sk, us), flush=True)
+        was = ""
+        if len(ent) >= 6 and ent[4]:
+            us_was = dict(((tt, ss), u) for u, tt, ss in cands).get((ent[4], ent[5]))
+            was = "   (table had %s sk%d: %s us)" % (L.TILE_NAMES[ent[4]], ent[5], "%.1f" % us_was if us_was is not None else "-")
+        print("%-5s %-36s bf16   plan %-12s sk%-2d %8.1f us -> %-12s sk%-2d %8.1f us%s" % (role, sig, L.TILE_NAMES[p.tile], p.splitk, us_plan or -1,
+                                                                                       L.TILE_NAMES[t], sk, us, was), flush=True)
 
     cnn = ModifiedFPN().to(dev)
     cnn.load_state_dict(S.seeded_state_dict(cnn.state_dict(), 1234, device=dev))
@@ -195,9 +203,9 @@ def main():
             total["best"] += n * u[1]
     print("conv launches per step: %d over %d signatures; plan %.1f ms -> tuned %.1f ms" % (sum(seen.values()), len(seen), total["plan"] / 1e3, total["best"] / 1e3))
     out = {k: v for k, v in sorted(table.items()) if not k.endswith("#us")}
-    with open(OUT, "w") as f:
+    with open(a.out, "w") as f:
         json.dump(out, f, indent=0)
-    print("wrote %d signatures to %s" % (len(out), OUT))
+    print("wrote %d signatures to %s" % (len(out), a.out))
 
 
 if __name__ == "__main__":
