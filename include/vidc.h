@@ -111,10 +111,6 @@ typedef struct vidc_conv_desc {
                               vidc_pack_conv_weight_bf16x3 (same strides as fp32)     */
     int32_t dilation;      /* tap spacing of the kernel (nn.Conv2d dilation); 0 or 1 = dense                  */
     void* y_split;         /* split-bf16 image of y (VIDC_SPLIT_OUT), or NULL         */
-    const void* prefetch;  /* NULL, or device memory a LATER launch of the stream reads HBM-cold (the next conv's packed weights):
-                              the launch touches its first prefetch_bytes (at most 4 x 128 bytes per thread of the grid) so that they
-                              sit in the Infinity Cache by then.  A hint: no result depends on it.                */
-    int64_t prefetch_bytes;
 } vidc_conv_desc;
 
 /* Workgroup tilings (BM x BN output tile; _Kn = n k-slices reduced inside the workgroup through LDS). */

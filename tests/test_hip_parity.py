@@ -223,54 +223,6 @@ def test_pipelined_fragment_reads_are_bit_identical(shape, pair):
             assert torch.equal(ys[0], ys[1]), (pair, prec, sk)
 
 
-@pytest.mark.parametrize("shape", [CONV_SHAPES[1], CONV_SHAPES[4], CONV_SHAPES[6]])
-@pytest.mark.parametrize("tile", [1, 4, 6, 17, 23, 26, 28, 33, 37])
-def test_conv_prefetch_hint_changes_nothing(shape, tile):
-    """vidc_conv_desc.prefetch makes the launch touch memory a LATER launch will read (the next conv's weights, into the Infinity
-    Cache): a hint.  With it -- any size, also sizes that are no multiple of a line, larger than the grid covers, or tiny -- the result
-    is bit-identical to the launch without it, in every loop form (plain, loader waves, 2-deep ring, pipelined reads; split-K too)
-    and the prefetched buffer is left untouched."""
-    from vi_depth_completion_amd import ops
-    B, H, W, cin, cout, k, stride, groups = shape
-    x, w, s1, b1 = _conv_case(23, B, H, W, cin, cout, k, stride, groups)
-    pad = k // 2
-    for prec, packer in ((1, ops.pack_conv_weight_bf16x3), (0, ops.pack_conv_weight)):
-        wp = torch.stack([packer(wg.to(DEV)) for wg in w])
-        for sk in (1, 2):
-            args = (nhwc(x).to(DEV), wp, s1.to(DEV), b1.to(DEV), k, k, stride, pad)
-            kw = dict(relu1=True, tile=tile, groups=groups, precision=prec, splitk=sk)
-            base = ops.conv2d_bn_act(*args, **kw)
-            for n in (37, 4096, 3_000_001, 40_000_000):
-                other = torch.arange(n, dtype=torch.float32, device=DEV)
-                y = ops.conv2d_bn_act(*args, prefetch=other, **kw)
-                assert torch.equal(y, base), (tile, prec, sk, n)
-                assert torch.equal(other, torch.arange(n, dtype=torch.float32, device=DEV))
-
-
-@pytest.mark.parametrize("precision", ["mixed", "fp32"])
-def test_weight_prefetch_links_leave_the_frame_bit_identical(seeded_weights, precision, monkeypatch):
-    """engine.Program links every conv to the weights of the conv after it (VIDC_PREFETCH_AHEAD, default 1).  The same frames with the
-    links off: identical depth maps, one and two lanes."""
-    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
-    monkeypatch.setenv("VIDC_PRECISION", precision)
-    frames = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in S.synthetic_batch(1, 240, 320, 1234, frame0=170 + i).items()} for i in range(4)]
-    runs = {}
-    for ahead in ("1", "0", "2"):
-        monkeypatch.setenv("VIDC_PREFETCH_AHEAD", ahead)
-        p = DepthCompletionPipeline(enriched_samples=200)
-        p.load_state_dicts(seeded_weights["sn"], seeded_weights["dc"])
-        p.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(240, 320))
-        for lanes in (1, 2):
-            p.rng = np.random.RandomState(9)
-            runs[(ahead, lanes)] = [o.cpu() for o in p.run_interleaved(iter(frames), lanes=lanes)]
-        linked = sum(1 for op in p.frame_program(1, 240, 320).c_ops if op.kind == 1 and op.u.conv.prefetch)
-        assert (linked > 100) == (ahead != "0"), linked
-        del p
-    for key, outs in runs.items():
-        for f, (a, b) in enumerate(zip(outs, runs[("1", 1)])):
-            assert torch.equal(a, b), "frame %d differs (prefetch ahead %s, %d lanes, %s)" % (f, key[0], key[1], precision)
-
-
 @pytest.mark.parametrize("cfg", [(0, 1, 1), (1, 1, 1), (0, 4, 3), (1, 2, 3)])
 def test_conv_fused_split_output(cfg):
     """VIDC_SPLIT_OUT: the split-bf16 image written by the conv / split-K finalize epilogue is bit-identical to splitting

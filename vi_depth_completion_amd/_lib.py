@@ -52,7 +52,6 @@ class ConvDesc(C.Structure):
         ("x_gs", C.c_int64), ("w_gs", C.c_int64), ("y_gs", C.c_int64), ("r_gs", C.c_int64), ("p_gs", C.c_int64),
         ("tile", C.c_int32), ("splitk", C.c_int32), ("precision", C.c_int32), ("dilation", C.c_int32),
         ("y_split", C.c_void_p),
-        ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
     ]
 
 

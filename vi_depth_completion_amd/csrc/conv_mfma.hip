@@ -34,7 +34,6 @@ struct ConvArgs {
     int B, H, W, Cin, ldx, Ho, Wo, Cout, ldy, ldr, KH, KW, stride, pad, flags, groups, dil;
     long long x_gs, w_gs, y_gs, r_gs, p_gs;
     int M, K, ksteps, splitk, tiles_m, tiles_n;
-    const char* pf; unsigned pf_lines;      // Infinity-Cache prefetch for a later launch: 128-byte lines at pf (0: none)
     unsigned dv_tiles_m[3], dv_splitk[3], dv_tiles_n[3], dv_ntaps[3], dv_kw[3];   // {multiplier, shift, d == 1 mask} of fast_div()
 };
 
@@ -88,18 +87,14 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 // Stage s has landed when only DMA groups younger than its own are outstanding.  Issue order: prologue B_0..B_{PRO-1},
 // A_0..A_{PRO-1} (PRO = NS-1; always issued, zero-sourced past the K range), then one (A, B) pair per main-loop iteration
 // s = 0 .. nst-NS; the last NS-1 iterations issue nothing.
-// `pf` = prefetch loads (at most 4) the wave issued between the prologue and the main loop: younger than every prologue stage.
 template <int NS, int A_J, int LPS>
-__device__ __forceinline__ void wait_stage(int s, int nst, int pf = 0) {
+__device__ __forceinline__ void wait_stage(int s, int nst) {
     constexpr int PRO = NS - 1;
-    static_assert((NS - 2) * LPS + 4 <= 63, "vmcnt is a 6-bit counter");
     const int n_main = nst > PRO ? nst - PRO : 0;
     const int loop_issued = s < n_main ? s : n_main;                    // (A, B) pairs issued by the loop before this wait
-    if (s < PRO) {                                                      // its A group is in the prologue's A run
-        wait_vmcnt_dyn<(NS - 2) * LPS + 4>((PRO - 1 - s) * A_J + loop_issued * LPS + pf);
-        return;
-    }
-    const int younger = (loop_issued - (s - PRO) - 1) * LPS;            // stage s was issued by loop iteration s-PRO
+    int younger;
+    if (s < PRO) younger = (PRO - 1 - s) * A_J + loop_issued * LPS;     // its A group is in the prologue's A run
+    else         younger = (loop_issued - (s - PRO) - 1) * LPS;         // stage s was issued by loop iteration s-PRO
     wait_vmcnt_dyn<(NS - 2) * LPS>(younger);      // younger <= (NS-2)*LPS always (A_J <= LPS)
 }
 // The same count for a wait that is not taken in the iteration that consumes the stage: stage q has landed, seen from loop iteration `it`
@@ -204,37 +199,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
     const int wm = wq / WNW, wn = wq - wm * WNW;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     VIDC_STAMP(8);      // kernel arguments arrived, work item decoded
-    // ---- Infinity-Cache prefetch for a LATER launch (vidc_conv_desc.prefetch) -------------------------------------------------------
-    // A small layer's launch is latency: its HBM-cold weight prologue lands ~3400 clk after it was issued.  The weights of the NEXT
-    // conv of the stream are known when this one starts, so every compute wave touches one dword per 128-byte line of them (up to 4
-    // lines per lane): the lines travel HBM -> Infinity Cache (memory side, shared by all XCDs) while this kernel computes, and the next
-    // launch's prologue is served from there (tools/weight_warmth_probe.py: 1.3-1.7 us of a 9-15 us bf16x3 layer-3 launch).
-    // vmcnt retires in order, so WHERE the loads sit in a wave's instruction stream matters: compute waves of the loader tilings issue
-    // no DMA and take them first thing; waves that also feed the ring issue them right after their prologue DMAs -- younger than every
-    // prologue stage (whose waits allow for them: wait_stage's `pf`), older than everything the main loop issues.  Issue is decided per
-    // wave (lanes past the end re-touch the last line), so the count is wave-uniform.  The destination register stays reserved until
-    // the wait after the main loop.  No arithmetic depends on any of it.
-    unsigned pf_keep = 0;
-    auto issue_prefetch = [&]() -> int {
-        int n = 0;
-        if constexpr (!CHAIN) {
-            if (a.pf_lines) {
-                const unsigned per = NW * 64u, total = gridDim.x * per;
-                unsigned line0 = blockIdx.x * per + (unsigned)wave_all * 64u;
-#pragma unroll
-                for (int r = 0; r < 4; ++r, line0 += total)
-                    if (line0 < a.pf_lines) {                                       // wave-uniform
-                        const unsigned line = min(line0 + (unsigned)lane, a.pf_lines - 1u);
-                        const char* p = a.pf + (size_t)line * 128;
-                        asm volatile("global_load_dword %0, %1, off" : "+v"(pf_keep) : "v"(p) : "memory");
-                        ++n;
-                    }
-            }
-        }
-        return n;
-    };
-    int pf_n = 0;
-    if constexpr (SPEC != 0) { if (!is_loader) issue_prefetch(); }
     const int units = a.ksteps;                                       // K in units of 32 floats
     const int stages_total = (units + WKW - 1) / WKW;
     const int st_begin = (int)fast_div((unsigned)(stages_total * kz), a.dv_splitk);          // stages_total * splitk < 2^31
@@ -438,7 +402,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
     } else {
 #pragma unroll
         for (int s = 0; s < PRO; ++s) { issue_a(s); advance(); }     // the B halves of these stages are already in flight
-        pf_n = issue_prefetch();
     }
     VIDC_STAMP(1);      // prologue DMAs issued
 
@@ -464,7 +427,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
         // most NS-2 whole stages remain.
         if constexpr (!SPEC) {      // SPEC: the loader waves wait for their DMA before this barrier
             if constexpr (XB) wait_landed<NS, A_J, LPS>(s + 1 < nst ? s + 1 : nst - 1, s, nst);
-            else wait_stage<NS, A_J, LPS>(s, nst, pf_n);
+            else wait_stage<NS, A_J, LPS>(s, nst);
         }
         __builtin_amdgcn_s_barrier();     // every wave's pieces of stage s are in LDS; everyone finished stage s-1
         if (s == 0) VIDC_STAMP(2);      // first stage landed
@@ -623,9 +586,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
 
     VIDC_STAMP(3);      // main loop done
     dep.mark(3);
-    if constexpr (!CHAIN) {
-        if (a.pf_lines) asm volatile("s_waitcnt vmcnt(0)" ::"v"(pf_keep) : "memory");      // the prefetch loads have written their register (long ago)
-    }
     if (WKW > 1) {
         __syncthreads();
         float* red = smem;
@@ -1113,8 +1073,6 @@ int make_args(const vidc_conv_desc& dd, ConvArgs& a) {
     a.groups = dd.groups; a.dil = dd.dilation > 1 ? dd.dilation : 1; a.x_gs = dd.x_gs; a.w_gs = dd.w_gs; a.y_gs = dd.y_gs; a.r_gs = dd.r_gs; a.p_gs = dd.p_gs;
     a.M = dd.B * dd.Ho * dd.Wo; a.K = dd.KH * dd.KW * dd.Cin; a.ksteps = a.K / BK;
     a.splitk = dd.splitk;
-    a.pf = reinterpret_cast<const char*>(dd.prefetch);
-    a.pf_lines = (dd.prefetch && dd.prefetch_bytes > 0) ? (unsigned)(dd.prefetch_bytes / 128 < (1ll << 20) ? dd.prefetch_bytes / 128 : (1ll << 20)) : 0u;    // <= 128 MiB
     const TileInfo ti = kTiles[dd.tile];
     a.tiles_m = (a.M + ti.bm - 1) / ti.bm;
     a.tiles_n = (a.Cout + ti.bn - 1) / ti.bn;

@@ -774,17 +774,6 @@ class Program:
         for op in conv_ops:
             if op.u.conv.splitk > 1:
                 op.u.conv.workspace = self.workspaces[op.stream_id].data_ptr()
-        # Infinity-Cache prefetch (include/vidc.h, vidc_conv_desc.prefetch): every conv touches the packed weights of the conv that follows
-        # it AHEAD places later in the program (wrapping: the last ones prefetch for the next replay), so that a small layer's weight
-        # prologue is not HBM-cold.  Layers above VIDC_PREFETCH_MB stream their weights at HBM rate anyway and are not prefetched.
-        ahead = int(os.environ.get("VIDC_PREFETCH_AHEAD", "1"))
-        cap = float(os.environ.get("VIDC_PREFETCH_MB", "48")) * 1e6
-        if ahead > 0 and len(conv_ops) > ahead:
-            for i, op in enumerate(conv_ops):
-                nxt = conv_ops[(i + ahead) % len(conv_ops)].u.conv
-                nbytes = 4 * nxt.groups * nxt.Cout * nxt.KH * nxt.KW * nxt.Cin
-                if nxt.w and nbytes <= cap and (nxt.groups == 1 or nxt.w_gs == nxt.Cout * nxt.KH * nxt.KW * nxt.Cin):
-                    op.u.conv.prefetch, op.u.conv.prefetch_bytes = nxt.w, nbytes
         self.c_ops = ops
         self.captured = False
         if dry_run:

@@ -49,9 +49,8 @@ def split_bf16x3(x_nhwc):
 
 def conv2d_bn_act(x, w_packed, scale1, shift1, kh, kw, stride=1, pad=0, relu1=False, scale2=None, shift2=None, relu2=False,
                   residual=None, relu3=False, accumulate_into=None, tile=0, splitk=1, groups=1, precision=0, split_out=None,
-                  no_f32_out=False, workspace=None, prefetch=None):
+                  no_f32_out=False, workspace=None):
     """x: NHWC (B,H,W,G*Cin) contiguous; w_packed: (G,Cout,kh*kw*Cin) or (Cout,K); returns NHWC (B,Ho,Wo,G*Cout).
-    prefetch: a device tensor a later launch will read cold (vidc_conv_desc.prefetch: touched into the Infinity Cache; a hint only).
     precision=1 (bf16x3): x is split here; w_packed must come from pack_conv_weight_bf16x3.
     workspace: optional persistent split-K scratch (float32, zero-initialised once by the caller; include/vidc.h)."""
     _dev(x, w_packed, scale1, shift1)
@@ -103,9 +102,6 @@ def conv2d_bn_act(x, w_packed, scale1, shift1, kh, kw, stride=1, pad=0, relu1=Fa
     elif nbytes:
         ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=x.device)     # zeroed: ticket counters at its head
         d.workspace = L.ptr(ws)
-    if prefetch is not None:
-        _dev(prefetch)
-        d.prefetch, d.prefetch_bytes = L.ptr(prefetch), prefetch.numel() * prefetch.element_size()
     L.check(L.lib().vidc_conv2d_bn_act(C.byref(d), L.current_stream()), "conv2d_bn_act")
     return y
 
