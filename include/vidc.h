@@ -427,6 +427,12 @@ int vidc_bn_train_forward(const float* x, float* y, long long M, int C, int ldx,
 int vidc_bn_train_backward(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
                            int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                            void* dx_bf16, void* scratch, vidc_stream_t stream);
+/* The same, which can also write dx TRANSPOSED as plain bf16 rows dx_bf16_t[C][Mp] (Mp = M rounded up to a multiple of 64, zeros past
+ * M; may be NULL): when the BatchNorm follows a conv, dx is that conv's dY and this is the left operand of its weight-gradient GEMM --
+ * what vidc_im2col_transposed(dY, KH = KW = 1, split = 2) would build with one more launch and one more pass over dY. */
+int vidc_bn_train_backward_t(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
+                             int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                             void* dx_bf16, void* dx_bf16_t, int Mp, void* scratch, vidc_stream_t stream);
 /* out[c] = sum over rows of dy[.][c]: the bias gradient of a convolution. */
 int vidc_colsum(const float* dy, long long M, int C, int ld, float* out, void* scratch, vidc_stream_t stream);
 /* y = a + b, ReLU optional (Bottleneck: relu(bn3(conv3(.)) + identity); decoder: z1 + z2 + z3 + z4). */
@@ -485,7 +491,9 @@ int vidc_conv_wgrad(const float* dy, const float* x, float* dw_oihw, int B, int 
  * "activations" = the rows of dY^T and "weights" = the rows of Xt (both K-contiguous, K = pixels).  vidc_im2col_transposed writes
  * xt[(tap*C + c)][m] = x[b, oy*s - p + kh, ox*s - p + kw, c] (0 outside the image and for m >= B*Ho*Wo; rows Mp long, Mp % 32 == 0);
  * with KH = KW = 1, stride 1, pad 0 it transposes dY; split = 1 writes the rows as split-bf16 operands (vidc_split_bf16x3's layout) for
- * a VIDC_PREC_BF16X3 GEMM, split = 2 as plain bf16 rows (Mp % 64 == 0) for a VIDC_PREC_BF16 one.  vidc_wgrad_permute: dw_oihw[co][ci][tap] = tmp[co][tap*Cin + ci]. */
+ * a VIDC_PREC_BF16X3 GEMM, split = 2 as plain bf16 rows (Mp % 64 == 0) for a VIDC_PREC_BF16 one.  split + 4: the rows in CHANNEL-major
+ * order, xt[(c*KH*KW + tap)][m] -- the GEMM's output row [co][c*KH*KW + tap] is then the OIHW layout of the weight gradient itself and
+ * can be written straight into the parameter's .grad.  vidc_wgrad_permute (tap-major order): dw_oihw[co][ci][tap] = tmp[co][tap*Cin + ci]. */
 int vidc_im2col_transposed(const float* x, float* xt, int B, int H, int W, int C, int ldx, int Ho, int Wo, int KH, int KW, int stride, int pad,
                            int Mp, int split, vidc_stream_t stream);
 int vidc_wgrad_permute(const float* tmp, float* dw_oihw, int Cout, int Cin, int taps, vidc_stream_t stream);

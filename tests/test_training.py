@@ -276,6 +276,18 @@ def test_im2col_transposed_operands(k, stride, pad, C, H, W):
     xb = torch.empty(k * k * C, Mq // 2, device=DEV)
     L.check(lib.vidc_im2col_transposed(L.ptr(xd), L.ptr(xb), B, H, W, C, C, Ho, Wo, k, k, stride, pad, Mq, 2, st), "im2col^T bf16")
     assert torch.equal(xb.view(torch.bfloat16).cpu(), F.pad(want, (0, Mq - Mp)).to(torch.bfloat16))
+    # split + 4: the same rows in channel-major order (c * taps + tap) = F.unfold's own row order: the wgrad GEMM then writes OIHW directly
+    want_cm = F.pad(cols.permute(1, 0, 2).reshape(C * k * k, M), (0, Mp - M))
+    for fmt, got_ref in ((0, xt), (1, xs)):
+        xc = torch.full((k * k * C, Mp), float("nan"), device=DEV)
+        L.check(lib.vidc_im2col_transposed(L.ptr(xd), L.ptr(xc), B, H, W, C, C, Ho, Wo, k, k, stride, pad, Mp, fmt | 4, st), "im2col^T channel-major")
+        if fmt == 0:
+            assert torch.equal(xc.cpu(), want_cm)
+        perm = got_ref.view(k * k, C, Mp).permute(1, 0, 2).reshape(C * k * k, Mp)
+        assert torch.equal(xc.view(torch.int32).cpu(), perm.contiguous().view(torch.int32).cpu())
+    xcb = torch.empty(k * k * C, Mq // 2, device=DEV)
+    L.check(lib.vidc_im2col_transposed(L.ptr(xd), L.ptr(xcb), B, H, W, C, C, Ho, Wo, k, k, stride, pad, Mq, 2 | 4, st), "im2col^T bf16 channel-major")
+    assert torch.equal(xcb.view(torch.bfloat16).cpu(), F.pad(want_cm, (0, Mq - Mp)).to(torch.bfloat16))
 
 
 def _bf16_round(t):
@@ -498,6 +510,59 @@ def test_plain_bf16_training_mode(golden_dir, seeded_weights, monkeypatch):
     assert cos > 0.99
     assert losses["bf16"][-1] < 0.9 * losses["bf16"][0]
     assert abs(losses["bf16"][-1] - losses["fp32"][-1]) < 0.05 * losses["fp32"][-1]
+
+
+@gpu
+def test_fused_transposed_gradient_of_the_bn_backward_is_bit_identical(golden_dir, seeded_weights, monkeypatch):
+    """bf16 mode: the BatchNorm backward behind a conv also writes that conv's dY transposed as bf16 rows (vidc_bn_train_backward_t), the
+    left operand of its weight-gradient GEMM, instead of a transpose launch per conv.  Same values rounded once from the same fp32
+    result: the whole flat gradient and the loss are identical to the step with the separate transposes (VIDC_TRAIN_DYT_FUSED=0).
+    The same comparison covers the weight-gradient GEMM writing the parameter's .grad in place (channel-major operand rows: its output is
+    OIHW) against the staged form with a permute / copy launch per conv (VIDC_TRAIN_WGRAD_INPLACE=0).
+    And the kernel alone against vidc_bn_train_backward + vidc_im2col_transposed on a ragged shape (M not a multiple of 64)."""
+    import ctypes as C
+    from vi_depth_completion_amd import _lib as L
+    from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
+    from vi_depth_completion_amd.training import DepthCompletionTrainer
+    lib = L.lib()
+    B, H, W, Cc = 2, 9, 13, 192
+    M, Mp = B * H * W, (B * H * W + 63) // 64 * 64
+    g = torch.Generator().manual_seed(3)
+    dy, x = torch.randn(B, H, W, Cc, generator=g).to(DEV), torch.randn(B, H, W, Cc, generator=g).to(DEV)
+    yr = torch.randn(B, H, W, Cc, generator=g).to(DEV)
+    gamma, mean, rstd = (torch.rand(Cc, generator=g) + 0.5).to(DEV), torch.randn(Cc, generator=g).to(DEV) * 0.1, (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+    sc = torch.empty(lib.vidc_train_scratch_bytes(M, Cc), dtype=torch.uint8, device=DEV)
+    outs = []
+    for fused in (False, True):
+        dx, dxb = torch.empty_like(dy), torch.zeros(B, H, W, Cc // 2, device=DEV)
+        dxt = torch.full((Cc, Mp // 2), 7.0, device=DEV)
+        dg, db = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+        L.check(lib.vidc_bn_train_backward_t(L.ptr(dy), L.ptr(x), L.ptr(yr), L.ptr(dx), M, Cc, Cc, Cc, Cc, Cc, L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
+                                             L.ptr(dg), L.ptr(db), L.ptr(dxb), L.ptr(dxt) if fused else None, Mp, L.ptr(sc), L.current_stream()), "bn_bwd_t")
+        if not fused:
+            L.check(lib.vidc_im2col_transposed(L.ptr(dx), L.ptr(dxt), B, H, W, Cc, Cc, H, W, 1, 1, 1, 0, Mp, 2, L.current_stream()), "transpose")
+        outs.append([t.cpu() for t in (dx, dxb, dxt, dg, db)])
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    f, image, normal, depth_in, gt = _train_fixture(golden_dir)
+    ins = [t.to(DEV) for t in (image, normal, depth_in, gt)]
+    monkeypatch.setenv("VIDC_TRAIN_PRECISION", "bf16")
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("VIDC_TRAIN_DYT_FUSED", fused)
+        monkeypatch.setenv("VIDC_TRAIN_WGRAD_INPLACE", fused)      # (0: tap-major operand rows, staging buffer, permute / copy launches)
+        cnn = ModifiedFPN().to(DEV)
+        st = cnn.state_dict()
+        st.update({k: v.to(DEV) for k, v in seeded_weights["dc"].items()})
+        cnn.load_state_dict(st)
+        cnn.train()
+        tr = DepthCompletionTrainer(cnn, float(f["lr"]))
+        loss, _ = tr.forward_backward(*ins)
+        res[fused] = (float(loss), tr.flat_g.clone().cpu())
+        del tr, cnn
+        torch.cuda.empty_cache()
+    assert res["1"][0] == res["0"][0]
+    assert torch.equal(res["1"][1], res["0"][1])
 
 
 @gpu

@@ -180,6 +180,66 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, c
                                                                     vidc::bf16_rne(o[2]) | ((unsigned)vidc::bf16_rne(o[3]) << 16));
 }
 
+// The same map on 64 pixels x 64 channels per workgroup, which ALSO writes the transpose of dx as plain bf16 rows [C][Mp] (zero for
+// m >= M): dx of the BatchNorm behind a conv is that conv's dY, and its weight-gradient GEMM reads dY^T in exactly this format
+// (vidc_im2col_transposed(..., KH = KW = 1, split = 2) -- one launch and one pass over dY per conv that this kernel makes unnecessary).
+// LDS tile [pixel][channel], pitch 65 floats, both phases as in im2col_t64_kernel; every value is rounded once, from the fp32 result.
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_t64_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ dx, int M, int C,
+                        int lddy, int ldx, int ldy, int lddx, const float* __restrict__ mean, const float* __restrict__ rstd,
+                        const float* __restrict__ gamma, const double* __restrict__ sums, unsigned short* __restrict__ dx_bf16,
+                        unsigned short* __restrict__ dx_bf16_t, int Mp) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int c = c0 + tx * 4;
+    const double invM = 1.0 / (double)M;
+    float mu[4], rs[4], gs[4], m1[4], m2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ck = c + k < C ? c + k : C - 1;
+        mu[k] = mean[ck]; rs[k] = rstd[ck]; gs[k] = gamma[ck] * rs[k];
+        m1[k] = (float)(sums[ck] * invM); m2[k] = (float)(sums[C + ck] * invM);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + ty + 16 * r;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < M && c < C) {
+            const float4 g4 = *reinterpret_cast<const float4*>(dy + (size_t)m * lddy + c), x4 = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + c);
+            float g[4] = {g4.x, g4.y, g4.z, g4.w};
+            const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+            if (y) {
+                const float4 y4 = *reinterpret_cast<const float4*>(y + (size_t)m * ldy + c);
+                const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (!(yv[k] > 0.f)) g[k] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xv[k] - mu[k]) * rs[k];
+                o[k] = gs[k] * (g[k] - m1[k] - xh * m2[k]);
+            }
+            *reinterpret_cast<float4*>(dx + (size_t)m * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+            if (dx_bf16)
+                *reinterpret_cast<uint2*>(dx_bf16 + (size_t)m * C + c) = make_uint2(vidc::bf16_rne(o[0]) | ((unsigned)vidc::bf16_rne(o[1]) << 16),
+                                                                                    vidc::bf16_rne(o[2]) | ((unsigned)vidc::bf16_rne(o[3]) << 16));
+        }
+        float* t = &tile[ty + 16 * r][tx * 4];
+        t[0] = o[0]; t[1] = o[1]; t[2] = o[2]; t[3] = o[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cl = ty + 16 * r, cc = c0 + cl, m = m0 + tx * 4;
+        if (cc < C && m < Mp) {
+            const float v[4] = {tile[tx * 4][cl], tile[tx * 4 + 1][cl], tile[tx * 4 + 2][cl], tile[tx * 4 + 3][cl]};
+            *reinterpret_cast<uint2*>(dx_bf16_t + (size_t)cc * Mp + m) = make_uint2((unsigned)vidc::bf16_rne(v[0]) | ((unsigned)vidc::bf16_rne(v[1]) << 16),
+                                                                                    (unsigned)vidc::bf16_rne(v[2]) | ((unsigned)vidc::bf16_rne(v[3]) << 16));
+        }
+    }
+}
+
 // ---- elementwise ---------------------------------------------------------------------------------------------------------------
 // y = relu?(a + b)  (Bottleneck: out = relu(bn3(conv3) + identity); decoder: z1 + z2 + z3 + z4 without ReLU)
 __global__ void __launch_bounds__(TT)
@@ -603,6 +663,9 @@ im2col_t_kernel(const float* __restrict__ x, float* __restrict__ xt, int B, int 
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tap = blockIdx.z;
     const int kh = tap / KW, kw = tap - kh * KW;
+    const bool chan_major = split & 4;      // rows ordered c * taps + tap (the OIHW order of a weight gradient) instead of tap * C + c
+    split &= 3;
+    const int taps = KH * KW;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int m = m0 + ty + 8 * r, c = c0 + tx;
@@ -620,16 +683,17 @@ im2col_t_kernel(const float* __restrict__ x, float* __restrict__ xt, int B, int 
         const int c = c0 + ty + 8 * r, m = m0 + tx;
         if (c < C && m < Mp) {
             const float v = tile[tx][ty + 8 * r];
+            const size_t row = chan_major ? (size_t)c * taps + tap : (size_t)tap * C + c;
             if (split == 2) {    // plain bf16 rows
-                reinterpret_cast<unsigned short*>(xt)[((size_t)tap * C + c) * Mp + m] = vidc::bf16_rne(v);
+                reinterpret_cast<unsigned short*>(xt)[row * Mp + m] = vidc::bf16_rne(v);
             } else if (split) {  // the 32 pixels of this tile are one K unit of the GEMM: [32 x hi | 32 x lo] in the same 128 bytes
                 unsigned short h, l;
                 vidc::split_bf16(v, h, l);
-                unsigned short* u = reinterpret_cast<unsigned short*>(xt + ((size_t)tap * C + c) * Mp + m0);
+                unsigned short* u = reinterpret_cast<unsigned short*>(xt + row * Mp + m0);
                 u[tx] = h;
                 u[32 + tx] = l;
             } else {
-                xt[((size_t)tap * C + c) * Mp + m] = v;
+                xt[row * Mp + m] = v;
             }
         }
     }
@@ -644,6 +708,9 @@ im2col_t64_kernel(const float* __restrict__ x, float* __restrict__ xt, int B, in
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
     const int kh = tap / KW, kw = tap - kh * KW;
+    const bool chan_major = split & 4;      // rows ordered c * taps + tap instead of tap * C + c (see im2col_t_kernel)
+    split &= 3;
+    const int taps = KH * KW;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int m = m0 + ty + 16 * r, c = c0 + tx * 4;
@@ -662,9 +729,10 @@ im2col_t64_kernel(const float* __restrict__ x, float* __restrict__ xt, int B, in
         const int cl = ty + 16 * r, c = c0 + cl, m = m0 + tx * 4;
         if (c < C && m < Mp) {
             const float v[4] = {tile[tx * 4][cl], tile[tx * 4 + 1][cl], tile[tx * 4 + 2][cl], tile[tx * 4 + 3][cl]};
-            float* row = xt + ((size_t)tap * C + c) * Mp;
+            const size_t ri = chan_major ? (size_t)c * taps + tap : (size_t)tap * C + c;
+            float* row = xt + ri * Mp;
             if (split == 2) {    // plain bf16 rows: 4 pixels = 8 bytes
-                unsigned short* u = reinterpret_cast<unsigned short*>(xt) + ((size_t)tap * C + c) * Mp + m;
+                unsigned short* u = reinterpret_cast<unsigned short*>(xt) + ri * Mp + m;
                 *reinterpret_cast<uint2*>(u) = make_uint2((unsigned)vidc::bf16_rne(v[0]) | ((unsigned)vidc::bf16_rne(v[1]) << 16),
                                                           (unsigned)vidc::bf16_rne(v[2]) | ((unsigned)vidc::bf16_rne(v[3]) << 16));
             } else if (split) {  // 4 pixels of one 32-pixel K unit: their hi halves and their lo halves, 8 bytes each
@@ -757,22 +825,34 @@ extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int 
     return VIDC_OK;
 }
 
-extern "C" int vidc_bn_train_backward(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
-                                      int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
-                                      void* dx_bf16, void* scratch, vidc_stream_t stream) {
+extern "C" int vidc_bn_train_backward_t(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
+                                        int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                                        void* dx_bf16, void* dx_bf16_t, int Mp, void* scratch, vidc_stream_t stream) {
     VIDC_REQUIRE(dy && x && dx && gamma && save_mean && save_rstd && dgamma && dbeta && scratch, VIDC_ERR_NULL, "vidc_bn_train_backward: null pointer");
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!y_relu || ldy % 4 == 0), VIDC_ERR_SHAPE,
                  "vidc_bn_train_backward: bad shape");
+    VIDC_REQUIRE(!dx_bf16_t || (Mp >= M && Mp % 64 == 0 && M < (1ll << 31) && (reinterpret_cast<uintptr_t>(dx_bf16_t) & 7) == 0), VIDC_ERR_SHAPE,
+                 "vidc_bn_train_backward_t: the transposed copy has rows of Mp = M rounded up to a multiple of 64 pixels, 8-byte aligned");
     hipStream_t st = vidc::as_stream(stream);
     const int nch = chunks_for(M, C);
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
     hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean, save_rstd, rows_for(M, C), partial);
     hipLaunchKernelGGL(chan_final_kernel<FinalParamGrad>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, FinalParamGrad{dgamma, dbeta});
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, save_mean, save_rstd,
-                       gamma, sums, reinterpret_cast<unsigned short*>(dx_bf16));
+    if (dx_bf16_t)
+        hipLaunchKernelGGL(bn_bwd_apply_t64_kernel, dim3(Mp / 64, (C + 63) / 64), dim3(256), 0, st, dy, x, y_relu, dx, (int)M, C, lddy, ldx, ldy, lddx, save_mean,
+                           save_rstd, gamma, sums, reinterpret_cast<unsigned short*>(dx_bf16), reinterpret_cast<unsigned short*>(dx_bf16_t), Mp);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, save_mean, save_rstd,
+                           gamma, sums, reinterpret_cast<unsigned short*>(dx_bf16));
     VIDC_CHECK_LAUNCH("bn_train_backward");
     return VIDC_OK;
+}
+
+extern "C" int vidc_bn_train_backward(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
+                                      int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                                      void* dx_bf16, void* scratch, vidc_stream_t stream) {
+    return vidc_bn_train_backward_t(dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, gamma, save_mean, save_rstd, dgamma, dbeta, dx_bf16, nullptr, 0, scratch, stream);
 }
 
 extern "C" int vidc_colsum(const float* dy, long long M, int C, int ld, float* out, void* scratch, vidc_stream_t stream) {
@@ -963,7 +1043,7 @@ extern "C" int vidc_im2col_transposed(const float* x, float* xt, int B, int H, i
     VIDC_REQUIRE(x && xt, VIDC_ERR_NULL, "vidc_im2col_transposed: null pointer");
     const long long M = (long long)B * Ho * Wo;
     VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0 && Mp >= M && Mp % 32 == 0 && M < (1ll << 31) &&
-                     (long long)KH * KW <= 65535 && split >= 0 && split <= 2 && (split != 2 || Mp % 64 == 0), VIDC_ERR_SHAPE,
+                     (long long)KH * KW <= 65535 && split >= 0 && (split & 3) <= 2 && split < 8 && ((split & 3) != 2 || Mp % 64 == 0), VIDC_ERR_SHAPE,
                  "vidc_im2col_transposed: bad shape (Mp = M rounded up to a multiple of 32; 64 for plain bf16 rows)");
     const bool wide = C % 4 == 0 && ldx % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xt)) & 15) == 0;
     if (wide)

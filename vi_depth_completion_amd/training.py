@@ -37,10 +37,12 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 class Act:
     """An activation: NHWC rows `t` (B,H,W,C view, possibly a channel slice of a wider buffer) + its gradient (same geometry)."""
-    __slots__ = ("t", "grad", "bf", "grad_bf")      # bf / grad_bf: bf16 operand copies (dense rows) written by the producing kernel
+    __slots__ = ("t", "grad", "bf", "grad_bf", "grad_t", "conv_out")      # bf / grad_bf: bf16 operand copies (dense rows) written by the producing kernel
+    # grad_t: (tensor, Mp) -- the gradient transposed as bf16 rows [C][Mp], written by the BatchNorm backward behind a conv (conv_out): the
+    # left operand of that conv's weight-gradient GEMM
 
     def __init__(self, t):
-        self.t, self.grad, self.bf, self.grad_bf = t, None, None, None
+        self.t, self.grad, self.bf, self.grad_bf, self.grad_t, self.conv_out = t, None, None, None, None, False
 
     @property
     def ld(self):
@@ -318,11 +320,12 @@ class DepthCompletionTrainer:
                 L.check(L.lib().vidc_pack_conv_weights_batched(L.ptr(dev), n, blocks, L.current_stream()), "pack")
         self._packed_fresh = True
 
-    def _wgrad_gemm(self, g, x, key, geom):
-        """dW through the conv kernel: dW[co][tap][ci] = sum over pixels of dY^T[co][m] * Xt[tap*Cin + ci][m] is the 1x1 case of
-        vidc_conv2d_bn_act with the rows of dY^T as activations and the rows of Xt (the transposed im2col of x) as weights -- LDS-tiled,
-        split-K, at several times the rate of the direct pixel-reduction kernel (vidc_conv_wgrad, kept for shapes beyond the 32-bit
-        limits of the conv kernel).  Returns False when the shape does not fit."""
+    def _wgrad_gemm(self, g, x, key, geom, g_t=None):
+        """dW through the conv kernel: dW[co][ci][tap] = sum over pixels of dY^T[co][m] * Xt[ci*taps + tap][m] is the 1x1 case of
+        vidc_conv2d_bn_act with the rows of dY^T as activations and the rows of Xt (the transposed im2col of x, channel-major) as weights
+        -- LDS-tiled, split-K, at several times the rate of the direct pixel-reduction kernel (vidc_conv_wgrad, kept for shapes beyond the
+        32-bit limits of the conv kernel) -- and its output is the parameter's .grad in place.  g_t: dY^T if the BatchNorm backward has
+        written it already.  Returns False when the shape does not fit."""
         B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad = geom
         if os.environ.get("VIDC_WGRAD", "gemm") != "gemm":
             return False
@@ -333,12 +336,21 @@ class DepthCompletionTrainer:
         e = 2 if bf16 else 1                     # pixels per 4-byte element of an operand row
         if taps * ci * Mp * 4 // e >= (1 << 31) or co * Mp // e >= (1 << 29) or ci % 32 or co % 4:
             return False
-        gt, xt, tmp = self._empty(co, Mp // e), self._empty(taps * ci, Mp // e), self._empty(co, taps * ci)
+        xt = self._empty(taps * ci, Mp // e)
         split = {L.PREC_FP32: 0, L.PREC_BF16X3: 1, L.PREC_BF16: 2}[self.precision]      # operands written in the GEMM's format directly
-        L.check(lib.vidc_im2col_transposed(L.ptr(g), L.ptr(gt), B, Ho, Wo, co, _ld(g), Ho, Wo, 1, 1, 1, 0, Mp, split, st), "transpose dY")
-        L.check(lib.vidc_im2col_transposed(L.ptr(x.t), L.ptr(xt), B, H, W, ci, x.ld, Ho, Wo, kh, kw, stride, pad, Mp, split, st), "im2col^T")
+        if g_t is not None and bf16 and g_t[1] == Mp and g_t[0].numel() == co * Mp // e:
+            gt = g_t[0]                           # written by the BatchNorm backward that produced g (vidc_bn_train_backward_t)
+        else:
+            gt = self._empty(co, Mp // e)
+            L.check(lib.vidc_im2col_transposed(L.ptr(g), L.ptr(gt), B, Ho, Wo, co, _ld(g), Ho, Wo, 1, 1, 1, 0, Mp, split, st), "transpose dY")
+        # rows of Xt in channel-major order (split + 4): the GEMM's output [co][ci*taps + tap] IS the OIHW weight gradient, written in place
+        # (no staging buffer, no permute / copy launch)
+        inplace = os.environ.get("VIDC_TRAIN_WGRAD_INPLACE", "1") == "1"      # 0: tap-major rows, staging buffer, permute / copy (A/B, tests)
+        L.check(lib.vidc_im2col_transposed(L.ptr(x.t), L.ptr(xt), B, H, W, ci, x.ld, Ho, Wo, kh, kw, stride, pad, Mp, split | (4 if inplace else 0), st), "im2col^T")
         Mp //= e
         n_out = taps * ci
+        gw = self.grad[key + ".weight"]
+        tmp = gw if inplace else self._empty(co, n_out)
         d = L.ConvDesc()
         d.x, d.w, d.y = L.ptr(gt), L.ptr(xt), L.ptr(tmp)
         d.scale1, d.shift1 = L.ptr(self._const(self._ones, n_out, 1.0)), L.ptr(self._const(self._zeros, n_out, 0.0))
@@ -349,11 +361,11 @@ class DepthCompletionTrainer:
         d.x_gs, d.w_gs, d.y_gs, d.p_gs = Mp, n_out * Mp, n_out, n_out
         self._plan(d, "gemm")
         L.check(lib.vidc_conv2d_bn_act(C.byref(d), st), "wgrad gemm")
-        gw = self.grad[key + ".weight"]
-        if taps == 1:
-            gw.view(co, ci).copy_(tmp)
-        else:
-            L.check(lib.vidc_wgrad_permute(L.ptr(tmp), L.ptr(gw), co, ci, taps, st), "wgrad permute")
+        if not inplace:
+            if taps == 1:
+                gw.view(co, ci).copy_(tmp)
+            else:
+                L.check(lib.vidc_wgrad_permute(L.ptr(tmp), L.ptr(gw), co, ci, taps, st), "wgrad permute")
         return True
 
     def conv(self, x, key, stride=1, pad=0, relu=False, out=None):
@@ -365,18 +377,19 @@ class DepthCompletionTrainer:
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
         wp = self._pack(key, "f", w)
         y = Act(out if out is not None else self._empty(B, Ho, Wo, co))
+        y.conv_out = not relu and os.environ.get("VIDC_TRAIN_DYT_FUSED", "1") == "1"
         self._conv_call(x.t, wp, bias if bias is not None else self._const(self._zeros, co, 0.0), y.t, kh, kw, stride, pad, relu, False, x_bf=x.bf)
 
         def backward():
-            g, g_bf = y.grad, y.grad_bf
+            g, g_bf, g_t = y.grad, y.grad_bf, y.grad_t
             if relu:                                         # y = relu(conv): mask first
                 gm = self._empty(B, Ho, Wo, co)
                 L.check(L.lib().vidc_relu_backward(L.ptr(g), L.ptr(y.t), L.ptr(gm), y.rows, co, _ld(g), y.ld, co, 0, L.current_stream()), "relu_bwd")
-                g, g_bf = gm, None
+                g, g_bf, g_t = gm, None, None
             lib = L.lib()
 
-            def weight_and_bias_gradient(g=g):     # (column sums for the bias); on the lane's side stream: see __init__
-                if not self._wgrad_gemm(g, x, key, (B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad)):
+            def weight_and_bias_gradient(g=g, g_t=g_t):     # (column sums for the bias); on the lane's side stream: see __init__
+                if not self._wgrad_gemm(g, x, key, (B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad), g_t=g_t):
                     sc = self._scratch_bytes(lib.vidc_conv_wgrad_scratch_bytes(B, Ho, Wo, co, ci, kh, kw))
                     L.check(lib.vidc_conv_wgrad(L.ptr(g), L.ptr(x.t), L.ptr(self.grad[key + ".weight"]), B, H, W, ci, x.ld, Ho, Wo, co, _ld(g), kh, kw, stride,
                                                 pad, L.ptr(sc), L.current_stream()), "wgrad")
@@ -397,7 +410,7 @@ class DepthCompletionTrainer:
             if not acc:
                 x.grad = self._empty(B, H, W, ci)
             if acc:
-                x.grad_bf = None                             # x.grad changes below
+                x.grad_bf = x.grad_t = None                  # x.grad changes below
             self._conv_call(gz, wd, self._const(self._zeros, ci, 0.0), x.grad, kh, kw, 1, kh - 1 - pad, False, acc, x_bf=g_bf)
 
         self._record(backward)
@@ -422,13 +435,18 @@ class DepthCompletionTrainer:
             dx = self._empty(*x.t.shape) if acc else None
             target = dx if acc else self._empty(*x.t.shape)
             tbf = self._empty(*x.t.shape[:-1], Cc // 2) if (bf16 and not acc) else None
-            L.check(L.lib().vidc_bn_train_backward(L.ptr(y.grad), L.ptr(x.t), L.ptr(y.t) if relu else None, L.ptr(target), x.rows, Cc, _ld(y.grad), x.ld, y.ld,
-                                                   Cc, L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(self.grad[key + ".weight"]), L.ptr(self.grad[key + ".bias"]),
-                                                   L.ptr(tbf) if tbf is not None else None, L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_backward")
+            # x = a conv's output: dx is that conv's dY, and its weight-gradient GEMM wants dY^T as bf16 rows [C][Mp] -- written here, by the
+            # kernel that produces dY, instead of by a transpose launch of its own (one launch and one pass over dY less per conv)
+            Mp = (x.rows + 63) // 64 * 64
+            tbt = self._empty(Cc, Mp // 2) if (tbf is not None and x.conv_out and x.rows < (1 << 31)) else None
+            L.check(L.lib().vidc_bn_train_backward_t(L.ptr(y.grad), L.ptr(x.t), L.ptr(y.t) if relu else None, L.ptr(target), x.rows, Cc, _ld(y.grad), x.ld, y.ld,
+                                                     Cc, L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(self.grad[key + ".weight"]), L.ptr(self.grad[key + ".bias"]),
+                                                     L.ptr(tbf) if tbf is not None else None, L.ptr(tbt) if tbt is not None else None, Mp,
+                                                     L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_backward")
             if acc:
                 self._accumulate(x, target)
             else:
-                x.grad, x.grad_bf = target, tbf
+                x.grad, x.grad_bf, x.grad_t = target, tbf, ((tbt, Mp) if tbt is not None else None)
 
         self._record(backward)
         return y
@@ -444,7 +462,7 @@ class DepthCompletionTrainer:
         if x.grad is None:
             x.grad = g
             return
-        x.grad_bf = None                                     # the in-place sum below makes a bf16 copy of x.grad stale
+        x.grad_bf = x.grad_t = None                          # the in-place sum below makes the bf16 copies of x.grad stale
         Cc = x.t.shape[-1]
         L.check(L.lib().vidc_relu_backward(L.ptr(g), None, L.ptr(x.grad), x.rows, Cc, _ld(g), 0, _ld(x.grad), 1, L.current_stream()), "accumulate")
 
