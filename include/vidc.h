@@ -437,6 +437,10 @@ int vidc_bn_train_backward_t(const float* dy, const float* x, const float* y_rel
 int vidc_colsum(const float* dy, long long M, int C, int ld, float* out, void* scratch, vidc_stream_t stream);
 /* y = a + b, ReLU optional (Bottleneck: relu(bn3(conv3(.)) + identity); decoder: z1 + z2 + z3 + z4). */
 int vidc_add_rows(const float* a, const float* b, float* y, long long M, int C, int lda, int ldb, int ldy, int relu, vidc_stream_t stream);
+/* The same; y_bf16 (may be NULL): additionally the result rounded to bf16 as dense rows of C values (the operand copy the next convs of a
+ * VIDC_PREC_BF16 step read, as vidc_bn_train_forward's y_bf16). */
+int vidc_add_rows_bf16(const float* a, const float* b, float* y, long long M, int C, int lda, int ldb, int ldy, int relu, void* y_bf16,
+                       vidc_stream_t stream);
 /* dx (accumulate ? += : =) dy * (y > 0); y == NULL: plain copy / accumulate. */
 int vidc_relu_backward(const float* dy, const float* y, float* dx, long long M, int C, int lddy, int ldy, int lddx, int accumulate,
                        vidc_stream_t stream);

@@ -89,6 +89,7 @@ SIGNATURES = {
     "vidc_bn_train_backward_t": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "vidc_colsum": (C.c_int, [_vp, C.c_longlong, _i, _i, _vp, _vp, _vp]),
     "vidc_add_rows": (C.c_int, [_vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp]),
+    "vidc_add_rows_bf16": (C.c_int, [_vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp, _vp]),
     "vidc_relu_backward": (C.c_int, [_vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp]),
     "vidc_maxpool3x3s2_backward": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_upsample_bilinear_ac_backward": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

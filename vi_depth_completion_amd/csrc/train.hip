@@ -243,7 +243,8 @@ bn_bwd_apply_t64_kernel(const float* __restrict__ dy, const float* __restrict__ 
 // ---- elementwise ---------------------------------------------------------------------------------------------------------------
 // y = relu?(a + b)  (Bottleneck: out = relu(bn3(conv3) + identity); decoder: z1 + z2 + z3 + z4 without ReLU)
 __global__ void __launch_bounds__(TT)
-add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long long M, int C, int lda, int ldb, int ldy, int relu) {
+add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long long M, int C, int lda, int ldb, int ldy, int relu,
+           unsigned short* __restrict__ y_bf16) {
     const int c4 = C >> 2;
     const long long i = (long long)blockIdx.x * TT + threadIdx.x;
     if (i >= M * c4) return;
@@ -253,6 +254,9 @@ add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __re
     float4 o = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     *reinterpret_cast<float4*>(y + r * ldy + c) = o;
+    if (y_bf16)         // the bf16 operand copy (dense rows) the convs of the next block read in a VIDC_PREC_BF16 step: saves their cast launches
+        *reinterpret_cast<uint2*>(y_bf16 + r * C + c) = make_uint2(vidc::bf16_rne(o.x) | ((unsigned)vidc::bf16_rne(o.y) << 16),
+                                                                   vidc::bf16_rne(o.z) | ((unsigned)vidc::bf16_rne(o.w) << 16));
 }
 
 // dx (=|+=) dy * (y > 0)   (y NULL: plain copy / accumulate)
@@ -869,12 +873,18 @@ extern "C" int vidc_colsum(const float* dy, long long M, int C, int ld, float* o
     return VIDC_OK;
 }
 
-extern "C" int vidc_add_rows(const float* a, const float* b, float* y, long long M, int C, int lda, int ldb, int ldy, int relu, vidc_stream_t stream) {
+extern "C" int vidc_add_rows_bf16(const float* a, const float* b, float* y, long long M, int C, int lda, int ldb, int ldy, int relu, void* y_bf16,
+                                  vidc_stream_t stream) {
     VIDC_REQUIRE(a && b && y, VIDC_ERR_NULL, "vidc_add_rows: null pointer");
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldy % 4 == 0, VIDC_ERR_SHAPE, "vidc_add_rows: bad shape");
-    hipLaunchKernelGGL(add_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, vidc::as_stream(stream), a, b, y, M, C, lda, ldb, ldy, relu);
+    hipLaunchKernelGGL(add_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, vidc::as_stream(stream), a, b, y, M, C, lda, ldb, ldy, relu,
+                       reinterpret_cast<unsigned short*>(y_bf16));
     VIDC_CHECK_LAUNCH("add_kernel");
     return VIDC_OK;
+}
+
+extern "C" int vidc_add_rows(const float* a, const float* b, float* y, long long M, int C, int lda, int ldb, int ldy, int relu, vidc_stream_t stream) {
+    return vidc_add_rows_bf16(a, b, y, M, C, lda, ldb, ldy, relu, nullptr, stream);
 }
 
 extern "C" int vidc_relu_backward(const float* dy, const float* y, float* dx, long long M, int C, int lddy, int ldy, int lddx, int accumulate,

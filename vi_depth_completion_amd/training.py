@@ -469,7 +469,10 @@ class DepthCompletionTrainer:
     def add(self, a, b, relu, out=None):
         Cc = a.t.shape[-1]
         y = Act(out if out is not None else self._empty(*a.t.shape))
-        L.check(L.lib().vidc_add_rows(L.ptr(a.t), L.ptr(b.t), L.ptr(y.t), a.rows, Cc, a.ld, b.ld, y.ld, int(relu), L.current_stream()), "add")
+        if self.precision == L.PREC_BF16 and Cc % 64 == 0 and relu and os.environ.get("VIDC_TRAIN_ADD_BF16", "1") == "1":      # a block output: the next block's convs read it as a bf16 operand
+            y.bf = self._empty(*a.t.shape[:-1], Cc // 2)
+        L.check(L.lib().vidc_add_rows_bf16(L.ptr(a.t), L.ptr(b.t), L.ptr(y.t), a.rows, Cc, a.ld, b.ld, y.ld, int(relu),
+                                           L.ptr(y.bf) if y.bf is not None else None, L.current_stream()), "add")
 
         def backward():
             g = y.grad
