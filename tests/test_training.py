@@ -139,6 +139,41 @@ def test_conv_bn_relu_block_gradients(cin, cout, k, stride, pad, H, W):
 
 
 @gpu
+def test_maxpool_backward_wide_kernel_equals_scalar_and_autograd():
+    """vidc_maxpool3x3s2_backward: the 4-channels-per-thread kernel (aligned, channel strides multiples of 4) against the scalar one (forced
+    by an odd gradient stride) -- identical bits -- and against torch autograd on the CPU, ties included (first maximum in scan order)."""
+    from vi_depth_completion_amd import _lib as L
+    lib = L.lib()
+    B, H, W, Cc = 2, 11, 14, 8
+    g = torch.Generator().manual_seed(9)
+    x = torch.randint(0, 4, (B, H, W, Cc), generator=g).float()            # many ties
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = torch.randn(B, Ho, Wo, Cc, generator=g)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.max_pool2d(xr, 3, 2, 1).backward(dy.permute(0, 3, 1, 2))
+    want = xr.grad.permute(0, 2, 3, 1)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    wide = torch.empty(B, H, W, Cc, device=DEV)
+    L.check(lib.vidc_maxpool3x3s2_backward(L.ptr(xd), L.ptr(dyd), L.ptr(wide), B, H, W, Cc, Cc, Cc, Cc, L.current_stream()), "maxpool_bwd")
+    odd = torch.empty(B, H, W, Cc + 1, device=DEV)
+    L.check(lib.vidc_maxpool3x3s2_backward(L.ptr(xd), L.ptr(dyd), L.ptr(odd), B, H, W, Cc, Cc, Cc, Cc + 1, L.current_stream()), "maxpool_bwd scalar")
+    assert torch.equal(wide.cpu(), odd[..., :Cc].cpu())
+    assert torch.equal(wide.cpu(), want)
+    # bilinear upsampling (align_corners=True) backward: the 4-channel kernel against the scalar one, and against autograd
+    h, w, Hh, Ww = 8, 10, 15, 20
+    gy = torch.randn(B, Hh, Ww, Cc, generator=g)
+    src = torch.randn(B, Cc, h, w, generator=g).requires_grad_(True)
+    F.interpolate(src, size=(Hh, Ww), mode="bilinear", align_corners=True).backward(gy.permute(0, 3, 1, 2))
+    gyd = gy.to(DEV)
+    wide = torch.empty(B, h, w, Cc, device=DEV)
+    L.check(lib.vidc_upsample_bilinear_ac_backward(L.ptr(gyd), L.ptr(wide), B, h, w, Cc, Cc, Cc, Hh, Ww, L.current_stream()), "upsample_bwd")
+    odd = torch.empty(B, h, w, Cc + 1, device=DEV)
+    L.check(lib.vidc_upsample_bilinear_ac_backward(L.ptr(gyd), L.ptr(odd), B, h, w, Cc, Cc, Cc + 1, Hh, Ww, L.current_stream()), "upsample_bwd scalar")
+    assert torch.equal(wide.cpu(), odd[..., :Cc].cpu())
+    assert (wide.cpu() - src.grad.permute(0, 2, 3, 1)).abs().max() < 1e-5
+
+
+@gpu
 def test_bottleneck_pool_upsample_gradients():
     """A miniature of the network's graph: max-pool -> projection Bottleneck (stride 2) -> identity Bottleneck -> upsample -> add, so the
     fan-outs (block input feeds conv1 AND the shortcut) accumulate; gradients w.r.t. the input and a few parameters vs torch."""

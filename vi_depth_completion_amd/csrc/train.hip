@@ -315,6 +315,49 @@ maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, fl
     }
     dx[(((long long)b * H + h) * W + w) * lddx + c] = acc;
 }
+// The same map, four channels per thread with 16-byte accesses and 32-bit offsets (C, ldx, lddy, lddx multiples of 4, tensors below 2^31
+// elements: the pyramids' 64-channel pool); per channel the scan order and the additions are those of the scalar kernel: identical bits.
+__global__ void __launch_bounds__(TT)
+maxpool_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W, int C, int ldx, int lddy, int lddx) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, c4 = C >> 2;
+    const unsigned i = blockIdx.x * TT + threadIdx.x;
+    if (i >= (unsigned)B * H * W * c4) return;
+    const int c = (int)(i % c4) * 4;
+    unsigned p = i / c4;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int oy = h / 2; oy <= (h + 1) / 2; ++oy) {
+        if (oy >= Ho) continue;
+        for (int ox = w / 2; ox <= (w + 1) / 2; ++ox) {
+            if (ox >= Wo) continue;
+            float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            int at[4] = {-1, -1, -1, -1};                    // kh * 3 + kw of the first maximum
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = 2 * oy - 1 + kh;
+                if (ih < 0 || ih >= H) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iw = 2 * ox - 1 + kw;
+                    if (iw < 0 || iw >= W) continue;
+                    const float4 v4 = *reinterpret_cast<const float4*>(x + (unsigned)((b * H + ih) * W + iw) * (unsigned)ldx + c);
+                    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (v[k] > best[k] || at[k] < 0) { best[k] = v[k]; at[k] = kh * 3 + kw; }
+                }
+            }
+            const int mine = (h - (2 * oy - 1)) * 3 + (w - (2 * ox - 1));
+            const float4 g4 = *reinterpret_cast<const float4*>(dy + (unsigned)((b * Ho + oy) * Wo + ox) * (unsigned)lddy + c);
+            const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (at[k] == mine) acc[k] += g[k];
+        }
+    }
+    *reinterpret_cast<float4*>(dx + (unsigned)((b * H + h) * W + w) * (unsigned)lddx + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
 
 // ---- bilinear upsampling (align_corners = True) backward, gather form ------------------------------------------------------------
 // Forward (pointwise.hip / F.interpolate): src = dst * (in - 1) / (out - 1) in fp32, i0 = floor(src), i1 = min(i0 + 1, in - 1),
@@ -358,6 +401,40 @@ upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B,
     }
     dx[(((long long)b * h + ii) * w + jj) * lddx + c] = acc;
 }
+// The same map, four channels per thread (16-byte accesses, 32-bit offsets): the interpolation weights of a pixel are computed once for
+// the four; per channel the (Y, X) scan order and every product are those of the scalar kernel -- identical bits.
+__global__ void __launch_bounds__(TT)
+upsample_bwd4_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int h, int w, int C, int lddy, int lddx, int H, int W) {
+    const int c4 = C >> 2;
+    const unsigned i = blockIdx.x * TT + threadIdx.x;
+    if (i >= (unsigned)B * h * w * c4) return;
+    const int c = (int)(i % c4) * 4;
+    unsigned p = i / c4;
+    const int jj = (int)(p % w); p /= w;
+    const int ii = (int)(p % h);
+    const int b = (int)(p / h);
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    int Y0 = 0, Y1 = H - 1, X0 = 0, X1 = W - 1;
+    if (sy > 0.f) { Y0 = max(0, (int)floorf((float)(ii - 1) / sy) - 1); Y1 = min(H - 1, (int)ceilf((float)(ii + 1) / sy) + 1); }
+    if (sx > 0.f) { X0 = max(0, (int)floorf((float)(jj - 1) / sx) - 1); X1 = min(W - 1, (int)ceilf((float)(jj + 1) / sx) + 1); }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int Y = Y0; Y <= Y1; ++Y) {
+        int a0, a1; float ly;
+        up_src(Y, h, H, a0, a1, ly);
+        const float wy = (a0 == ii ? 1.f - ly : 0.f) + (a1 == ii ? ly : 0.f);
+        if (wy == 0.f) continue;
+        for (int X = X0; X <= X1; ++X) {
+            int b0, b1; float lx;
+            up_src(X, w, W, b0, b1, lx);
+            const float wx = (b0 == jj ? 1.f - lx : 0.f) + (b1 == jj ? lx : 0.f);
+            if (wx == 0.f) continue;
+            const float4 g = *reinterpret_cast<const float4*>(dy + (unsigned)((b * H + Y) * W + X) * (unsigned)lddy + c);
+            const float ww = wy * wx;
+            acc[0] += ww * g.x; acc[1] += ww * g.y; acc[2] += ww * g.z; acc[3] += ww * g.w;
+        }
+    }
+    *reinterpret_cast<float4*>(dx + (unsigned)((b * h + ii) * w + jj) * (unsigned)lddx + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
 
 // ---- padded 1x1 head (depth_completion.py:141-147: Conv2d(192, 1, 1, padding=1)) backward -----------------------------------------
 // g_low: [B][h+2][w+2] gradient at the 62x82 map; x: NHWC [B][h][w][C].  dx[b,y,x,c] = g_low[b,y+1,x+1] * w[c]
@@ -390,12 +467,23 @@ head_wgrad_partial_kernel(const float* __restrict__ g_low, const float* __restri
     }
     partial[(size_t)blockIdx.y * C + c] = s;
 }
+// Eight lanes per output: lane j sums chunks j, j + 8, ... and the eight sums are added in the order j = 0..7 -- a fixed order, so the
+// result is reproducible; one lane per output walked up to 600 chunks serially (120 us on the critical path of every pyramid's stem).
 __global__ void __launch_bounds__(TT) head_wgrad_final_kernel(const double* __restrict__ partial, int n_chunks, int C, float* __restrict__ dw) {
-    const int c = blockIdx.x * TT + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[8][TT / 8];
+    const int l = threadIdx.x % (TT / 8), j = threadIdx.x / (TT / 8);
+    const int c = blockIdx.x * (TT / 8) + l;
     double s = 0.0;
-    for (int k = 0; k < n_chunks; ++k) s += partial[(size_t)k * C + c];
-    dw[c] = (float)s;
+    if (c < C)
+        for (int k = j; k < n_chunks; k += 8) s += partial[(size_t)k * C + c];
+    red[j][l] = s;
+    __syncthreads();
+    if (j == 0 && c < C) {
+        double t = red[0][l];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += red[q][l];
+        dw[c] = (float)t;
+    }
 }
 
 // ---- generic fixed-order sum of n floats (fp64): head bias gradient, loss ----------------------------------------------------------
@@ -475,11 +563,15 @@ pack_weight_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, in
 //  dgrad (kind & 1): a block takes U output channels x kPackCi input channels: U contiguous runs of kPackCi*taps parameter elements in,
 //      kPackCi*taps runs of U packed elements out (kernel flipped).
 // U = 32 channels per 128-byte unit for fp32 / split-bf16 ([32 x hi | 32 x lo]), 64 for plain bf16.
+// (a 1x1 conv has 1/9 of the elements per unit / per input channel: its blocks take 64 of them instead of 8 -- with 8 a block moved 256-512
+//  elements and the launch, ~600 000 blocks for the 310 M parameters, was bound by block start-up and the item search, not by bandwidth)
 constexpr int kPackUnits = 8, kPackCi = 8;
+__host__ __device__ inline int pack_units(int taps) { return taps == 1 ? 64 : kPackUnits; }
+__host__ __device__ inline int pack_ci(int taps) { return taps == 1 ? 64 : kPackCi; }
 __host__ __device__ inline long long pack_item_blocks(int Cout, int Cin, int KH, int KW, int kind) {
-    const int U = (kind & 4) ? 64 : 32;
-    if (!(kind & 1)) return ((long long)Cout * (Cin / U) + kPackUnits - 1) / kPackUnits;
-    return (long long)(Cout / U) * ((Cin + kPackCi - 1) / kPackCi);
+    const int U = (kind & 4) ? 64 : 32, pu = pack_units(KH * KW), pc = pack_ci(KH * KW);
+    if (!(kind & 1)) return ((long long)Cout * (Cin / U) + pu - 1) / pu;
+    return (long long)(Cout / U) * ((Cin + pc - 1) / pc);
 }
 __device__ inline void pack_store(const vidc_pack_item& it, long long off, float v) {
     if (it.kind & 4) {
@@ -495,7 +587,8 @@ __device__ inline void pack_store(const vidc_pack_item& it, long long off, float
     }
 }
 __global__ void __launch_bounds__(TT) pack_batched_kernel(const vidc_pack_item* __restrict__ items, int n) {
-    __shared__ float tile[64 * (kPackCi * 9 + 1)];          // 64 channels x (8 x 9 + 1) floats = 18.25 KB; also holds 8 units x 64 x 9
+    __shared__ float tile[64 * (kPackCi * 9 + 1)];          // 64 channels x (8 x 9 + 1) floats = 18.25 KB; also holds 8 units x 64 x 9, 64 units x 64 x 1
+    static_assert(64 * 64 <= 64 * (kPackCi * 9 + 1) && 64 * (64 + 1) <= 64 * (kPackCi * 9 + 1), "1x1 blocks must fit the tile");
     int lo = 0, hi = n - 1;
     const long long blk = blockIdx.x;
     while (lo < hi) {
@@ -506,8 +599,9 @@ __global__ void __launch_bounds__(TT) pack_batched_kernel(const vidc_pack_item* 
     const int lb = (int)(blk - it.block_begin);
     const int taps = it.KH * it.KW, U = (it.kind & 4) ? 64 : 32, seg = U * taps;
     if (!(it.kind & 1)) {
-        const long long units = (long long)it.Cout * (it.Cin / U), u0 = (long long)lb * kPackUnits;
-        const int cnt = (int)min((long long)kPackUnits, units - u0) * seg;
+        const int pu = pack_units(taps);
+        const long long units = (long long)it.Cout * (it.Cin / U), u0 = (long long)lb * pu;
+        const int cnt = (int)min((long long)pu, units - u0) * seg;
         const float* src = it.w + u0 * seg;
         for (int i = threadIdx.x; i < cnt; i += TT) tile[i] = src[i];
         __syncthreads();
@@ -516,9 +610,10 @@ __global__ void __launch_bounds__(TT) pack_batched_kernel(const vidc_pack_item* 
             pack_store(it, u0 * seg + i, tile[u * seg + lane * taps + tap]);
         }
     } else {
-        const int ci_tiles = (it.Cin + kPackCi - 1) / kPackCi;
-        const int cu = lb / ci_tiles, ci0 = (lb - cu * ci_tiles) * kPackCi, nci = min(kPackCi, it.Cin - ci0);
-        const int run = nci * taps, pitch = kPackCi * taps + 1;
+        const int pc = pack_ci(taps);
+        const int ci_tiles = (it.Cin + pc - 1) / pc;
+        const int cu = lb / ci_tiles, ci0 = (lb - cu * ci_tiles) * pc, nci = min(pc, it.Cin - ci0);
+        const int run = nci * taps, pitch = pc * taps + 1;
         for (int i = threadIdx.x; i < U * run; i += TT) {
             const int col = i / run, r = i - col * run;
             tile[col * pitch + r] = it.w[((long long)(cu * U + col) * it.Cin + ci0) * taps + r];
@@ -767,24 +862,42 @@ __global__ void __launch_bounds__(TT) wgrad_permute_kernel(const float* __restri
 __global__ void __launch_bounds__(TT)
 stem_wgrad_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x, int B, int Cin, int H, int W, int Ho, int Wo, int Cout, int lddy,
                           int rows_per_chunk, double* __restrict__ partial /* [chunk][Cout*Cin*9] */) {
-    const int n = Cout * Cin * 9;
-    const int idx = blockIdx.x * TT + threadIdx.x;
-    if (idx >= n) return;
-    const int kw = idx % 3, kh = (idx / 3) % 3, ci = (idx / 9) % Cin, co = idx / (9 * Cin);
+    // One thread per (co, ci) with the nine taps in registers: a row costs one dy load, nine x loads and nine fp64 multiply-adds.  (The
+    // first version had one thread per (co, ci, kh, kw): ~20 instructions per multiply-add, 265 M of them -- 300 us at the end of every
+    // pyramid's backward.)  Per output the rows are added in the same order as before; a tap outside the image adds dy * 0.
+    const int t = blockIdx.x * TT + threadIdx.x;
+    if (t >= Cout * Cin) return;
+    const int ci = t % Cin, co = t / Cin;
     const long long M = (long long)B * Ho * Wo;
     const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
-    double s = 0.0;
+    double s[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = 0.0;
     int ox = (int)(r0 % Wo);                              // (b, oy, ox) of the row walk incrementally: no division in the loop
     const long long q0 = r0 / Wo;
     int oy = (int)(q0 % Ho), b = (int)(q0 / Ho);
     const float* gp = dy + r0 * lddy + co;
-    for (long long m = r0; m < r1; ++m, gp += lddy) {
-        const int iy = 2 * oy - 1 + kh, ix = 2 * ox - 1 + kw;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            s += (double)*gp * (double)x[(((long long)b * Cin + ci) * H + iy) * W + ix];
+    const int n_rows = (int)(r1 - r0);
+    for (int r = 0; r < n_rows; ++r, gp += lddy) {
+        const double g = (double)*gp;
+        const float* plane = x + ((long long)b * Cin + ci) * H * W;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = 2 * oy - 1 + kh;
+            const bool row_ok = (unsigned)iy < (unsigned)H;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = 2 * ox - 1 + kw;
+                const bool inside = row_ok && (unsigned)ix < (unsigned)W;
+                const float xv = plane[inside ? iy * W + ix : 0];
+                s[kh * 3 + kw] += g * (double)(inside ? xv : 0.f);
+            }
+        }
         if (++ox == Wo) { ox = 0; if (++oy == Ho) { oy = 0; ++b; } }
     }
-    partial[(size_t)blockIdx.y * n + idx] = s;
+    double* out = partial + (size_t)blockIdx.y * ((size_t)Cout * Cin * 9) + (size_t)t * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[k] = s[k];
 }
 
 }  // namespace
@@ -900,7 +1013,12 @@ extern "C" int vidc_maxpool3x3s2_backward(const float* x, const float* dy, float
                                           vidc_stream_t stream) {
     VIDC_REQUIRE(x && dy && dx, VIDC_ERR_NULL, "vidc_maxpool3x3s2_backward: null pointer");
     VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, VIDC_ERR_SHAPE, "vidc_maxpool3x3s2_backward: bad shape");
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks((long long)B * H * W * C)), dim3(TT), 0, vidc::as_stream(stream), x, dy, dx, B, H, W, C, ldx, lddy, lddx);
+    const bool wide = C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (long long)B * H * W * (ldx > lddx ? ldx : lddx) < (1ll << 31) &&
+                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+    if (wide)
+        hipLaunchKernelGGL(maxpool_bwd4_kernel, dim3(blocks((long long)B * H * W * (C / 4))), dim3(TT), 0, vidc::as_stream(stream), x, dy, dx, B, H, W, C, ldx, lddy, lddx);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks((long long)B * H * W * C)), dim3(TT), 0, vidc::as_stream(stream), x, dy, dx, B, H, W, C, ldx, lddy, lddx);
     VIDC_CHECK_LAUNCH("maxpool_bwd_kernel");
     return VIDC_OK;
 }
@@ -909,7 +1027,12 @@ extern "C" int vidc_upsample_bilinear_ac_backward(const float* dy, float* dx, in
                                                   vidc_stream_t stream) {
     VIDC_REQUIRE(dy && dx, VIDC_ERR_NULL, "vidc_upsample_bilinear_ac_backward: null pointer");
     VIDC_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0 && H > 0 && W > 0, VIDC_ERR_SHAPE, "vidc_upsample_bilinear_ac_backward: bad shape");
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(blocks((long long)B * h * w * C)), dim3(TT), 0, vidc::as_stream(stream), dy, dx, B, h, w, C, lddy, lddx, H, W);
+    const bool wide = C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (long long)B * H * W * lddy < (1ll << 31) && (long long)B * h * w * lddx < (1ll << 31) &&
+                      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+    if (wide)
+        hipLaunchKernelGGL(upsample_bwd4_kernel, dim3(blocks((long long)B * h * w * (C / 4))), dim3(TT), 0, vidc::as_stream(stream), dy, dx, B, h, w, C, lddy, lddx, H, W);
+    else
+        hipLaunchKernelGGL(upsample_bwd_kernel, dim3(blocks((long long)B * h * w * C)), dim3(TT), 0, vidc::as_stream(stream), dy, dx, B, h, w, C, lddy, lddx, H, W);
     VIDC_CHECK_LAUNCH("upsample_bwd_kernel");
     return VIDC_OK;
 }
@@ -924,7 +1047,7 @@ extern "C" int vidc_head_backward(const float* g_low, const float* x, const floa
     double* partial = reinterpret_cast<double*>(scratch);
     hipLaunchKernelGGL(head_dgrad_kernel, dim3(blocks(M * C)), dim3(TT), 0, st, g_low, wgt, dx, B, h, w, C, lddx);
     hipLaunchKernelGGL(head_wgrad_partial_kernel, dim3(blocks(C), nch), dim3(TT), 0, st, g_low, x, B, h, w, C, ldx, kRowsPerChunk, partial);
-    hipLaunchKernelGGL(head_wgrad_final_kernel, dim3(blocks(C)), dim3(TT), 0, st, partial, nch, C, dw);
+    hipLaunchKernelGGL(head_wgrad_final_kernel, dim3((C + TT / 8 - 1) / (TT / 8)), dim3(TT), 0, st, partial, nch, C, dw);
     const long long n = (long long)B * (h + 2) * (w + 2);
     const int nb = (int)((n + (long long)TT * 16 - 1) / ((long long)TT * 16));
     double* p2 = partial + (size_t)nch * C;
@@ -1085,8 +1208,8 @@ extern "C" int vidc_stem_wgrad(const float* dy, const float* x_nchw, float* dw_o
     const int rows = kStemRows;
     const int chunks = (int)((M + rows - 1) / rows);
     double* partial = reinterpret_cast<double*>(scratch);
-    hipLaunchKernelGGL(stem_wgrad_partial_kernel, dim3(blocks(n), chunks), dim3(TT), 0, st, dy, x_nchw, B, Cin, H, W, Ho, Wo, Cout, lddy, rows, partial);
-    hipLaunchKernelGGL(head_wgrad_final_kernel, dim3(blocks(n)), dim3(TT), 0, st, partial, chunks, n, dw_oihw);
+    hipLaunchKernelGGL(stem_wgrad_partial_kernel, dim3(blocks((long long)Cout * Cin), chunks), dim3(TT), 0, st, dy, x_nchw, B, Cin, H, W, Ho, Wo, Cout, lddy, rows, partial);
+    hipLaunchKernelGGL(head_wgrad_final_kernel, dim3((n + TT / 8 - 1) / (TT / 8)), dim3(TT), 0, st, partial, chunks, n, dw_oihw);
     VIDC_CHECK_LAUNCH("stem_wgrad");
     return VIDC_OK;
 }
