@@ -149,8 +149,9 @@ def test_maxpool_backward_wide_kernel_equals_scalar_and_autograd():
     x = torch.randint(0, 4, (B, H, W, Cc), generator=g).float()            # many ties
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     dy = torch.randn(B, Ho, Wo, Cc, generator=g)
-    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
-    F.max_pool2d(xr, 3, 2, 1).backward(dy.permute(0, 3, 1, 2))
+    with torch.enable_grad():          # (other tests of the suite switch gradient recording off globally)
+        xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+        F.max_pool2d(xr, 3, 2, 1).backward(dy.permute(0, 3, 1, 2))
     want = xr.grad.permute(0, 2, 3, 1)
     xd, dyd = x.to(DEV), dy.to(DEV)
     wide = torch.empty(B, H, W, Cc, device=DEV)
@@ -162,8 +163,9 @@ def test_maxpool_backward_wide_kernel_equals_scalar_and_autograd():
     # bilinear upsampling (align_corners=True) backward: the 4-channel kernel against the scalar one, and against autograd
     h, w, Hh, Ww = 8, 10, 15, 20
     gy = torch.randn(B, Hh, Ww, Cc, generator=g)
-    src = torch.randn(B, Cc, h, w, generator=g).requires_grad_(True)
-    F.interpolate(src, size=(Hh, Ww), mode="bilinear", align_corners=True).backward(gy.permute(0, 3, 1, 2))
+    with torch.enable_grad():
+        src = torch.randn(B, Cc, h, w, generator=g).requires_grad_(True)
+        F.interpolate(src, size=(Hh, Ww), mode="bilinear", align_corners=True).backward(gy.permute(0, 3, 1, 2))
     gyd = gy.to(DEV)
     wide = torch.empty(B, h, w, Cc, device=DEV)
     L.check(lib.vidc_upsample_bilinear_ac_backward(L.ptr(gyd), L.ptr(wide), B, h, w, Cc, Cc, Cc, Hh, Ww, L.current_stream()), "upsample_bwd")

@@ -467,21 +467,23 @@ head_wgrad_partial_kernel(const float* __restrict__ g_low, const float* __restri
     }
     partial[(size_t)blockIdx.y * C + c] = s;
 }
-// Eight lanes per output: lane j sums chunks j, j + 8, ... and the eight sums are added in the order j = 0..7 -- a fixed order, so the
-// result is reproducible; one lane per output walked up to 600 chunks serially (120 us on the critical path of every pyramid's stem).
+// kFinalLanes lanes per output: lane j sums chunks j, j + kFinalLanes, ... and the partial sums are added in the order j = 0, 1, ... -- a
+// fixed order, so the result is reproducible; one lane per output walked up to 600 chunks serially (120 us on the critical path of every
+// pyramid's stem).
+constexpr int kFinalLanes = 32;
 __global__ void __launch_bounds__(TT) head_wgrad_final_kernel(const double* __restrict__ partial, int n_chunks, int C, float* __restrict__ dw) {
-    __shared__ double red[8][TT / 8];
-    const int l = threadIdx.x % (TT / 8), j = threadIdx.x / (TT / 8);
-    const int c = blockIdx.x * (TT / 8) + l;
+    __shared__ double red[kFinalLanes][TT / kFinalLanes];
+    const int l = threadIdx.x % (TT / kFinalLanes), j = threadIdx.x / (TT / kFinalLanes);
+    const int c = blockIdx.x * (TT / kFinalLanes) + l;
     double s = 0.0;
     if (c < C)
-        for (int k = j; k < n_chunks; k += 8) s += partial[(size_t)k * C + c];
+        for (int k = j; k < n_chunks; k += kFinalLanes) s += partial[(size_t)k * C + c];
     red[j][l] = s;
     __syncthreads();
     if (j == 0 && c < C) {
         double t = red[0][l];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) t += red[q][l];
+        for (int q = 1; q < kFinalLanes; ++q) t += red[q][l];
         dw[c] = (float)t;
     }
 }
@@ -878,7 +880,8 @@ stem_wgrad_partial_kernel(const float* __restrict__ dy, const float* __restrict_
     int oy = (int)(q0 % Ho), b = (int)(q0 / Ho);
     const float* gp = dy + r0 * lddy + co;
     const int n_rows = (int)(r1 - r0);
-    for (int r = 0; r < n_rows; ++r, gp += lddy) {
+#pragma unroll 4
+    for (int r = 0; r < n_rows; ++r, gp += lddy) {      // (unrolled: the 40 loads of four rows are independent of the running sums)
         const double g = (double)*gp;
         const float* plane = x + ((long long)b * Cin + ci) * H * W;
 #pragma unroll
@@ -904,7 +907,8 @@ stem_wgrad_partial_kernel(const float* __restrict__ dy, const float* __restrict_
 
 // ---- C ABI ----------------------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int kStemRows = 256;            // rows per workgroup of vidc_stem_wgrad (M = 153 600 at batch 8: 600 chunks x 7 blocks)
+constexpr int kStemRows = 64;             // rows per workgroup of vidc_stem_wgrad (M = 153 600 at batch 8: 2400 chunks of 192 threads -- the kernel is
+                                          // a chain of dependent L2 latencies per thread, so it wants many short chains rather than few long ones)
 constexpr int kRowsPerChunk = 256;        // rows per workgroup of the per-channel reductions: M = 10^4..10^5 rows -> hundreds of workgroups per 64 channels
 inline int chunks_for(long long M) { return (int)((M + kRowsPerChunk - 1) / kRowsPerChunk); }
 // Rows per workgroup of the per-channel reductions (chan_partial_kernel): about 512 workgroups per launch whatever the shape -- a function of
@@ -1047,7 +1051,7 @@ extern "C" int vidc_head_backward(const float* g_low, const float* x, const floa
     double* partial = reinterpret_cast<double*>(scratch);
     hipLaunchKernelGGL(head_dgrad_kernel, dim3(blocks(M * C)), dim3(TT), 0, st, g_low, wgt, dx, B, h, w, C, lddx);
     hipLaunchKernelGGL(head_wgrad_partial_kernel, dim3(blocks(C), nch), dim3(TT), 0, st, g_low, x, B, h, w, C, ldx, kRowsPerChunk, partial);
-    hipLaunchKernelGGL(head_wgrad_final_kernel, dim3((C + TT / 8 - 1) / (TT / 8)), dim3(TT), 0, st, partial, nch, C, dw);
+    hipLaunchKernelGGL(head_wgrad_final_kernel, dim3((C + TT / kFinalLanes - 1) / (TT / kFinalLanes)), dim3(TT), 0, st, partial, nch, C, dw);
     const long long n = (long long)B * (h + 2) * (w + 2);
     const int nb = (int)((n + (long long)TT * 16 - 1) / ((long long)TT * 16));
     double* p2 = partial + (size_t)nch * C;
@@ -1209,7 +1213,7 @@ extern "C" int vidc_stem_wgrad(const float* dy, const float* x_nchw, float* dw_o
     const int chunks = (int)((M + rows - 1) / rows);
     double* partial = reinterpret_cast<double*>(scratch);
     hipLaunchKernelGGL(stem_wgrad_partial_kernel, dim3(blocks((long long)Cout * Cin), chunks), dim3(TT), 0, st, dy, x_nchw, B, Cin, H, W, Ho, Wo, Cout, lddy, rows, partial);
-    hipLaunchKernelGGL(head_wgrad_final_kernel, dim3((n + TT / 8 - 1) / (TT / 8)), dim3(TT), 0, st, partial, chunks, n, dw_oihw);
+    hipLaunchKernelGGL(head_wgrad_final_kernel, dim3((n + TT / kFinalLanes - 1) / (TT / kFinalLanes)), dim3(TT), 0, st, partial, chunks, n, dw_oihw);
     VIDC_CHECK_LAUNCH("stem_wgrad");
     return VIDC_OK;
 }
