@@ -880,23 +880,33 @@ stem_wgrad_partial_kernel(const float* __restrict__ dy, const float* __restrict_
     int oy = (int)(q0 % Ho), b = (int)(q0 / Ho);
     const float* gp = dy + r0 * lddy + co;
     const int n_rows = (int)(r1 - r0);
-#pragma unroll 4
-    for (int r = 0; r < n_rows; ++r, gp += lddy) {      // (unrolled: the 40 loads of four rows are independent of the running sums)
+    const size_t plane_stride = (size_t)Cin * H * W;
+    const float* plane = x + ((size_t)b * Cin + ci) * H * W;
+    for (int r = 0; r < n_rows; ++r, gp += lddy) {
         const double g = (double)*gp;
-        const float* plane = x + ((long long)b * Cin + ci) * H * W;
+        const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+        if (iy0 >= 0 && ix0 >= 0 && iy0 + 2 < H && ix0 + 2 < W) {      // wave-uniform: the whole 3x3 patch is inside (all but the border rows):
+            const float* p0 = plane + iy0 * W + ix0;                    // nine loads at fixed offsets, no per-tap bounds logic (which was ~200
+            const float* p1 = p0 + W;                                   // scalar instructions per row and bound the kernel)
+            const float* p2 = p1 + W;
+            const float v[9] = {p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], p2[0], p2[1], p2[2]};
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int iy = 2 * oy - 1 + kh;
-            const bool row_ok = (unsigned)iy < (unsigned)H;
+            for (int k = 0; k < 9; ++k) s[k] += g * (double)v[k];
+        } else {
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ix = 2 * ox - 1 + kw;
-                const bool inside = row_ok && (unsigned)ix < (unsigned)W;
-                const float xv = plane[inside ? iy * W + ix : 0];
-                s[kh * 3 + kw] += g * (double)(inside ? xv : 0.f);
+            for (int kh = 0; kh < 3; ++kh) {
+                const int iy = iy0 + kh;
+                const bool row_ok = (unsigned)iy < (unsigned)H;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ix = ix0 + kw;
+                    const bool inside = row_ok && (unsigned)ix < (unsigned)W;
+                    const float xv = plane[inside ? iy * W + ix : 0];
+                    s[kh * 3 + kw] += g * (double)(inside ? xv : 0.f);
+                }
             }
         }
-        if (++ox == Wo) { ox = 0; if (++oy == Ho) { oy = 0; ++b; } }
+        if (++ox == Wo) { ox = 0; if (++oy == Ho) { oy = 0; ++b; plane += plane_stride; } }
     }
     double* out = partial + (size_t)blockIdx.y * ((size_t)Cout * Cin * 9) + (size_t)t * 9;
 #pragma unroll
