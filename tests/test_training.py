@@ -581,6 +581,13 @@ def test_fused_transposed_gradient_of_the_bn_backward_is_bit_identical(golden_di
         outs.append([t.cpu() for t in (dx, dxb, dxt, dg, db)])
     for a, b in zip(*outs):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # vidc_transpose_bf16 of the dense bf16 copy == vidc_im2col_transposed(split = 2) of the fp32 tensor it was rounded from
+    xb = torch.empty(B, H, W, Cc // 2, device=DEV)
+    L.check(lib.vidc_cast_bf16(L.ptr(x), L.ptr(xb), M, Cc, Cc, L.current_stream()), "cast")
+    t_a, t_b = torch.full((Cc, Mp // 2), 3.0, device=DEV), torch.full((Cc, Mp // 2), 5.0, device=DEV)
+    L.check(lib.vidc_transpose_bf16(L.ptr(xb), L.ptr(t_a), M, Cc, Mp, L.current_stream()), "transpose_bf16")
+    L.check(lib.vidc_im2col_transposed(L.ptr(x), L.ptr(t_b), B, H, W, Cc, Cc, H, W, 1, 1, 1, 0, Mp, 2 | 4, L.current_stream()), "im2col^T")
+    assert torch.equal(t_a.view(torch.int32).cpu(), t_b.view(torch.int32).cpu())
     f, image, normal, depth_in, gt = _train_fixture(golden_dir)
     ins = [t.to(DEV) for t in (image, normal, depth_in, gt)]
     monkeypatch.setenv("VIDC_TRAIN_PRECISION", "bf16")
@@ -588,6 +595,8 @@ def test_fused_transposed_gradient_of_the_bn_backward_is_bit_identical(golden_di
     for fused in ("1", "0"):
         monkeypatch.setenv("VIDC_TRAIN_DYT_FUSED", fused)
         monkeypatch.setenv("VIDC_TRAIN_WGRAD_INPLACE", fused)      # (0: tap-major operand rows, staging buffer, permute / copy launches)
+        monkeypatch.setenv("VIDC_TRAIN_XT_BF16", fused)            # (0: the 1x1 convs' right operand transposed from the fp32 tensor)
+        monkeypatch.setenv("VIDC_TRAIN_ADD_BF16", fused)           # (0: the next block's convs cast the block output themselves)
         cnn = ModifiedFPN().to(DEV)
         st = cnn.state_dict()
         st.update({k: v.to(DEV) for k, v in seeded_weights["dc"].items()})

@@ -849,6 +849,37 @@ im2col_t64_kernel(const float* __restrict__ x, float* __restrict__ xt, int B, in
         }
     }
 }
+// Dense bf16 rows x[M][C] -> their transpose xt[C][Mp] (zeros for m >= M; Mp % 64 == 0): the right operand of the weight-gradient GEMM of a
+// 1x1 / stride-1 conv in the plain-bf16 mode, from the bf16 operand copy its forward already read (half the bytes of the fp32 source, no
+// rounding step: the bits are those vidc_im2col_transposed(split = 2) produces from the fp32 tensor, which rounds the same values).
+// 64 x 64 tile through LDS, 16-byte reads along C, 32-byte runs along m out.
+__global__ void __launch_bounds__(256)
+transpose_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ xt, int M, int C, int Mp) {
+    __shared__ unsigned short tile[64][66];
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    {
+        const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;            // 8 channel-octets x 32 rows, two passes
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ml = ty + 32 * r, m = m0 + ml, c = c0 + tx * 8;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (m < M && c < C) v = *reinterpret_cast<const uint4*>(x + (size_t)m * C + c);
+            unsigned short* t = &tile[ml][tx * 8];
+            t[0] = (unsigned short)v.x; t[1] = (unsigned short)(v.x >> 16); t[2] = (unsigned short)v.y; t[3] = (unsigned short)(v.y >> 16);
+            t[4] = (unsigned short)v.z; t[5] = (unsigned short)(v.z >> 16); t[6] = (unsigned short)v.w; t[7] = (unsigned short)(v.w >> 16);
+        }
+    }
+    __syncthreads();
+    const int cl = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16, c = c0 + cl, m = m0 + seg;
+    if (c < C && m < Mp) {
+        unsigned w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = (unsigned)tile[seg + 2 * k][cl] | ((unsigned)tile[seg + 2 * k + 1][cl] << 16);
+        uint4* dst = reinterpret_cast<uint4*>(xt + (size_t)c * Mp + m);
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+}
 // dw_oihw[co][ci][tap] = tmp[co][tap * Cin + ci]
 __global__ void __launch_bounds__(TT) wgrad_permute_kernel(const float* __restrict__ tmp, float* __restrict__ dw, int Cout, int Cin, int taps) {
     const long long i = (long long)blockIdx.x * TT + threadIdx.x;
@@ -1200,6 +1231,17 @@ extern "C" int vidc_im2col_transposed(const float* x, float* xt, int B, int H, i
         hipLaunchKernelGGL(im2col_t_kernel, dim3(Mp / 32, (C + 31) / 32, KH * KW), dim3(256), 0, vidc::as_stream(stream), x, xt, B, H, W, C, ldx, Ho, Wo, KH, KW,
                            stride, pad, (int)M, Mp, split);
     VIDC_CHECK_LAUNCH("im2col_t_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_transpose_bf16(const void* x_bf16, void* xt_bf16, long long M, int C, int Mp, vidc_stream_t stream) {
+    VIDC_REQUIRE(x_bf16 && xt_bf16, VIDC_ERR_NULL, "vidc_transpose_bf16: null pointer");
+    VIDC_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && Mp >= M && Mp % 64 == 0 && M < (1ll << 31) &&
+                     ((reinterpret_cast<uintptr_t>(x_bf16) | reinterpret_cast<uintptr_t>(xt_bf16)) & 15) == 0,
+                 VIDC_ERR_SHAPE, "vidc_transpose_bf16: C a multiple of 8, Mp = M rounded up to a multiple of 64, 16-byte aligned tensors");
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(Mp / 64, (C + 63) / 64), dim3(256), 0, vidc::as_stream(stream),
+                       reinterpret_cast<const unsigned short*>(x_bf16), reinterpret_cast<unsigned short*>(xt_bf16), (int)M, C, Mp);
+    VIDC_CHECK_LAUNCH("transpose_bf16_kernel");
     return VIDC_OK;
 }
 

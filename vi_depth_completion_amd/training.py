@@ -156,6 +156,13 @@ class DepthCompletionTrainer:
         # against 32.6 in bf16, 80.4 against 71.6 in fp32 -- ~340 extra fork / join edges per step cost more than the shorter chain
         # saves (the same finding as for side streams inside the inference graphs).
         self.wgrad_side = os.environ.get("VIDC_TRAIN_WGRAD_STREAM", "0") == "1"
+        # Round-3 launch reductions, each bit-identical to the form it replaces; the switches exist for the A/B runs and the tests:
+        # dY^T of a conv written by the BatchNorm backward that produces dY; the weight-gradient GEMM writing .grad in place (channel-major
+        # operand rows); the residual add writing the block output's bf16 operand copy.
+        self.dyt_fused = os.environ.get("VIDC_TRAIN_DYT_FUSED", "1") == "1"
+        self.wgrad_inplace = os.environ.get("VIDC_TRAIN_WGRAD_INPLACE", "1") == "1"
+        self.add_bf16 = os.environ.get("VIDC_TRAIN_ADD_BF16", "1") == "1"
+        self.xt_from_bf16 = os.environ.get("VIDC_TRAIN_XT_BF16", "1") == "1"      # 1x1 convs: the wgrad GEMM's right operand transposed from the bf16 copy
         self._wgrad_streams, self._wgrad_used = {}, []
         self._retired = []          # outgrown scratch / workspace buffers that captured graphs still address (see _retire)
         self._keepalive = []        # backward closures already run in the current _run_tape, kept until the stream lanes have joined
@@ -345,8 +352,12 @@ class DepthCompletionTrainer:
             L.check(lib.vidc_im2col_transposed(L.ptr(g), L.ptr(gt), B, Ho, Wo, co, _ld(g), Ho, Wo, 1, 1, 1, 0, Mp, split, st), "transpose dY")
         # rows of Xt in channel-major order (split + 4): the GEMM's output [co][ci*taps + tap] IS the OIHW weight gradient, written in place
         # (no staging buffer, no permute / copy launch)
-        inplace = os.environ.get("VIDC_TRAIN_WGRAD_INPLACE", "1") == "1"      # 0: tap-major rows, staging buffer, permute / copy (A/B, tests)
-        L.check(lib.vidc_im2col_transposed(L.ptr(x.t), L.ptr(xt), B, H, W, ci, x.ld, Ho, Wo, kh, kw, stride, pad, Mp, split | (4 if inplace else 0), st), "im2col^T")
+        inplace = self.wgrad_inplace            # False: tap-major rows, staging buffer, permute / copy (A/B, tests)
+        if bf16 and taps == 1 and stride == 1 and pad == 0 and x.bf is not None and self.xt_from_bf16:
+            # 1x1 / stride 1: Xt is the plain transpose of x, taken from the bf16 operand copy the forward conv read (half the bytes, same bits)
+            L.check(lib.vidc_transpose_bf16(L.ptr(x.bf), L.ptr(xt), M, ci, Mp, st), "transpose x (bf16)")
+        else:
+            L.check(lib.vidc_im2col_transposed(L.ptr(x.t), L.ptr(xt), B, H, W, ci, x.ld, Ho, Wo, kh, kw, stride, pad, Mp, split | (4 if inplace else 0), st), "im2col^T")
         Mp //= e
         n_out = taps * ci
         gw = self.grad[key + ".weight"]
@@ -376,8 +387,11 @@ class DepthCompletionTrainer:
         B, H, W, _ = x.t.shape
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
         wp = self._pack(key, "f", w)
+        if self.precision == L.PREC_BF16 and x.bf is None and ci % 64 == 0:      # the bf16 operand copy, made once per activation: every conv that
+            x.bf = self._empty(B, H, W, ci // 2)                                   # reads x uses it, and so does the weight-gradient transpose
+            L.check(L.lib().vidc_cast_bf16(L.ptr(x.t), L.ptr(x.bf), B * H * W, ci, x.ld, L.current_stream()), "cast")
         y = Act(out if out is not None else self._empty(B, Ho, Wo, co))
-        y.conv_out = not relu and os.environ.get("VIDC_TRAIN_DYT_FUSED", "1") == "1"
+        y.conv_out = not relu and self.dyt_fused
         self._conv_call(x.t, wp, bias if bias is not None else self._const(self._zeros, co, 0.0), y.t, kh, kw, stride, pad, relu, False, x_bf=x.bf)
 
         def backward():
@@ -469,7 +483,7 @@ class DepthCompletionTrainer:
     def add(self, a, b, relu, out=None):
         Cc = a.t.shape[-1]
         y = Act(out if out is not None else self._empty(*a.t.shape))
-        if self.precision == L.PREC_BF16 and Cc % 64 == 0 and relu and os.environ.get("VIDC_TRAIN_ADD_BF16", "1") == "1":      # a block output: the next block's convs read it as a bf16 operand
+        if self.precision == L.PREC_BF16 and Cc % 64 == 0 and relu and self.add_bf16:      # a block output: the next block's convs read it as a bf16 operand
             y.bf = self._empty(*a.t.shape[:-1], Cc // 2)
         L.check(L.lib().vidc_add_rows_bf16(L.ptr(a.t), L.ptr(b.t), L.ptr(y.t), a.rows, Cc, a.ld, b.ld, y.ld, int(relu),
                                            L.ptr(y.bf) if y.bf is not None else None, L.current_stream()), "add")
