@@ -429,7 +429,8 @@ int vidc_bn_train_backward(const float* dy, const float* x, const float* y_relu,
                            void* dx_bf16, void* scratch, vidc_stream_t stream);
 /* The same, which can also write dx TRANSPOSED as plain bf16 rows dx_bf16_t[C][Mp] (Mp = M rounded up to a multiple of 64, zeros past
  * M; may be NULL): when the BatchNorm follows a conv, dx is that conv's dY and this is the left operand of its weight-gradient GEMM --
- * what vidc_im2col_transposed(dY, KH = KW = 1, split = 2) would build with one more launch and one more pass over dY. */
+ * what vidc_im2col_transposed(dY, KH = KW = 1, split = 2) would build with one more launch and one more pass over dY.  dx may be NULL when
+ * both bf16 forms are written (a stride-1 conv without bias reads its dY only through them). */
 int vidc_bn_train_backward_t(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
                              int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                              void* dx_bf16, void* dx_bf16_t, int Mp, void* scratch, vidc_stream_t stream);

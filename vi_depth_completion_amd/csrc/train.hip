@@ -220,7 +220,7 @@ bn_bwd_apply_t64_kernel(const float* __restrict__ dy, const float* __restrict__ 
                 const float xh = (xv[k] - mu[k]) * rs[k];
                 o[k] = gs[k] * (g[k] - m1[k] - xh * m2[k]);
             }
-            *reinterpret_cast<float4*>(dx + (size_t)m * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+            if (dx) *reinterpret_cast<float4*>(dx + (size_t)m * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);      // (NULL: nobody reads the fp32 form)
             if (dx_bf16)
                 *reinterpret_cast<uint2*>(dx_bf16 + (size_t)m * C + c) = make_uint2(vidc::bf16_rne(o[0]) | ((unsigned)vidc::bf16_rne(o[1]) << 16),
                                                                                     vidc::bf16_rne(o[2]) | ((unsigned)vidc::bf16_rne(o[3]) << 16));
@@ -990,7 +990,8 @@ extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int 
 extern "C" int vidc_bn_train_backward_t(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
                                         int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                                         void* dx_bf16, void* dx_bf16_t, int Mp, void* scratch, vidc_stream_t stream) {
-    VIDC_REQUIRE(dy && x && dx && gamma && save_mean && save_rstd && dgamma && dbeta && scratch, VIDC_ERR_NULL, "vidc_bn_train_backward: null pointer");
+    VIDC_REQUIRE(dy && x && gamma && save_mean && save_rstd && dgamma && dbeta && scratch, VIDC_ERR_NULL, "vidc_bn_train_backward: null pointer");
+    VIDC_REQUIRE(dx || (dx_bf16 && dx_bf16_t), VIDC_ERR_NULL, "vidc_bn_train_backward: dx may be NULL only when both bf16 forms are written");
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!y_relu || ldy % 4 == 0), VIDC_ERR_SHAPE,
                  "vidc_bn_train_backward: bad shape");
     VIDC_REQUIRE(!dx_bf16_t || (Mp >= M && Mp % 64 == 0 && M < (1ll << 31) && (reinterpret_cast<uintptr_t>(dx_bf16_t) & 7) == 0), VIDC_ERR_SHAPE,

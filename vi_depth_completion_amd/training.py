@@ -37,12 +37,13 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 class Act:
     """An activation: NHWC rows `t` (B,H,W,C view, possibly a channel slice of a wider buffer) + its gradient (same geometry)."""
-    __slots__ = ("t", "grad", "bf", "grad_bf", "grad_t", "conv_out")      # bf / grad_bf: bf16 operand copies (dense rows) written by the producing kernel
+    __slots__ = ("t", "grad", "bf", "grad_bf", "grad_t", "conv_out", "no_f32_grad")      # bf / grad_bf: bf16 operand copies (dense rows) written by the producing kernel
     # grad_t: (tensor, Mp) -- the gradient transposed as bf16 rows [C][Mp], written by the BatchNorm backward behind a conv (conv_out): the
     # left operand of that conv's weight-gradient GEMM
 
     def __init__(self, t):
         self.t, self.grad, self.bf, self.grad_bf, self.grad_t, self.conv_out = t, None, None, None, None, False
+        self.no_f32_grad = False      # conv output whose conv reads dY only through grad_bf / grad_t: the BatchNorm backward skips the fp32 form
 
     @property
     def ld(self):
@@ -162,6 +163,7 @@ class DepthCompletionTrainer:
         self.dyt_fused = os.environ.get("VIDC_TRAIN_DYT_FUSED", "1") == "1"
         self.wgrad_inplace = os.environ.get("VIDC_TRAIN_WGRAD_INPLACE", "1") == "1"
         self.add_bf16 = os.environ.get("VIDC_TRAIN_ADD_BF16", "1") == "1"
+        self.skip_f32_dy = os.environ.get("VIDC_TRAIN_SKIP_F32_DY", "1") == "1"    # the BatchNorm backward writes no fp32 dY where only the bf16 forms are read
         self.xt_from_bf16 = os.environ.get("VIDC_TRAIN_XT_BF16", "1") == "1"      # 1x1 convs: the wgrad GEMM's right operand transposed from the bf16 copy
         self._wgrad_streams, self._wgrad_used = {}, []
         self._retired = []          # outgrown scratch / workspace buffers that captured graphs still address (see _retire)
@@ -327,6 +329,17 @@ class DepthCompletionTrainer:
                 L.check(L.lib().vidc_pack_conv_weights_batched(L.ptr(dev), n, blocks, L.current_stream()), "pack")
         self._packed_fresh = True
 
+    def _wgrad_fits(self, geom):
+        """Whether `_wgrad_gemm` takes this shape (else the direct pixel-reduction kernel runs, which reads the fp32 dY)."""
+        B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad = geom
+        if os.environ.get("VIDC_WGRAD", "gemm") != "gemm":
+            return False
+        taps, M = kh * kw, B * Ho * Wo
+        bf16 = self.precision == L.PREC_BF16
+        Mp = (M + 63) // 64 * 64 if bf16 else (M + 31) // 32 * 32
+        e = 2 if bf16 else 1
+        return not (taps * ci * Mp * 4 // e >= (1 << 31) or co * Mp // e >= (1 << 29) or ci % 32 or co % 4)
+
     def _wgrad_gemm(self, g, x, key, geom, g_t=None):
         """dW through the conv kernel: dW[co][ci][tap] = sum over pixels of dY^T[co][m] * Xt[ci*taps + tap][m] is the 1x1 case of
         vidc_conv2d_bn_act with the rows of dY^T as activations and the rows of Xt (the transposed im2col of x, channel-major) as weights
@@ -334,15 +347,13 @@ class DepthCompletionTrainer:
         32-bit limits of the conv kernel) -- and its output is the parameter's .grad in place.  g_t: dY^T if the BatchNorm backward has
         written it already.  Returns False when the shape does not fit."""
         B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad = geom
-        if os.environ.get("VIDC_WGRAD", "gemm") != "gemm":
+        if not self._wgrad_fits(geom):
             return False
         lib, st = L.lib(), L.current_stream()
         taps, M = kh * kw, B * Ho * Wo
         bf16 = self.precision == L.PREC_BF16
         Mp = (M + 63) // 64 * 64 if bf16 else (M + 31) // 32 * 32
         e = 2 if bf16 else 1                     # pixels per 4-byte element of an operand row
-        if taps * ci * Mp * 4 // e >= (1 << 31) or co * Mp // e >= (1 << 29) or ci % 32 or co % 4:
-            return False
         xt = self._empty(taps * ci, Mp // e)
         split = {L.PREC_FP32: 0, L.PREC_BF16X3: 1, L.PREC_BF16: 2}[self.precision]      # operands written in the GEMM's format directly
         if g_t is not None and bf16 and g_t[1] == Mp and g_t[0].numel() == co * Mp // e:
@@ -392,6 +403,9 @@ class DepthCompletionTrainer:
             L.check(L.lib().vidc_cast_bf16(L.ptr(x.t), L.ptr(x.bf), B * H * W, ci, x.ld, L.current_stream()), "cast")
         y = Act(out if out is not None else self._empty(B, Ho, Wo, co))
         y.conv_out = not relu and self.dyt_fused
+        # stride 1, no bias, bf16 operands, GEMM weight gradient: this conv's backward reads dY only as bf16 rows (dgrad) and as dY^T (wgrad)
+        y.no_f32_grad = (y.conv_out and self.skip_f32_dy and self.precision == L.PREC_BF16 and stride == 1 and bias is None and co % 64 == 0 and
+                         B * Ho * Wo < (1 << 31) and self._wgrad_fits((B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad)))
         self._conv_call(x.t, wp, bias if bias is not None else self._const(self._zeros, co, 0.0), y.t, kh, kw, stride, pad, relu, False, x_bf=x.bf)
 
         def backward():
@@ -425,7 +439,8 @@ class DepthCompletionTrainer:
                 x.grad = self._empty(B, H, W, ci)
             if acc:
                 x.grad_bf = x.grad_t = None                  # x.grad changes below
-            self._conv_call(gz, wd, self._const(self._zeros, ci, 0.0), x.grad, kh, kw, 1, kh - 1 - pad, False, acc, x_bf=g_bf)
+            # (gz None: the BatchNorm backward wrote dY as bf16 only -- y.t stands in for its geometry, the kernel reads g_bf)
+            self._conv_call(gz if gz is not None else y.t, wd, self._const(self._zeros, ci, 0.0), x.grad, kh, kw, 1, kh - 1 - pad, False, acc, x_bf=g_bf)
 
         self._record(backward)
         return y
@@ -446,14 +461,16 @@ class DepthCompletionTrainer:
 
         def backward():
             acc = x.grad is not None
+            skip_f32 = (not acc) and bf16 and x.conv_out and x.no_f32_grad and x.rows < (1 << 31)      # dY is read through its two bf16 forms only
             dx = self._empty(*x.t.shape) if acc else None
-            target = dx if acc else self._empty(*x.t.shape)
+            target = dx if acc else (None if skip_f32 else self._empty(*x.t.shape))
             tbf = self._empty(*x.t.shape[:-1], Cc // 2) if (bf16 and not acc) else None
             # x = a conv's output: dx is that conv's dY, and its weight-gradient GEMM wants dY^T as bf16 rows [C][Mp] -- written here, by the
             # kernel that produces dY, instead of by a transpose launch of its own (one launch and one pass over dY less per conv)
             Mp = (x.rows + 63) // 64 * 64
             tbt = self._empty(Cc, Mp // 2) if (tbf is not None and x.conv_out and x.rows < (1 << 31)) else None
-            L.check(L.lib().vidc_bn_train_backward_t(L.ptr(y.grad), L.ptr(x.t), L.ptr(y.t) if relu else None, L.ptr(target), x.rows, Cc, _ld(y.grad), x.ld, y.ld,
+            L.check(L.lib().vidc_bn_train_backward_t(L.ptr(y.grad), L.ptr(x.t), L.ptr(y.t) if relu else None, L.ptr(target) if target is not None else None,
+                                                     x.rows, Cc, _ld(y.grad), x.ld, y.ld,
                                                      Cc, L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(self.grad[key + ".weight"]), L.ptr(self.grad[key + ".bias"]),
                                                      L.ptr(tbf) if tbf is not None else None, L.ptr(tbt) if tbt is not None else None, Mp,
                                                      L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_backward")
