@@ -422,6 +422,11 @@ size_t vidc_train_scratch_bytes(long long M, int C);
 int vidc_bn_train_forward(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
                           void* y_bf16, void* scratch, vidc_stream_t stream);
+/* The same with the Bottleneck tail in the apply pass: y = relu?(BatchNorm(x) + residual) (residual NHWC with channel stride ldr, or NULL);
+ * the BatchNorm value is rounded to fp32 before the sum, so the result equals vidc_bn_train_forward followed by vidc_add_rows. */
+int vidc_bn_train_forward_add(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
+                              void* y_bf16, const float* residual, int ldr, void* scratch, vidc_stream_t stream);
 /* Its backward.  y_relu: the forward output when a ReLU followed (its mask is applied to dy), else NULL.  dx may alias dy.
  * dx_bf16 (may be NULL): dx as dense bf16 rows as well (the dgrad conv of the layer in front reads it). */
 int vidc_bn_train_backward(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,

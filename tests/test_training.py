@@ -597,6 +597,7 @@ def test_fused_transposed_gradient_of_the_bn_backward_is_bit_identical(golden_di
         monkeypatch.setenv("VIDC_TRAIN_WGRAD_INPLACE", fused)      # (0: tap-major operand rows, staging buffer, permute / copy launches)
         monkeypatch.setenv("VIDC_TRAIN_XT_BF16", fused)            # (0: the 1x1 convs' right operand transposed from the fp32 tensor)
         monkeypatch.setenv("VIDC_TRAIN_SKIP_F32_DY", fused)        # (0: the BatchNorm backward also writes the fp32 dY nobody reads)
+        monkeypatch.setenv("VIDC_TRAIN_BN_ADD_FUSED", fused)       # (0: relu(bn3(.) + identity) as a BatchNorm followed by an add kernel)
         monkeypatch.setenv("VIDC_TRAIN_ADD_BF16", fused)           # (0: the next block's convs cast the block output themselves)
         cnn = ModifiedFPN().to(DEV)
         st = cnn.state_dict()

@@ -128,19 +128,24 @@ __global__ void __launch_bounds__(TT) chan_final_kernel(const double* __restrict
 __global__ void __launch_bounds__(TT)
 bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long long M, int C, int ldx, int ldy, const float* __restrict__ mean,
                 const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                unsigned short* __restrict__ y_bf16) {
+                unsigned short* __restrict__ y_bf16, const float* __restrict__ res, int ldr) {
     const int c4 = C >> 2;
     const long long i = (long long)blockIdx.x * TT + threadIdx.x;
     if (i >= M * c4) return;
     const long long r = i / c4;
     const int c = (int)(i - r * c4) * 4;
     const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
-    float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+    float in[4] = {v.x, v.y, v.z, v.w}, out[4], add[4] = {0.f, 0.f, 0.f, 0.f};
+    if (res) {          // Bottleneck tail: relu(bn3(.) + identity) in the same pass (the BatchNorm value is rounded to fp32 before the sum, as when
+        const float4 q = *reinterpret_cast<const float4*>(res + r * ldr + c);      // it was stored and read back by a separate add kernel)
+        add[0] = q.x; add[1] = q.y; add[2] = q.z; add[3] = q.w;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float alpha = rstd[c + k] * gamma[c + k];
         const float bb = beta[c + k] - mean[c + k] * alpha;
-        const float o = in[k] * alpha + bb;
+        float o = in[k] * alpha + bb;
+        if (res) o = __fadd_rn(o, add[k]);
         out[k] = relu ? fmaxf(o, 0.f) : o;
     }
     *reinterpret_cast<float4*>(y + r * ldy + c) = make_float4(out[0], out[1], out[2], out[3]);
@@ -968,11 +973,12 @@ extern "C" size_t vidc_train_scratch_bytes(long long M, int C) {
     return ((size_t)chunks_for(M, C) * 2 * (size_t)C + 2 * (size_t)C) * sizeof(double) + 256;
 }
 
-extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
-                                     float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
-                                     void* y_bf16, void* scratch, vidc_stream_t stream) {
+extern "C" int vidc_bn_train_forward_add(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
+                                         void* y_bf16, const float* residual, int ldr, void* scratch, vidc_stream_t stream) {
     VIDC_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && scratch, VIDC_ERR_NULL, "vidc_bn_train_forward: null pointer");
-    VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0, VIDC_ERR_SHAPE, "vidc_bn_train_forward: bad shape");
+    VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || (ldr >= C && ldr % 4 == 0)),
+                 VIDC_ERR_SHAPE, "vidc_bn_train_forward: bad shape");
     hipStream_t st = vidc::as_stream(stream);
     const int nch = chunks_for(M, C);
     double* partial = reinterpret_cast<double*>(scratch);
@@ -982,9 +988,16 @@ extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int 
     hipLaunchKernelGGL(chan_final_kernel<FinalStats>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums,
                        FinalStats{M, eps, momentum, save_mean, save_rstd, running_mean, running_var});
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, x, y, M, C, ldx, ldy, save_mean, save_rstd, gamma, beta, relu,
-                       reinterpret_cast<unsigned short*>(y_bf16));
+                       reinterpret_cast<unsigned short*>(y_bf16), residual, ldr);
     VIDC_CHECK_LAUNCH("bn_train_forward");
     return VIDC_OK;
+}
+
+extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
+                                     void* y_bf16, void* scratch, vidc_stream_t stream) {
+    return vidc_bn_train_forward_add(x, y, M, C, ldx, ldy, gamma, beta, running_mean, running_var, eps, momentum, relu, save_mean, save_rstd, y_bf16, nullptr, 0,
+                                     scratch, stream);
 }
 
 extern "C" int vidc_bn_train_backward_t(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,

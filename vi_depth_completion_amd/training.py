@@ -163,6 +163,7 @@ class DepthCompletionTrainer:
         self.dyt_fused = os.environ.get("VIDC_TRAIN_DYT_FUSED", "1") == "1"
         self.wgrad_inplace = os.environ.get("VIDC_TRAIN_WGRAD_INPLACE", "1") == "1"
         self.add_bf16 = os.environ.get("VIDC_TRAIN_ADD_BF16", "1") == "1"
+        self.bn_add_fused = os.environ.get("VIDC_TRAIN_BN_ADD_FUSED", "1") == "1"   # Bottleneck tail relu(bn3(.) + identity) inside bn3's apply pass
         self.skip_f32_dy = os.environ.get("VIDC_TRAIN_SKIP_F32_DY", "1") == "1"    # the BatchNorm backward writes no fp32 dY where only the bf16 forms are read
         self.xt_from_bf16 = os.environ.get("VIDC_TRAIN_XT_BF16", "1") == "1"      # 1x1 convs: the wgrad GEMM's right operand transposed from the bf16 copy
         self._wgrad_streams, self._wgrad_used = {}, []
@@ -446,7 +447,9 @@ class DepthCompletionTrainer:
         return y
 
     # ---- BatchNorm (train mode) + ReLU ---------------------------------------------------------------------------------------------
-    def bn(self, x, key, relu, out=None):
+    def bn(self, x, key, relu, out=None, residual=None):
+        """BatchNorm2d in train mode (+ReLU).  residual: the Bottleneck tail in the same pass, y = relu?(bn(x) + residual) -- the value and
+        the backward are those of bn(x, relu=False) followed by add(., residual, relu); the add's launch and its pass over the map go."""
         Cc = x.t.shape[-1]
         y = Act(out if out is not None else torch.empty_like(x.t))
         mean, rstd = self._empty(Cc), self._empty(Cc)
@@ -454,12 +457,29 @@ class DepthCompletionTrainer:
         bf16 = self.precision == L.PREC_BF16 and Cc % 64 == 0
         if bf16:
             y.bf = self._empty(*x.t.shape[:-1], Cc // 2)
-        L.check(L.lib().vidc_bn_train_forward(L.ptr(x.t), L.ptr(y.t), x.rows, Cc, x.ld, y.ld, L.ptr(gamma), L.ptr(beta), L.ptr(self.buf[key + ".running_mean"]),
-                                              L.ptr(self.buf[key + ".running_var"]), BN_EPS, BN_MOMENTUM, int(relu), L.ptr(mean), L.ptr(rstd),
-                                              L.ptr(y.bf) if y.bf is not None else None, L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_forward")
+        L.check(L.lib().vidc_bn_train_forward_add(L.ptr(x.t), L.ptr(y.t), x.rows, Cc, x.ld, y.ld, L.ptr(gamma), L.ptr(beta), L.ptr(self.buf[key + ".running_mean"]),
+                                                  L.ptr(self.buf[key + ".running_var"]), BN_EPS, BN_MOMENTUM, int(relu), L.ptr(mean), L.ptr(rstd),
+                                                  L.ptr(y.bf) if y.bf is not None else None, L.ptr(residual.t) if residual is not None else None,
+                                                  residual.ld if residual is not None else 0, L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_forward")
         self._nbt.append(self.buf[key + ".num_batches_tracked"])
+        y_in = y               # what the BatchNorm part of the backward takes dy from
+        if residual is not None:
+            y_in = Act(y.t)    # (geometry only: its .grad is the masked gradient handed on by the add part)
+
+        def add_backward():    # the add's backward (training.add): mask by the ReLU, hand the gradient to both summands
+            g = y.grad
+            if relu:
+                gm = self._empty(*y.t.shape)
+                L.check(L.lib().vidc_relu_backward(L.ptr(g), L.ptr(y.t), L.ptr(gm), y.rows, Cc, _ld(g), y.ld, Cc, 0, L.current_stream()), "relu_bwd")
+                g = gm
+            y_in.grad = g
+            self._accumulate(residual, g)
+
+        mask_relu = relu and residual is None      # with a residual the ReLU sits behind the sum: its mask is applied by add_backward
 
         def backward():
+            if residual is not None:
+                add_backward()
             acc = x.grad is not None
             skip_f32 = (not acc) and bf16 and x.conv_out and x.no_f32_grad and x.rows < (1 << 31)      # dY is read through its two bf16 forms only
             dx = self._empty(*x.t.shape) if acc else None
@@ -469,8 +489,8 @@ class DepthCompletionTrainer:
             # kernel that produces dY, instead of by a transpose launch of its own (one launch and one pass over dY less per conv)
             Mp = (x.rows + 63) // 64 * 64
             tbt = self._empty(Cc, Mp // 2) if (tbf is not None and x.conv_out and x.rows < (1 << 31)) else None
-            L.check(L.lib().vidc_bn_train_backward_t(L.ptr(y.grad), L.ptr(x.t), L.ptr(y.t) if relu else None, L.ptr(target) if target is not None else None,
-                                                     x.rows, Cc, _ld(y.grad), x.ld, y.ld,
+            L.check(L.lib().vidc_bn_train_backward_t(L.ptr(y_in.grad), L.ptr(x.t), L.ptr(y.t) if mask_relu else None, L.ptr(target) if target is not None else None,
+                                                     x.rows, Cc, _ld(y_in.grad), x.ld, y.ld,
                                                      Cc, L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(self.grad[key + ".weight"]), L.ptr(self.grad[key + ".bias"]),
                                                      L.ptr(tbf) if tbf is not None else None, L.ptr(tbt) if tbt is not None else None, Mp,
                                                      L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_backward")
@@ -567,9 +587,13 @@ class DepthCompletionTrainer:
     def _bottleneck(self, x, p, stride, project, out=None):
         t = self.bn(self.conv(x, p + "conv1"), p + "bn1", True)
         t = self.bn(self.conv(t, p + "conv2", stride, 1), p + "bn2", True)
-        t = self.bn(self.conv(t, p + "conv3"), p + "bn3", False)
+        if not self.bn_add_fused:
+            t = self.bn(self.conv(t, p + "conv3"), p + "bn3", False)
+            idn = self.bn(self.conv(x, p + "downsample.0", stride, 0), p + "downsample.1", False) if project else x
+            return self.add(t, idn, True, out=out)
+        t = self.conv(t, p + "conv3")
         idn = self.bn(self.conv(x, p + "downsample.0", stride, 0), p + "downsample.1", False) if project else x
-        return self.add(t, idn, True, out=out)
+        return self.bn(t, p + "bn3", True, out=out, residual=idn)      # relu(bn3(.) + identity) in the BatchNorm's apply pass
 
     def _pyramid(self, x_nchw, p, module, level_out):
         """ResNetPyramids.forward (depth_completion.py:55-65) in train mode; level l's output goes to `level_out[l]` (a channel slice of
