@@ -305,20 +305,33 @@ class DepthCompletionPipeline:
                 break
         for j, batch in enumerate(first):
             lane_objs[j].phase_a(batch)
+        # ... and a lane whose first frame has just been enriched takes its NEXT frame at once (segment 0 needs nothing else), before the
+        # host turns to the next lane's hypothesis draws: during the fill a lane has no depth decoder queued that would cover them.
+        started = []                            # batches whose phase_a has already run (in stream order)
+        early = os.environ.get("VIDC_EARLY_SECOND_FRAME", "1") == "1" and len(first) == n
         for j in range(len(first)):
             lane = lane_objs[j]
             k += 1
             if waiting is not None:
                 waiting.finish_enrich()
+                if early:
+                    nxt = next(batches, None)
+                    if nxt is not None:
+                        waiting.phase_a(nxt)    # (the lane has no output to hand out yet: this is its second frame)
+                        started.append(nxt)
+                    else:
+                        early = False
             lane.phase_b(copy_outputs)
             waiting = lane if lane.pending_enrich is not None else None
-        for batch in batches:
+        import itertools
+        for idx, batch in enumerate(itertools.chain(list(started), batches)):
             lane = lane_objs[k % n]
             k += 1
-            out = lane.collect()
-            if out is not None:
-                yield out
-            lane.phase_a(batch)
+            if idx >= len(started):             # (else: segment 0 of this frame is already running)
+                out = lane.collect()
+                if out is not None:
+                    yield out
+                lane.phase_a(batch)
             if waiting is not None:
                 waiting.finish_enrich()
             lane.phase_b(copy_outputs)
