@@ -510,6 +510,10 @@ int vidc_im2col_transposed(const float* x, float* xt, int B, int H, int W, int C
  * dense bf16 rows x[M][C] -> xt[C][Mp] (zeros for m >= M, Mp % 64 == 0, C % 8 == 0).  Same bits as vidc_im2col_transposed(split = 2) of
  * the fp32 tensor the copy was rounded from. */
 int vidc_transpose_bf16(const void* x_bf16, void* xt_bf16, long long M, int C, int Mp, vidc_stream_t stream);
+/* vidc_im2col_transposed(..., split = 2 + 4) from the bf16 operand copy of x (dense bf16 rows [B*H*W][C]) instead of the fp32 tensor: the
+ * right operand of any conv's weight-gradient GEMM in the plain-bf16 mode at half the input bytes, same bits. */
+int vidc_im2col_transposed_bf16(const void* x_bf16, void* xt_bf16, int B, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                                int Mp, vidc_stream_t stream);
 int vidc_wgrad_permute(const float* tmp, float* dw_oihw, int Cout, int Cin, int taps, vidc_stream_t stream);
 /* wgrad of the 3x3 / stride-2 stem conv on the NCHW network input (Cin = 1 or 3). */
 size_t vidc_stem_wgrad_scratch_bytes(int B, int Cin, int H, int W, int Cout);

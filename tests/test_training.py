@@ -325,6 +325,12 @@ def test_im2col_transposed_operands(k, stride, pad, C, H, W):
     xcb = torch.empty(k * k * C, Mq // 2, device=DEV)
     L.check(lib.vidc_im2col_transposed(L.ptr(xd), L.ptr(xcb), B, H, W, C, C, Ho, Wo, k, k, stride, pad, Mq, 2 | 4, st), "im2col^T bf16 channel-major")
     assert torch.equal(xcb.view(torch.bfloat16).cpu(), F.pad(want_cm, (0, Mq - Mp)).to(torch.bfloat16))
+    if C % 8 == 0:       # the same operand gathered from the dense bf16 copy of x (vidc_cast_bf16) instead of the fp32 tensor
+        xbf = torch.empty(B, H, W, C // 2, device=DEV)
+        L.check(lib.vidc_cast_bf16(L.ptr(xd), L.ptr(xbf), B * H * W, C, C, st), "cast")
+        xcb2 = torch.full((k * k * C, Mq // 2), 9.0, device=DEV)
+        L.check(lib.vidc_im2col_transposed_bf16(L.ptr(xbf), L.ptr(xcb2), B, H, W, C, Ho, Wo, k, k, stride, pad, Mq, st), "im2col^T from bf16")
+        assert torch.equal(xcb2.view(torch.int32).cpu(), xcb.view(torch.int32).cpu())
 
 
 def _bf16_round(t):

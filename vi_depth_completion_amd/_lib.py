@@ -109,6 +109,7 @@ SIGNATURES = {
     "vidc_im2col_transposed": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_wgrad_permute": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "vidc_transpose_bf16": (C.c_int, [_vp, _vp, C.c_longlong, _i, _i, _vp]),
+    "vidc_im2col_transposed_bf16": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_stem_wgrad_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "vidc_stem_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vidc_chain_create": (C.c_int, [C.POINTER(ConvDesc), _i, C.POINTER(_vp)]),

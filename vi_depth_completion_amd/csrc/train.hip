@@ -854,6 +854,37 @@ im2col_t64_kernel(const float* __restrict__ x, float* __restrict__ xt, int B, in
         }
     }
 }
+// im2col_t64_kernel for the plain-bf16 mode from the bf16 operand copy of x (dense rows [B*H*W][C] of bf16, what the forward conv read)
+// instead of the fp32 tensor: half the bytes in, no rounding step (same bits: the copy holds the rounded values).  Rows of xt in channel-major
+// order (c * taps + tap), plain bf16, Mp % 64 == 0.
+__global__ void __launch_bounds__(256)
+im2col_t64_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ xt, int B, int H, int W, int C, int Ho, int Wo, int KH, int KW,
+                       int stride, int pad, int M, int Mp) {
+    __shared__ unsigned short tile[64][66];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
+    const int kh = tap / KW, kw = tap - kh * KW, taps = KH * KW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + ty + 16 * r, c = c0 + tx * 4;
+        uint2 v = make_uint2(0u, 0u);
+        if (m < M && c < C) {
+            const int ox = m % Wo, q = m / Wo, oy = q % Ho, b = q / Ho;
+            const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const uint2*>(x + ((size_t)(b * H + iy) * W + ix) * C + c);
+        }
+        unsigned short* t = &tile[ty + 16 * r][tx * 4];
+        t[0] = (unsigned short)v.x; t[1] = (unsigned short)(v.x >> 16); t[2] = (unsigned short)v.y; t[3] = (unsigned short)(v.y >> 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cl = ty + 16 * r, c = c0 + cl, m = m0 + tx * 4;
+        if (c < C && m < Mp)
+            *reinterpret_cast<uint2*>(xt + ((size_t)c * taps + tap) * Mp + m) =
+                make_uint2((unsigned)tile[tx * 4][cl] | ((unsigned)tile[tx * 4 + 1][cl] << 16), (unsigned)tile[tx * 4 + 2][cl] | ((unsigned)tile[tx * 4 + 3][cl] << 16));
+    }
+}
 // Dense bf16 rows x[M][C] -> their transpose xt[C][Mp] (zeros for m >= M; Mp % 64 == 0): the right operand of the weight-gradient GEMM of a
 // 1x1 / stride-1 conv in the plain-bf16 mode, from the bf16 operand copy its forward already read (half the bytes of the fp32 source, no
 // rounding step: the bits are those vidc_im2col_transposed(split = 2) produces from the fp32 tensor, which rounds the same values).
@@ -1245,6 +1276,20 @@ extern "C" int vidc_im2col_transposed(const float* x, float* xt, int B, int H, i
         hipLaunchKernelGGL(im2col_t_kernel, dim3(Mp / 32, (C + 31) / 32, KH * KW), dim3(256), 0, vidc::as_stream(stream), x, xt, B, H, W, C, ldx, Ho, Wo, KH, KW,
                            stride, pad, (int)M, Mp, split);
     VIDC_CHECK_LAUNCH("im2col_t_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_im2col_transposed_bf16(const void* x_bf16, void* xt_bf16, int B, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                                           int Mp, vidc_stream_t stream) {
+    VIDC_REQUIRE(x_bf16 && xt_bf16, VIDC_ERR_NULL, "vidc_im2col_transposed_bf16: null pointer");
+    const long long M = (long long)B * Ho * Wo;
+    VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0 && Mp >= M && Mp % 64 == 0 && M < (1ll << 31) &&
+                     (long long)B * H * W * C < (1ll << 31) && (long long)KH * KW <= 65535 &&
+                     ((reinterpret_cast<uintptr_t>(x_bf16) | reinterpret_cast<uintptr_t>(xt_bf16)) & 7) == 0,
+                 VIDC_ERR_SHAPE, "vidc_im2col_transposed_bf16: bad shape (C a multiple of 4, Mp = M rounded up to a multiple of 64, 8-byte aligned tensors)");
+    hipLaunchKernelGGL(im2col_t64_bf16_kernel, dim3(Mp / 64, (C + 63) / 64, KH * KW), dim3(256), 0, vidc::as_stream(stream),
+                       reinterpret_cast<const unsigned short*>(x_bf16), reinterpret_cast<unsigned short*>(xt_bf16), B, H, W, C, Ho, Wo, KH, KW, stride, pad, (int)M, Mp);
+    VIDC_CHECK_LAUNCH("im2col_t64_bf16_kernel");
     return VIDC_OK;
 }
 

@@ -368,6 +368,9 @@ class DepthCompletionTrainer:
         if bf16 and taps == 1 and stride == 1 and pad == 0 and x.bf is not None and self.xt_from_bf16:
             # 1x1 / stride 1: Xt is the plain transpose of x, taken from the bf16 operand copy the forward conv read (half the bytes, same bits)
             L.check(lib.vidc_transpose_bf16(L.ptr(x.bf), L.ptr(xt), M, ci, Mp, st), "transpose x (bf16)")
+        elif bf16 and inplace and x.bf is not None and self.xt_from_bf16 and B * H * W * ci < (1 << 31):
+            # any other geometry: the transposed im2col gathered from the bf16 copy as well (half the input bytes of the fp32 source)
+            L.check(lib.vidc_im2col_transposed_bf16(L.ptr(x.bf), L.ptr(xt), B, H, W, ci, Ho, Wo, kh, kw, stride, pad, Mp, st), "im2col^T (bf16)")
         else:
             L.check(lib.vidc_im2col_transposed(L.ptr(x.t), L.ptr(xt), B, H, W, ci, x.ld, Ho, Wo, kh, kw, stride, pad, Mp, split | (4 if inplace else 0), st), "im2col^T")
         Mp //= e
