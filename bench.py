@@ -24,6 +24,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+_T0 = time.perf_counter()
 
 from vi_depth_completion_amd import sharding, synthetic as S   # noqa: E402
 
@@ -57,7 +58,16 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=2, help="frames executing concurrently in --mode streams")
     ap.add_argument("--lanes", type=int, default=2, help="--mode interleaved: software-pipelined frame streams on this many HIP streams, frame i on lane "
                                                           "i mod L (pipeline.run_interleaved(lanes=L)); results are bit-identical for every L")
-    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the second leg (the same steps with every conv in exact fp32 MFMA arithmetic)")
+    ap.add_argument("--frames-per-launch", type=int, default=2,
+                    help="--mode interleaved: this many consecutive items of the stream share every launch of a tick (pipeline.run_interleaved("
+                         "frames_per_launch=F): the frame program is recorded for batch F x B; items stay --batch frames each, with their own "
+                         "gravity, plane block and draws in _call_cnn order).  1 = one item per launch (rounds 1-3)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="only the mixed-mode leg (bf16x3 MFMA on the layers the measured table selects): it becomes "
+                                                               "the headline, with its dtype in the line")
+    ap.add_argument("--no-mixed-leg", action="store_true", help="only the headline leg (every conv in exact fp32 MFMA arithmetic)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the short child-process runs of BASELINE configs[4] (training step, bf16) and "
+                                                                 "configs[2] (640x480 stream, batch 8, plane head) that the default N=1 run appends as `extra_legs`")
+    ap.add_argument("--extra-legs-budget", type=float, default=75.0, help="seconds of wall clock since the start of this process after which no further extra leg is started")
     ap.add_argument("--no-sequential-leg", action="store_true", help="skip the short back-to-back _call_cnn measurement (per-frame latency and the "
                                                                        "rate of the operator the reference's harness calls, network_run.py:294-296)")
     ap.add_argument("--sequential-frames", type=int, default=20)
@@ -74,26 +84,15 @@ def parse():
 
 
 def launch_ranks(args):
-    """`bench.py --gpus N` called without a launcher: start the N ranks as a CHILD process (torch.distributed.run, rendezvous on
-    127.0.0.1) and return its exit code.  This process has not initialised the GPU (torch.cuda.device_count() does not on this
-    image), and it never replaces itself with another program."""
-    import socket
+    """`bench.py --gpus N` called without a launcher: start the N ranks as a CHILD process (torch.distributed.run --standalone, which
+    picks its own rendezvous port on 127.0.0.1) and return its exit code.  This process makes no HIP call at all (the ranks check
+    world size against the visible GPUs themselves and exit non-zero), and it never replaces itself with another program."""
     import subprocess
-    backend = os.environ.get("VIDC_DIST_BACKEND", "nccl")
-    n_dev = torch.cuda.device_count()
-    if backend == "nccl" and n_dev < args.gpus and not args.launcher_selftest:
-        print("bench.py: --gpus %d needs %d GPUs, this node shows %d (VIDC_DIST_BACKEND=gloo shares GPUs between ranks to try the "
-              "multi-rank path on a smaller box)" % (args.gpus, args.gpus, n_dev), file=sys.stderr)
-        return 2
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or args.gpus) // args.gpus)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 
@@ -225,8 +224,8 @@ def measure(args, dev, rank, world, precision):
             for out in pipe.run_stream(frames(n), in_flight=args.in_flight):
                 pass
         else:       # n frames = n + 1 pipeline ticks, all inside the timed region; outputs stay in the program's buffer (valid until the
-            for out in pipe.run_interleaved(frames(n), copy_outputs=False, lanes=args.lanes):      # next item is requested: documented lifetime)
-                pass
+            for out in pipe.run_interleaved(frames(n), copy_outputs=False, lanes=args.lanes, frames_per_launch=args.frames_per_launch):      # next item
+                pass                                                                                                                      # is requested: documented lifetime)
         return out
 
     run(args.warmup)
@@ -241,6 +240,23 @@ def measure(args, dev, rank, world, precision):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+
+    # ---- latency of the first item of a stream in the mode that was timed (outside the timed region): host time from the first request to
+    #      the first depth map being complete on the device; with --frames-per-launch F the first F items finish together ------------------
+    first_item_ms = None
+    if rank == 0 and args.mode == "interleaved":
+        lat = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            gen = pipe.run_interleaved(frames(2 * args.lanes * args.frames_per_launch), copy_outputs=False, lanes=args.lanes, frames_per_launch=args.frames_per_launch)
+            next(gen)
+            torch.cuda.current_stream().synchronize()
+            lat.append(time.perf_counter() - t1)
+            for _o in gen:
+                pass
+        torch.cuda.synchronize()
+        first_item_ms = round(1e3 * sorted(lat)[1], 3)
 
     # ---- the operator the reference's harness calls, frame after frame (network_run.py:294-296: one _call_cnn per batch, its output
     #      consumed before the next call): per-frame latency and the rate with ONE frame in flight.  Outside the timed region. ----------
@@ -266,8 +282,9 @@ def measure(args, dev, rank, world, precision):
     roofline = None
     extra = {}
     if rank == 0:
-        if args.mode == "interleaved":     # the program that was timed: one tick = both networks, 4-group pyramid launches
-            fp = pipe.frame_program(B, H, W)
+        fpt = B * (args.frames_per_launch if args.mode == "interleaved" else 1)      # frames per execution of the program measured below
+        if args.mode == "interleaved":     # the program that was timed: one tick = both networks, 4-group pyramid launches, F items per launch
+            fp = pipe.frame_program(fpt, H, W)
             sn_t, sn_total, sn_ops = conv_stack_times(fp)
             dc_t, dc_total, dc_ops = {}, 0.0, []
         else:
@@ -275,7 +292,7 @@ def measure(args, dev, rank, world, precision):
             dc_prog = pipe.cnn.program(B, H, W, dev)
             sn_t, sn_total, sn_ops = conv_stack_times(sn_prog)
             dc_t, dc_total, dc_ops = conv_stack_times(dc_prog)
-        flops = FLOPS_PER_FRAME.get((H, W), 293.88e9 * H * W / (240.0 * 320.0)) * B
+        flops = FLOPS_PER_FRAME.get((H, W), 293.88e9 * H * W / (240.0 * 320.0)) * fpt
         kernels = {}
         for d in (sn_t, dc_t):
             for k, (ms, cnt, fl) in d.items():
@@ -297,11 +314,12 @@ def measure(args, dev, rank, world, precision):
             r = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                  "kernel": kernel_name(tile, prec),
                  "arithmetic": ("bf16x3: 3 x v_mfma_f32_32x32x16_bf16 per fp32-equivalent product" if prec else "v_mfma_f32_32x32x2_f32"),
-                 "launches_per_frame": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2), "gflop_per_launch": round(fl / cnt / 1e9, 3),
-                 "ms_per_frame": round(ms, 3),
+                 "launches_per_frame": round(cnt / fpt, 2), "launches_per_tick": cnt, "frames_per_tick": fpt,
+                 "avg_launch_us": round(1e3 * ms / cnt, 2), "gflop_per_launch": round(fl / cnt / 1e9, 3),
+                 "ms_per_frame": round(ms / fpt, 3),
                  "timing_note": "per-launch durations are taken on ONE stream (the frame program alone, HIP events between ops, rescaled to its graph replay time); "
                                 "with --lanes 2 launches of the two streams overlap and a kernel trace of the run shows longer per-kernel durations: "
-                                "profiles/r3_kernel_stats_mixed.csv / r3_kernel_stats_fp32.csv (--lanes 1) are the traces these numbers agree with",
+                                "profiles/r4_kernel_stats_fp32.csv / r4_kernel_stats_mixed.csv (--lanes 1) are the traces these numbers agree with",
                  "traffic_note": "no PMC pass on file for this instantiation in profiles/pmc_traffic.json (tools/evidence_r3.sh collects them on "
                                  "tools/frame_replay.py: rocprofv3 --pmc on the whole bench process segfaults in rocprofv3 on this pool)"}
             if prec:
@@ -322,21 +340,22 @@ def measure(args, dev, rank, world, precision):
                                         "algorithmic bytes of that launch %d (profiles/pmc_traffic.json; --pmc on the whole bench process "
                                         "segfaults in rocprofv3 on this pool)" % (pmc["command"], pmc["shape"], pmc["algorithmic_bytes"]))
         ranked = sorted(kernels, key=lambda k: -kernels[k][0])
-        extra = {"program_ms": ({"frame_program_tick": round(sn_total, 3)} if args.mode == "interleaved" else
+        extra = {"program_ms": ({"frame_program_tick": round(sn_total, 3), "frames_per_tick": fpt} if args.mode == "interleaved" else
                                 {"surface_normal": round(sn_total, 3), "depth_completion": round(dc_total, 3)}),
-                 "conv_ms_per_frame": round(conv_ms, 3), "conv_launches_per_frame": n_launch,
-                 "conv_stack": {"executed_gflop_per_frame": round(conv_flops / 1e9, 2),
+                 "conv_ms_per_frame": round(conv_ms / fpt, 3), "conv_launches_per_frame": round(n_launch / fpt, 2), "conv_launches_per_tick": n_launch,
+                 "first_item_latency_ms": first_item_ms,
+                 "conv_stack": {"executed_gflop_per_frame": round(conv_flops / fpt / 1e9, 2),
                                 "tflops_fp32_equivalent": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
                                 "tflops_bf16_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / (conv_ms * 1e-3) / 1e12, 2),
                                 "note": "over the conv time of ONE frame program alone (single stream)",
                                 # the same FLOPs at the frame rate of the timed region of this rank (with --lanes 2 the launches of two
                                 # frame programs overlap, so the chip executes more per second than one program's own conv time implies)
                                 "at_measured_frame_rate": {
-                                    "tflops_fp32_equivalent": round(conv_flops / B * (args.steps * B / elapsed) / 1e12, 2),
-                                    "tflops_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / B * (args.steps * B / elapsed) / 1e12, 2),
-                                    "frac_of_peak_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / B * (args.steps * B / elapsed) / 1e12
+                                    "tflops_fp32_equivalent": round(conv_flops / fpt * (args.steps * B / elapsed) / 1e12, 2),
+                                    "tflops_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / fpt * (args.steps * B / elapsed) / 1e12, 2),
+                                    "frac_of_peak_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / fpt * (args.steps * B / elapsed) / 1e12
                                                                    / (PEAK_BF16_MFMA_TFLOPS if precision == "mixed" else PEAK_F32_MFMA_TFLOPS), 4)}},
-                 "reference_formulation_gflop_per_frame": round(flops / 1e9, 2),
+                 "reference_formulation_gflop_per_frame": round(flops / fpt / 1e9, 2),
                  "conv_stack_tflops_reference_formulation": round(flops / (conv_ms * 1e-3) / 1e12, 2),
                  "precision_mode": precision, "sequential_call_cnn": sequential,
                  "other_conv_kernels": [roof(k) for k in ranked[1:4]]}
@@ -447,11 +466,17 @@ def main():
             dist.destroy_process_group()
         return
     H, W, B = args.height, args.width, args.batch
-    # Two legs over the same steps, both inside this process (no re-exec): the default mixed mode (bf16x3 MFMA on the layers the
-    # measured table selects) is the headline; the second leg runs EVERY conv in the reference's own arithmetic (fp32 MFMA, exact
-    # fp32 products and sums) and is reported beside it (value_fp32, ms_per_step_fp32, rmse_vs_oracle_fp32, roofline_fp32).
-    main_mode = os.environ.get("VIDC_PRECISION", "mixed")
-    legs = [main_mode] + ([] if (main_mode == "fp32" or args.no_fp32_leg) else ["fp32"])
+    # Two legs over the same steps, both inside this process (no re-exec).  The HEADLINE leg runs every conv in the reference's own
+    # arithmetic (fp32 MFMA: exact fp32 products and sums) -- value, ms_per_step, dtype "f32", rmse_vs_oracle and roofline describe it.
+    # The mixed mode (bf16x3 MFMA on the layers the measured table selects; narrower products, RMSE ~1e-5 against the 1e-3 bar) is
+    # reported beside it as value_mixed / dtype_mixed / roofline_mixed / mixed_leg.
+    if os.environ.get("VIDC_PRECISION") in ("fp32", "mixed"):
+        legs = [os.environ["VIDC_PRECISION"]]                  # an explicit mode: that leg alone
+    else:
+        legs = (["fp32"] if not args.no_fp32_leg else []) + (["mixed"] if not args.no_mixed_leg else [])
+        if not legs:
+            raise SystemExit("bench.py: --no-fp32-leg and --no-mixed-leg leave nothing to run")
+    main_mode = legs[0]
     res = {}
     for mode in legs:
         res[mode] = measure(args, dev, rank, world, mode)      # (both pipelines stay resident: ~6 GB of 288)
@@ -478,10 +503,17 @@ def main():
         masks = plane_masks(hb)
         ref = O.call_cnn(cpu_sn, cpu_dc, hb, masks, intr, 200, rng=np.random.RandomState(77))   # also the warm-up
         for m in legs:
+            # through the mode that was timed: the frame as the first item of a stream (with --frames-per-launch F it rides in the
+            # batch-F program next to a partner frame, which does not enter its result), draws from a generator in the oracle's state
             pipe = res[m]["pipe"]
             os.environ["VIDC_PRECISION"] = m
             pipe.rng = np.random.RandomState(77)
-            got = pipe._call_cnn({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in hb.items()}).cpu()
+            dev_hb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in hb.items()}
+            if args.mode == "interleaved":
+                partner = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in S.synthetic_batch(B, H, W, 1234, frame0=(rank + world) * B).items()}
+                got = list(pipe.run_interleaved(iter([dev_hb, partner]), lanes=args.lanes, frames_per_launch=args.frames_per_launch))[0].cpu()
+            else:
+                got = pipe._call_cnn(dev_hb).cpu()
             recs[m][2], recs[m][3] = float((got - ref).double().pow(2).sum()), float(ref.numel())
         if world == 1:      # the CPU baseline is timed at N=1 only (the other ranks would idle in the gather)
             # batch-1 convs do not scale to every host thread (0.26 frames/s on 128 threads in round 2 against 0.93 on 8 in the survey
@@ -512,9 +544,14 @@ def main():
     for m in legs:
         assert gathered[m].shape[0] == world, "gathered %d records from a world of %d ranks" % (gathered[m].shape[0], world)
     jobs = {m: sharding.combine(gathered[m]) for m in legs}
+    extra_legs = None
+    if rank == 0 and world == 1 and not args.no_extra_legs and not args.source and not args.plane_head and B == 1 and args.mode == "interleaved":
+        torch.cuda.synchronize()
+        extra_legs = run_extra_legs(args)
     if rank == 0:
         job = jobs[main_mode]
         frames, t_max = job["frames"], job["seconds"]
+        F = args.frames_per_launch if args.mode == "interleaved" else 1
         line = {
             "metric": "frames/sec", "value": round(frames / t_max, 3), "unit": "frames/s", "n_gpus": int(gathered[main_mode].shape[0]), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True,
@@ -527,27 +564,73 @@ def main():
                                     "pre-processing (PIL-exact resize to %dx%d, rasterisation) + warp + surface-normal net + plane "
                                     "block/enrichment + depth-completion net" % (args.source, B, "from the Mask R-CNN plane head every frame" if args.plane_head else "fixed", W, H))),
                        "height": H, "width": W, "batch_per_gpu": B, "weights": "seeded random-init (seed 1234)",
-                       "mode": args.mode, "lanes": (args.lanes if args.mode == "interleaved" else 1), "frames_in_flight": (2 * args.lanes if args.mode == "interleaved" else args.in_flight if args.mode == "streams" else 1),
+                       "mode": args.mode, "lanes": (args.lanes if args.mode == "interleaved" else 1), "frames_per_launch": F,
+                       "frames_per_launch_note": ("one step = one batch-%d item (its own gravity, plane block and draws, main.py:261-298); %d consecutive items of "
+                                                  "the stream share every launch of a tick (program recorded for batch %d), an item's result does not depend on "
+                                                  "its partner" % (B, F, F * B)) if F > 1 else None,
+                       "frames_in_flight": (2 * args.lanes * F if args.mode == "interleaved" else args.in_flight if args.mode == "streams" else 1),
                        "sharding": "frames round-robin over %d rank(s), no data-path collective" % world},
             "rmse_vs_oracle": (round(job["rmse"], 8) if job["rmse"] is not None else None),
             "roofline": lead["roofline"], "cpu_baseline": cpu_baseline,
         }
         line.update(lead["extra"])
-        if "fp32" in jobs and main_mode != "fp32":
-            j32, r32 = jobs["fp32"], res["fp32"]
+        for m in legs[1:]:
+            jm, rm = jobs[m], res[m]
             line.update({
-                "value_fp32": round(j32["frames"] / j32["seconds"], 3), "ms_per_step_fp32": round(1e3 * j32["seconds"] / args.steps, 4),
-                "dtype_fp32": "f32", "rmse_vs_oracle_fp32": (round(j32["rmse"], 8) if j32["rmse"] is not None else None),
-                "roofline_fp32": r32["roofline"],
-                "fp32_leg": {"what": "the same %d steps with every conv on v_mfma_f32_32x32x2_f32 (exact fp32 products and sums: the reference's "
-                                     "arithmetic), fresh pipeline in this process" % args.steps,
-                             "program_ms": r32["extra"].get("program_ms"), "conv_ms_per_frame": r32["extra"].get("conv_ms_per_frame"),
-                             "sequential_call_cnn": r32["extra"].get("sequential_call_cnn"),
-                             "conv_stack": r32["extra"].get("conv_stack")}})
+                "value_" + m: round(jm["frames"] / jm["seconds"], 3), "ms_per_step_" + m: round(1e3 * jm["seconds"] / args.steps, 4),
+                "dtype_" + m: ("f32" if m == "fp32" else "f32+bf16x3"), "rmse_vs_oracle_" + m: (round(jm["rmse"], 8) if jm["rmse"] is not None else None),
+                "roofline_" + m: rm["roofline"],
+                m + "_leg": {"what": ("the same %d steps in the mixed mode: the compute-bound convs on 3 x v_mfma_f32_32x32x16_bf16 per fp32-equivalent product "
+                                      "(operands split hi + lo in bf16, fp32 accumulate: narrower products than the reference's fp32), fresh pipeline in this "
+                                      "process" % args.steps) if m == "mixed" else
+                                     ("the same %d steps with every conv on v_mfma_f32_32x32x2_f32 (exact fp32 products and sums), fresh pipeline in this process" % args.steps),
+                             "program_ms": rm["extra"].get("program_ms"), "conv_ms_per_frame": rm["extra"].get("conv_ms_per_frame"),
+                             "first_item_latency_ms": rm["extra"].get("first_item_latency_ms"),
+                             "sequential_call_cnn": rm["extra"].get("sequential_call_cnn"),
+                             "conv_stack": rm["extra"].get("conv_stack")}})
+        if extra_legs is not None:
+            line["extra_legs"] = extra_legs
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_extra_legs(args):
+    """Driver-visible numbers for BASELINE configs[4] and configs[2]: each one is THIS script started as a child process
+    (its own GPU context, its own environment; a crash or a hang there cannot take the headline down) after both main legs have been
+    measured and before the line is printed.  Skipped once the wall clock of this run passes --extra-legs-budget."""
+    import subprocess
+    t_start = _T0
+    out = {}
+    specs = [("configs[4] training step, bf16, batch 8 per GPU, 320x240", {"VIDC_TRAIN_PRECISION": "bf16"},
+              ["--train", "--batch", "8", "--steps", "5", "--warmup", "3"]),
+             ("configs[2] 640x480 stream, batch 8, Mask R-CNN plane head every frame", {},
+              ["--batch", "8", "--source", "640x480", "--height", "240", "--plane-head", "--steps", "20", "--warmup", "4", "--frames-per-launch", "1",
+               "--no-cpu-baseline", "--no-sequential-leg", "--no-extra-legs"])]
+    for name, env_add, flags in specs:
+        if time.perf_counter() - t_start > args.extra_legs_budget:
+            out[name] = {"skipped": "wall-clock budget of the run (%.0f s) used up" % args.extra_legs_budget}
+            continue
+        env = {k: v for k, v in os.environ.items() if k not in ("VIDC_PRECISION", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        env.update(env_add)
+        t1 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1"] + flags, env=env, capture_output=True, text=True, timeout=80)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": "exit code %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+                continue
+            d = json.loads(lines[-1])
+            out[name] = {k: d.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "rmse_vs_oracle", "value_mixed", "ms_per_step_mixed",
+                                                       "dtype_mixed", "losses", "config")
+                         if d.get(k) is not None}
+            out[name]["roofline"] = {k: (d.get("roofline") or {}).get(k) for k in ("bound", "achieved", "peak", "unit", "frac")}
+            out[name]["command"] = "bench.py --gpus 1 " + " ".join(flags) + ("  [" + " ".join("%s=%s" % kv for kv in env_add.items()) + "]" if env_add else "")
+            out[name]["child_wall_s"] = round(time.perf_counter() - t1, 1)
+        except Exception as e:      # noqa: BLE001  (timeout, unparsable output: recorded, never raised)
+            out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
+    return out
 
 
 if __name__ == "__main__":

@@ -42,11 +42,12 @@ def test_bench_single_rank_needs_no_group():
 
 
 def test_bench_refuses_more_ranks_than_gpus():
-    """--gpus 2 on a node with fewer than 2 GPUs fails in the launcher (before any rank starts) unless the backend is gloo."""
+    """--gpus 2 on a node with fewer than 2 GPUs: every rank refuses (the launching process itself makes no HIP call, so it does not
+    count devices) and the job exits non-zero, unless the backend is gloo."""
     if torch.cuda.device_count() >= 2:
         pytest.skip("needs a node with fewer than 2 GPUs")
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1"], env=_env(VIDC_DIST_BACKEND="nccl"), capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "needs 2 GPUs" in r.stderr
+    assert r.returncode != 0 and ("one rank per GPU" in r.stderr or "no GPU visible" in r.stderr), r.stderr[-2000:]
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():

@@ -196,11 +196,17 @@ def test_frame_output_does_not_depend_on_the_shard(seeded_weights):
                 p.rng = np.random.RandomState(1000 + f)      # the draws of frame f happen in the tick that pulled it
                 yield frames[f]
         inter = dict(zip(ids, (o.cpu() for o in p.run_interleaved(feed()))))
-        return seq, inter
+        # the mode bench.py times: two lanes, two consecutive frames of the shard per launch (rank 0 of 1 pairs (0,1) (2,3); rank 1 of 2
+        # pairs (1,3): frame 1 changes batch slot and partner, frame 3 its partner)
+        paired = dict(zip(ids, (o.cpu() for o in p.run_interleaved(iter([frames[f] for f in ids]), lanes=2, frames_per_launch=2,
+                                                                   frame_rng=lambda i: np.random.RandomState(1000 + ids[i])))))
+        return seq, inter, paired
 
-    seq_a, int_a = run_shard(0, 1, 4)
-    seq_b, int_b = run_shard(1, 2, 4)
+    seq_a, int_a, pair_a = run_shard(0, 1, 4)
+    seq_b, int_b, pair_b = run_shard(1, 2, 4)
     for f in (1, 3):
         assert torch.equal(seq_a[f], seq_b[f]), "frame %d differs between shards (sequential path)" % f
         assert torch.equal(int_a[f], int_b[f]), "frame %d differs between shards (interleaved path)" % f
-    assert not torch.equal(seq_a[1], seq_a[3])
+        assert torch.equal(pair_a[f], pair_b[f]), "frame %d differs between shards (two frames per launch)" % f
+        assert float((pair_a[f] - seq_a[f]).pow(2).mean().sqrt()) < 1e-3
+    assert not torch.equal(seq_a[1], seq_a[3]) and not torch.equal(pair_a[1], pair_a[3])

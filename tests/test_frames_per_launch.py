@@ -1,0 +1,199 @@
+"""`run_interleaved(frames_per_launch=F)`: F consecutive items of a frame stream share every launch of a pipeline tick (the lane's
+frame program is recorded for batch F x B) -- the mode bench.py times with F = 2.
+
+What has to hold, and is asserted here on the GPU:
+  * every item keeps `_call_cnn` semantics (main.py:261-298): own gravity / plane block / enrichment, draws off the shared generator
+    in the order hypotheses(0), enrichment(0), hypotheses(1), ... of back-to-back `_call_cnn` calls (generator state compared);
+  * an item's depth map is bit-identical whatever partner it had, whichever batch slot it took, however many lanes ran, and whether
+    the stream ended on a full group or not (the tail runs through the SAME batch-F program with stale partners);
+  * shard independence: rank r of N pairs other frames together than rank 0 of 1 does -- same bits per frame;
+  * against the REFERENCE's golden depth maps: the bars of test_hip_parity.py::test_full_path_vs_golden (mixed 1e-3, fp32 2e-5).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from vi_depth_completion_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda"
+
+_PIPES = {}
+
+
+def _pipe(seeded_weights, mode):
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    if mode not in _PIPES:
+        p = DepthCompletionPipeline(enriched_samples=200)
+        p.load_state_dicts(seeded_weights["sn"], seeded_weights["dc"])
+        p.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(240, 320))
+        _PIPES[mode] = p
+    return _PIPES[mode]
+
+
+@pytest.fixture(params=["mixed", "fp32"])
+def pipe_mode(request, seeded_weights, monkeypatch):
+    monkeypatch.setenv("VIDC_PRECISION", request.param)      # engine.Program reads the mode when a program is recorded
+    return _pipe(seeded_weights, request.param), request.param
+
+
+def _frames(frame0, n, B=1):
+    return [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in S.synthetic_batch(B, 240, 320, 1234, frame0=frame0 + i * B).items()} for i in range(n)]
+
+
+def test_item_bits_do_not_depend_on_partner_slot_lanes_or_tail(pipe_mode):
+    pipe, mode = pipe_mode
+    frames = _frames(300, 7)
+    rng_of = lambda f: np.random.RandomState(9000 + f)      # noqa: E731  (frame f's own generator, whatever stream it is part of)
+
+    def run(first, last, lanes, F):
+        return [o.cpu() for o in pipe.run_interleaved(iter(frames[first:last]), lanes=lanes, frames_per_launch=F,
+                                                      frame_rng=lambda i: rng_of(first + i))]
+
+    ref = run(0, 7, 1, 2)                                   # groups (0,1) (2,3) (4,5) (6,-): the tail item has no partner
+    assert len(ref) == 7 and all(tuple(o.shape) == (1, 1, 240, 320) for o in ref)
+    assert not torch.equal(ref[0], ref[1])
+    for lanes in (2, 3):
+        got = run(0, 7, lanes, 2)
+        for f, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a, b), "frame %d differs with %d lanes (%s)" % (f, lanes, mode)
+    # the stream shifted by one item: every frame changes slot and partner, the old tail frame gets a partner
+    for lanes in (1, 2):
+        got = run(1, 7, lanes, 2)
+        for f, b in zip(range(1, 7), got):
+            assert torch.equal(ref[f], b), "frame %d differs when paired with another frame (%d lanes, %s)" % (f, lanes, mode)
+    # streams shorter than a group / than the number of lanes
+    assert torch.equal(run(3, 4, 2, 2)[0], ref[3])
+    short = run(0, 3, 3, 2)
+    assert len(short) == 3 and all(torch.equal(a, b) for a, b in zip(short, ref))
+    # against back-to-back _call_cnn with the same per-frame generators: other programs (batch 1, 1- and 3-group launches), same function
+    bar = 2e-5 if mode == "fp32" else 1e-3
+    saved = pipe.rng
+    try:
+        for f in (0, 3, 6):
+            pipe.rng = rng_of(f)
+            seq = pipe._call_cnn(frames[f]).cpu()
+            rmse = float((seq - ref[f]).pow(2).mean().sqrt())
+            assert rmse < bar, (mode, f, rmse)
+    finally:
+        pipe.rng = saved
+
+
+def test_three_items_per_launch_and_batched_items(seeded_weights, monkeypatch):
+    """F = 3 (a program of batch 3) and items that are batches themselves (B = 2, F = 2: a program of batch 4): same properties."""
+    monkeypatch.setenv("VIDC_PRECISION", "mixed")
+    pipe = _pipe(seeded_weights, "mixed")
+    frames = _frames(340, 5)
+    rng_of = lambda f: np.random.RandomState(700 + f)       # noqa: E731
+    a = [o.cpu() for o in pipe.run_interleaved(iter(frames), lanes=2, frames_per_launch=3, frame_rng=rng_of)]
+    b = [o.cpu() for o in pipe.run_interleaved(iter(frames[2:]), lanes=1, frames_per_launch=3, frame_rng=lambda i: rng_of(i + 2))]
+    assert len(a) == 5 and len(b) == 3
+    for f in range(2, 5):
+        assert torch.equal(a[f], b[f - 2]), f
+    items = _frames(360, 3, B=2)
+    c = [o.cpu() for o in pipe.run_interleaved(iter(items), lanes=2, frames_per_launch=2, frame_rng=rng_of)]
+    d = [o.cpu() for o in pipe.run_interleaved(iter(items[1:]), lanes=1, frames_per_launch=2, frame_rng=lambda i: rng_of(i + 1))]
+    assert len(c) == 3 and all(tuple(o.shape) == (2, 1, 240, 320) for o in c)
+    assert torch.equal(c[1], d[0]) and torch.equal(c[2], d[1])
+    saved = pipe.rng
+    try:
+        pipe.rng = rng_of(1)
+        seq = pipe._call_cnn(items[1]).cpu()
+    finally:
+        pipe.rng = saved
+    assert float((seq - c[1]).pow(2).mean().sqrt()) < 1e-3
+
+
+def _golden_batch(f, name):
+    img = torch.from_numpy(f["image_u8"]).permute(2, 0, 1).float().div(255) if name.startswith("demo_") else S.synthetic_batch(1, 240, 320, 1234)["image"][0]
+    sd = torch.zeros(240, 320)
+    rc = torch.from_numpy(f["sparse_rc"]).long()
+    sd[rc[:, 0], rc[:, 1]] = torch.from_numpy(f["sparse_val"])
+    return {"image": img[None], "sparse_depth": sd[None, None], "gravity": torch.from_numpy(f["gravity"])[None],
+            "aligned_direction": torch.from_numpy(f["aligned"])[None],
+            "homogeneous_coordinates": S.homogeneous_grid(S.DEMO_FC, S.DEMO_CC, 320, 240)[None]}
+
+
+def _golden_names(golden_dir):
+    return sorted(n[:-4] for n in os.listdir(golden_dir) if (n.startswith("demo_0") or n == "synthetic_f0.npz") and n.endswith(".npz"))
+
+
+def test_paired_stream_vs_the_reference_golden_depth(pipe_mode, golden_dir):
+    """Every golden frame (real images, real VI-SLAM points; host-resident batches like the reference's DataLoader hands out) through
+    the paired two-lane stream, each frame drawing from the generator state of its golden run: depth RMSE against the REFERENCE's
+    output below the `_call_cnn` bars -- mixed 1e-3 (north_star), fp32 2e-5."""
+    pipe, mode = pipe_mode
+    names = _golden_names(golden_dir)
+    fs = [np.load(os.path.join(golden_dir, n + ".npz")) for n in names]
+    frames = [_golden_batch(f, n) for f, n in zip(fs, names)]
+    outs = [o.cpu() for o in pipe.run_interleaved(iter(frames), lanes=2, frames_per_launch=2, frame_rng=lambda i: np.random.RandomState(int(fs[i]["np_seed"])))]
+    assert len(outs) == len(names) >= 5
+    for n, f, o in zip(names, fs, outs):
+        rmse = float(np.sqrt(np.mean((o[0, 0].numpy() - f["depth"]) ** 2)))
+        assert rmse < (2e-5 if mode == "fp32" else 1e-3), (mode, n, rmse)
+        assert float(o.min()) >= 0.0
+
+
+def test_draws_come_off_the_shared_generator_in_call_cnn_order(seeded_weights, golden_dir, monkeypatch):
+    """ONE generator for the whole stream (the reference's np.random): after the paired stream it is in exactly the state back-to-back
+    `_call_cnn` calls leave it in, and the enrichment actually drew (demo frames: planes are found, candidates exist).  The order
+    hypotheses(i), enrichment(i), hypotheses(i+1) is the only one that reproduces that state: enrichment(i) consumes a data-dependent
+    number of words (rejection sampling in randint, main.py:292)."""
+    monkeypatch.setenv("VIDC_PRECISION", "fp32")
+    pipe = _pipe(seeded_weights, "fp32")
+    names = [n for n in _golden_names(golden_dir) if n.startswith("demo_") and not n.endswith("dense")][:3]
+    fs = [np.load(os.path.join(golden_dir, n + ".npz")) for n in names]
+    frames = [_golden_batch(f, n) for f, n in zip(fs, names)] * 2 + [_golden_batch(fs[0], names[0])]        # 7 items: odd tail
+    saved, es = pipe.rng, pipe.args.enriched_samples
+    try:
+        pipe.rng = np.random.RandomState(4242)
+        seq = [pipe._call_cnn(b).cpu() for b in frames]
+        state_seq = pipe.rng.get_state()
+        states = {}
+        for lanes, F in ((1, 2), (2, 2), (2, 3), (2, 1)):
+            pipe.rng = np.random.RandomState(4242)
+            outs = [o.cpu() for o in pipe.run_interleaved(iter(frames), lanes=lanes, frames_per_launch=F)]
+            st = pipe.rng.get_state()
+            assert st[2] == state_seq[2] and np.array_equal(st[1], state_seq[1]), "generator state after the stream differs (lanes %d, F %d)" % (lanes, F)
+            for f, (a, b) in enumerate(zip(seq, outs)):
+                assert float((a - b).pow(2).mean().sqrt()) < 2e-5, (lanes, F, f)
+            states[(lanes, F)] = outs
+        for f, (a, b) in enumerate(zip(states[(1, 2)], states[(2, 2)])):
+            assert torch.equal(a, b), f
+        pipe.args.enriched_samples = 0
+        plain = [o.cpu() for o in pipe.run_interleaved(iter(frames[:2]), lanes=2, frames_per_launch=2)]
+        assert not torch.equal(plain[0], states[(2, 2)][0]), "enrichment had no effect on the demo frame: the test would not exercise it"
+    finally:
+        pipe.rng, pipe.args.enriched_samples = saved, es
+
+
+def test_recycled_input_buffers_and_unowned_outputs(seeded_weights, monkeypatch):
+    """The caller may overwrite its input tensors as soon as the generator hands control back (the lanes keep what they read later:
+    sparse depth, homogeneous grid), and copy_outputs=False hands out views that stay valid until the next item is requested."""
+    monkeypatch.setenv("VIDC_PRECISION", "mixed")
+    pipe = _pipe(seeded_weights, "mixed")
+    frames = _frames(380, 6)
+    rng_of = lambda f: np.random.RandomState(50 + f)        # noqa: E731
+    ref = [o.cpu() for o in pipe.run_interleaved(iter(frames), lanes=2, frames_per_launch=2, frame_rng=rng_of)]
+    reuse = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in frames[0].items()}
+
+    def recycled():
+        for fr in frames:
+            for k, v in fr.items():
+                if torch.is_tensor(v):
+                    reuse[k].copy_(v)
+            yield reuse
+    got = []
+    for o in pipe.run_interleaved(recycled(), lanes=2, frames_per_launch=2, frame_rng=rng_of, copy_outputs=False):
+        got.append(o.cpu())                                  # consumed before the next item is requested
+    assert len(got) == 6
+    for f, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), f
+    other = _frames(390, 1, B=2)[0]
+    with pytest.raises(ValueError, match="same shape"):
+        list(pipe.run_interleaved(iter([frames[0], other]), lanes=2, frames_per_launch=2))
+    with pytest.raises(ValueError, match="frames_per_launch"):
+        list(pipe.run_interleaved(iter(frames[:1]), frames_per_launch=0))

@@ -159,28 +159,39 @@ class DepthCompletionPipeline:
             m.load_state_dict(state)
 
     # ---- plane masks ---------------------------------------------------------------------------------------------------
-    def _masks_begin(self, rgb):
+    def _masks_begin(self, rgb, key=None):
         """Starts the plane-instance maps of a batch.  A device-side extractor (plane_mask.PlaneMaskDetector: `run_on_batch`) is
         enqueued on the current stream together with ONE asynchronous device->host copy of the (B,H,W) uint8 ids; anything else is
-        the reference's per-sample `run_on_tensor` call (main.py:273), resolved in `_masks_end`."""
+        the reference's per-sample `run_on_tensor` call (main.py:273), resolved in `_masks_end`.
+        `key`: names the pinned host buffer the ids land in (one per lane and batch slot in the stream modes, where the next
+        extraction is enqueued before the host has read this one).  Extractions on different streams are ordered one after the other
+        on the device: the detector owns ONE set of buffers and one captured graph."""
         ex = self.plane_masks_extraction
         if not hasattr(ex, "run_on_batch"):
             return None
         # (on the current stream: running the detector on a side stream next to the networks measured 224 vs 235 frames/s in round 1 and,
         #  with two lanes and the deferred enrichment wait of round 2, 272 vs 302 at batch 1 and 444 vs 568 at batch 8)
+        prev = getattr(self, "_masks_done", None)
+        if prev is not None:
+            torch.cuda.current_stream().wait_event(prev)
         ids = ex.run_on_batch(rgb)
-        if getattr(self, "_ids_host", None) is None or self._ids_host.shape != ids.shape:
-            self._ids_host = torch.empty(ids.shape, dtype=torch.uint8, pin_memory=True)
-        self._ids_host.copy_(ids, non_blocking=True)
+        hosts = self.__dict__.setdefault("_ids_hosts", {})
+        host = hosts.get(key)
+        if host is None or host.shape != ids.shape:
+            host = hosts[key] = torch.empty(ids.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(ids, non_blocking=True)
+        self._ids_host = host
         ev = torch.cuda.Event()
         ev.record()
-        return ev
+        self._masks_done = ev
+        return ev, host
 
     def _masks_end(self, handle, images, H, W):
         if handle is None:
             return [np.asarray(self.plane_masks_extraction.run_on_tensor(images[i])).reshape(H, W) for i in range(images.shape[0])]
-        handle.synchronize()
-        return [m.copy() for m in self._ids_host.numpy()]
+        ev, host = handle
+        ev.synchronize()
+        return [m.copy() for m in host.numpy()]
 
     # ---- the hot path ------------------------------------------------------------------------------------------------
     def _stage1(self, input_batch, slot=0, planes=None, rng=None):
@@ -236,13 +247,15 @@ class DepthCompletionPipeline:
     # ---- software-pipelined throughput mode ------------------------------------------------------------------------
     def frame_program(self, B, H, W):
         key = (B, H, W, self.surface_normal_cnn._version, self.cnn._version, self.surface_normal_cnn.warp_2dof_alignment.align_corners)
-        if getattr(self, "_frame_prog_key", None) != key:
-            self._frame_prog = build_frame_program(self.surface_normal_cnn, self.cnn, B, H, W, self.device)
-            self._frame_prog_key = key
-        return self._frame_prog
+        progs = self.__dict__.setdefault("_frame_progs", {})
+        if key not in progs:
+            for k in [k for k in progs if k[3:] != key[3:]]:      # programs of parameters / a warp convention that are gone
+                del progs[k]
+            progs[key] = build_frame_program(self.surface_normal_cnn, self.cnn, B, H, W, self.device)
+        return progs[key]
 
     @torch.no_grad()
-    def run_interleaved(self, batches, copy_outputs=True, lanes=None):
+    def run_interleaved(self, batches, copy_outputs=True, lanes=None, frames_per_launch=None, frame_rng=None):
         """Throughput mode, software-pipelined over frames: tick t runs the surface-normal network + plane block of frame
         t and the depth-completion network of frame t-1 as ONE program (build_frame_program).  Yields the depth map of
         every batch, in order; n batches take n+1 ticks.  Per frame the arithmetic is that of `_call_cnn` (same kernels;
@@ -265,7 +278,16 @@ class DepthCompletionPipeline:
         device-resident `sparse_depth` is copied once: its enrichment is finished one visit later, when the caller may have refilled
         the buffer).
         copy_outputs=False hands out the program's own output buffer: valid ONLY until the next item is requested, for every L (the
-        yielding lane's next visit relaunches its depth decoder into that buffer)."""
+        yielding lane's next visit relaunches its depth decoder into that buffer).
+
+        frames_per_launch = F > 1 (default: VIDC_FRAMES_PER_LAUNCH, else 1): F consecutive items of the stream share every launch of a
+        tick (`_run_grouped`): the lane's frame program is recorded for batch F x B and items F*p .. F*p+F-1 occupy its batch slots, so
+        a batch-1 stream runs its ResNet-101 layer-3 convolutions at M = 640 instead of 320 -- half the launches per frame, each above
+        the per-launch floor that bounds them at batch 1.  The items stay what the API hands in (main.py:261-298 semantics
+        per item: own gravity, own plane block, own draws in `_call_cnn` order); a stream whose length is not a multiple of F runs its
+        tail through the SAME program with the unused slots holding stale frames, so an item's bits do not depend on whether it had
+        a partner, on which slot it took, or on the shard it was part of (rows of an implicit GEMM do not interact; tile, split-K and K
+        order are the launch's).  frame_rng(i) -> generator: item i draws from its own generator instead of `self.rng`."""
         import os
         if not self.use_gravity:
             yield from self._run_interleaved_two_programs(batches, copy_outputs)
@@ -273,6 +295,12 @@ class DepthCompletionPipeline:
         n = int(lanes if lanes is not None else os.environ.get("VIDC_LANES", "1"))
         if n < 1:
             raise ValueError("run_interleaved: lanes must be >= 1")
+        fpl = int(frames_per_launch if frames_per_launch is not None else os.environ.get("VIDC_FRAMES_PER_LAUNCH", "1"))
+        if fpl < 1:
+            raise ValueError("run_interleaved: frames_per_launch must be >= 1")
+        if fpl > 1 or frame_rng is not None or os.environ.get("VIDC_GROUPED_SCHEDULER", "0") == "1":
+            yield from self._run_grouped(batches, copy_outputs, n, fpl, frame_rng)
+            return
         lane_objs = [_Lane(self, k, own_stream=n > 1) for k in range(n)]
         k = 0
         if n == 1:                              # on the caller's stream; an output is handed out by the tick that computed it
@@ -352,6 +380,77 @@ class DepthCompletionPipeline:
             if out is not None:
                 yield out
 
+    def _run_grouped(self, batches, copy_outputs, n_lanes, F, frame_rng):
+        """run_interleaved with F items per launch (see there).  Group p = items F*p .. F*p+F-1 runs on lane p mod L.  Per lane and group
+        the device work is: segment 0 [surface-normal side of group p + depth pyramids of the lane's previous group], the plane kernels
+        of every item, segment 1 [depth decoder of the previous group], the enrichment scatters.  The host side is two interleaved
+        sequences from this one thread:
+          * the DRAW sequence, strictly in item order -- hypotheses(i), [wait for item i's candidate counts], enrichment(i),
+            hypotheses(i+1), ... -- which is the order back-to-back `_call_cnn` calls consume the generator in;
+          * the LAUNCH sequence, which runs ahead of it: segment 0 of group p+L is launched as soon as group p is enriched (it needs
+            nothing else), i.e. before the draw sequence turns to group p+1 on the next lane -- so whenever the host waits for an item's
+            counts, the other lane has a whole segment 0 queued.  Segment 1 of a visit is launched after the first item's plane
+            kernels and before the wait for their counts, so the lane itself stays busy under the wait as well."""
+        lanes = [_GroupLane(self, k, F) for k in range(n_lanes)]
+        it = iter(batches)
+        state = {"taken": 0}
+
+        def start(lane):
+            """Pulls up to F items, each one copied into its batch slot before the next is requested (a caller that refills ONE set of
+            input tensors sees them consumed item by item), and launches segment 0 for them.  Returns the items' stream indices."""
+            idx = []
+            for j in range(F):
+                b = next(it, None)
+                if b is None:
+                    break
+                lane.put(j, b)
+                idx.append(state["taken"])
+                state["taken"] += 1
+            if idx:
+                lane.begin(len(idx))
+            return idx
+
+        groups = {}                              # group index -> stream indices of its items; filled as segment 0 of the group is launched
+        for p in range(n_lanes):
+            idx = start(lanes[p])
+            if not idx:
+                break
+            groups[p] = idx
+        ready, nxt, p = {}, 0, 0                 # group index -> (outputs, event, n items)
+
+        def flush():
+            nonlocal nxt
+            while nxt in ready:
+                out, ev, n = ready.pop(nxt)
+                nxt += 1
+                torch.cuda.current_stream().wait_event(ev)        # device-side: readers on the caller's stream find the items complete
+                B = out.shape[0] // F
+                for j in range(n):
+                    yield out[j * B:(j + 1) * B]
+
+        while p in groups:
+            lane = lanes[p % n_lanes]
+            items = groups.pop(p)
+            lane.stream.wait_stream(torch.cuda.current_stream())     # whoever read the lane's previous output did so on the caller's stream
+            for j, i in enumerate(items):
+                rng = frame_rng(i) if frame_rng is not None else self.rng
+                lane.hypotheses(j, rng)
+                if j == 0 and lane.have_prev:
+                    ready[p - n_lanes] = lane.decoder(copy_outputs)
+                lane.enrich(j, rng)
+            lane.have_prev, lane.prev_n = True, len(items)
+            nxt_items = start(lane)              # segment 0 of the lane's next group first (it does not touch the depth output), then
+            if nxt_items:                        # the finished items go to the caller
+                groups[p + n_lanes] = nxt_items
+                yield from flush()
+            else:                                # the lane's last group: the depth pyramids + decoder of it and nothing new -- into the
+                yield from flush()               # output buffer, so only after the caller has been handed what is in there
+                lane.stream.wait_stream(torch.cuda.current_stream())
+                ready[p] = lane.drain(copy_outputs)
+            p += 1
+        yield from flush()
+        assert not ready and not groups
+
     def _run_interleaved_two_programs(self, batches, copy_outputs):
         """run_interleaved for `use_gravity=False` (main.py:244-245, 270-271: SurfaceNormalDORN, no warp).  The DORN backbone shares no
         layer shapes with the depth network's pyramids, so there is no joint 4-group program; the two networks of consecutive frames
@@ -369,7 +468,9 @@ class DepthCompletionPipeline:
 
         def finish(st):
             """enrichment + depth network of a frame on stream B; returns its output (the caller's stream waits for it)."""
-            sb.wait_stream(sa)                                    # (normals + plane kernels of this frame; also orders B behind A's copies)
+            sb.wait_event(st["done_a"])                           # normals + plane kernels + copies of THIS frame (not the next frame's
+            #                                                       normals network, which stream A has already been given: that one runs beside
+            #                                                       this depth network)
             with torch.cuda.stream(sb):
                 depth_in = st["ds"]
                 if st["di"] is not None:
@@ -396,6 +497,8 @@ class DepthCompletionPipeline:
                     masks = self._masks_end(mh, batch["image"], ds.shape[-2], ds.shape[-1])
                     st["di"], st["nnz"] = st["planes"].plane_depth(normals, masks, ds, homo, rng=self.rng)
                     st["info_host"] = st["planes"].read_info_async(st["nnz"])
+            st["done_a"] = torch.cuda.Event()
+            st["done_a"].record(sa)
             prev, t = st, t + 1
             if out is not None:
                 yield out
@@ -512,7 +615,7 @@ class _Lane:
             prog = self.prog
             if self.have_prev:
                 self.dc_image.copy_(self.sn_image, non_blocking=True)
-            mh = pipe._masks_begin(rgb) if pipe.args.enriched_samples != 0 else None
+            mh = pipe._masks_begin(rgb, key=("lane", self.index)) if pipe.args.enriched_samples != 0 else None
             self.sn_image.copy_(rgb, non_blocking=True)
             self.grav.copy_(self._stage("gravity", batch["gravity"], dev).reshape(-1), non_blocking=True)
             self.algn.copy_(self._stage("aligned_direction", batch["aligned_direction"], dev).reshape(-1), non_blocking=True)
@@ -648,3 +751,170 @@ class _Lane:
             out = out.clone() if copy_outputs else out
         self.have_prev = batch is not None
         return out
+
+
+class _GroupLane:
+    """One lane of `DepthCompletionPipeline._run_grouped`: a frame program recorded for batch F x B whose batch slots hold F consecutive
+    items of the stream, a plane block per slot (an item's plane buffers live from its hypothesis draws to its enrichment, which for the
+    last slot of a group is after the next lane's visit has begun), its own HIP stream, and the group whose depth network is pending."""
+
+    def __init__(self, pipe, index, F):
+        self.pipe, self.index, self.F = pipe, index, F
+        ent = pipe.__dict__.setdefault("_group_lane_cache", {}).setdefault((index, F), {})
+        if "stream" not in ent:
+            ent["stream"] = torch.cuda.Stream(device=pipe.device)
+            ent["planes"] = [PlaneBlock() for _ in range(F)]
+            ent["stagers"] = [_Stager() for _ in range(F)]
+        self.cache, self.stream, self.planes, self.stagers = ent, ent["stream"], ent["planes"], ent["stagers"]
+        self.prog, self.shape0, self.have_prev, self.prev_n = None, None, False, 0
+        self.cur = [None] * F                     # per slot: the item whose plane block / enrichment is still to come
+        self.pending = [None] * F
+
+    # ---- program ---------------------------------------------------------------------------------------------------------------
+    def _prepare(self, rgb):
+        import os
+        pipe = self.pipe
+        B, _, H, W = rgb.shape
+        if self.prog is not None:
+            if (B, H, W) != self.shape0:
+                raise ValueError("run_interleaved: all batches of a stream must have the same shape (got %s after %s); "
+                                 "start a new stream for the remainder" % ((B, H, W), self.shape0))
+            return
+        self.shape0 = (B, H, W)
+        FB = self.F * B
+        key = (FB, H, W, pipe.surface_normal_cnn._version, pipe.cnn._version, pipe.surface_normal_cnn.warp_2dof_alignment.align_corners)
+        if self.cache.get("prog_key") != key:
+            # (lane 0 runs the pipeline's own cached program of that batch: `frame_program(F * B, H, W)` is what tools and bench.py inspect)
+            self.cache["prog"] = pipe.frame_program(FB, H, W) if self.index == 0 else build_frame_program(pipe.surface_normal_cnn, pipe.cnn, FB, H, W, pipe.device)
+            self.cache["prog_key"] = key
+            self.cache["ds"] = torch.zeros((FB, 1, H, W), dtype=torch.float32, device=pipe.device)
+            self.cache["homo"] = [None] * self.F
+        prog = self.prog = self.cache["prog"]
+        pipe.surface_normal_cnn._check(rgb)
+        pipe.cnn._check(rgb)
+        if not prog.captured and os.environ.get("VIDC_EXEC", "graph") == "graph":
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                prog.run()            # warm-up outside capture (sets kernel attributes)
+                prog.check_chains()
+                prog.capture_segments()
+                for vname in ("head", "tail"):
+                    if prog.has_variant(vname):
+                        prog.capture_variant(vname)
+            torch.cuda.current_stream().wait_stream(side)
+        self.sn_image, self.dc_image = prog.tensor(prog.inputs["sn_image"]), prog.tensor(prog.inputs["dc_image"])
+        self.dc_depth = prog.tensor(prog.inputs["dc_depth"])
+        self.normals = prog.tensor(prog.outputs["normals"])
+        self.grav = prog.storage[prog.inputs["gravity"].buf][: FB * 3]
+        self.algn = prog.storage[prog.inputs["aligned"].buf][: FB * 3]
+        self.ds_own = self.cache["ds"]
+
+    def _homo(self, j, batch):
+        """The item's homogeneous coordinates on the device, safe to read after the caller got control back: a host tensor goes through
+        the slot's staging ring; a device tensor of the caller is copied once and again only when it was written to since (its
+        data pointer / version counter: a camera's grid does not change between frames)."""
+        t = batch["homogeneous_coordinates"]
+        if not t.is_cuda:
+            return self.stagers[j]("homogeneous_coordinates", t, self.pipe.device)
+        ent = self.cache["homo"][j]
+        key = (t.data_ptr(), t._version, tuple(t.shape))
+        if ent is None or ent[0] != key:
+            ent = (key, t.clone(), t)             # (the source stays referenced: its address cannot be handed to another tensor meanwhile)
+            self.cache["homo"][j] = ent
+        return ent[1]
+
+    # ---- launch sequence -------------------------------------------------------------------------------------------------------------
+    def put(self, j, batch):
+        """One item into batch slot j of the lane's program (everything the lane reads later is copied or staged here: the caller may
+        refill its tensors as soon as this returns)."""
+        pipe, dev = self.pipe, self.pipe.device
+        self.stream.wait_stream(torch.cuda.current_stream())          # the item comes from the caller's stream
+        with torch.cuda.stream(self.stream):
+            rgb = self.stagers[j]("image", batch["image"], dev)
+            if j == 0:
+                self._prepare(rgb)
+                if self.have_prev:                # the previous group's images are still in the surface-normal input; its normals and its
+                    self.dc_image.copy_(self.sn_image, non_blocking=True)     # enriched depths were written in place
+            B = self.shape0[0]
+            if tuple(rgb.shape) != (B, 3) + self.shape0[1:]:
+                raise ValueError("run_interleaved: all batches of a stream must have the same shape (got %s after %s); "
+                                 "start a new stream for the remainder" % ((rgb.shape[0],) + tuple(rgb.shape[2:]), self.shape0))
+            sl = slice(j * B, (j + 1) * B)
+            mh = pipe._masks_begin(rgb, key=(self.index, j)) if pipe.args.enriched_samples != 0 else None
+            self.sn_image[sl].copy_(rgb, non_blocking=True)
+            self.grav[3 * j * B: 3 * (j + 1) * B].copy_(self.stagers[j]("gravity", batch["gravity"], dev).reshape(-1), non_blocking=True)
+            self.algn[3 * j * B: 3 * (j + 1) * B].copy_(self.stagers[j]("aligned_direction", batch["aligned_direction"], dev).reshape(-1), non_blocking=True)
+            ds = self.ds_own[sl]                  # own copy: the enrichment reads it after the caller may have refilled its buffer
+            ds.copy_(self.stagers[j]("sparse_depth", batch["sparse_depth"], dev), non_blocking=True)
+            homo = self._homo(j, batch) if pipe.args.enriched_samples != 0 else None
+            # (host-resident images stay referenced for a `run_on_tensor` extractor, which is called with the item's own image later)
+            self.cur[j] = (batch["image"], ds, homo, mh)
+            taken = torch.cuda.Event()
+            taken.record()
+        torch.cuda.current_stream().wait_event(taken)     # the caller's later writes to its tensors are ordered behind the lane's reads
+
+    def begin(self, n):
+        """Segment 0 for the n items just put: all four pyramids + the surface-normal decoder (the surface-normal side alone when the
+        lane has no previous group).  Draws nothing, waits for nothing."""
+        for j in range(n, self.F):
+            self.cur[j] = None
+        with torch.cuda.stream(self.stream):
+            prog = self.prog
+            if not self.have_prev and prog.has_variant("head"):
+                prog.launch_variant("head") if prog.captured else prog.run_variant("head")
+            else:
+                prog.launch_segment(0) if prog.captured else prog.run_segment(0)
+
+    def decoder(self, copy_outputs):
+        """Segment 1: the depth decoder of the lane's previous group (its pyramids ran in the segment 0 just before).  Returns
+        (outputs of the F slots, event, number of items in that group)."""
+        with torch.cuda.stream(self.stream):
+            prog = self.prog
+            prog.launch_segment(1) if prog.captured else prog.run_segment(1)
+            out = prog.tensor(prog.outputs["depth"])
+            out = out.clone() if copy_outputs else out
+            ev = torch.cuda.Event()
+            ev.record()
+        return out, ev, self.prev_n
+
+    def drain(self, copy_outputs):
+        """After the lane's last group: its three depth pyramids (the "tail" variant of segment 0) and its decoder."""
+        with torch.cuda.stream(self.stream):
+            prog = self.prog
+            self.dc_image.copy_(self.sn_image, non_blocking=True)
+            if prog.has_variant("tail"):
+                prog.launch_variant("tail") if prog.captured else prog.run_variant("tail")
+            else:
+                prog.launch_segment(0) if prog.captured else prog.run_segment(0)
+        out = self.decoder(copy_outputs)
+        self.have_prev = False
+        return out
+
+    # ---- draw sequence ---------------------------------------------------------------------------------------------------------------
+    def hypotheses(self, j, rng):
+        """main.py:272-283 for slot j: hypothesis draws, the plane kernels, the asynchronous read of the candidate counts."""
+        pipe = self.pipe
+        image, ds, homo, mh = self.cur[j]
+        B, H, W = self.shape0
+        sl = slice(j * B, (j + 1) * B)
+        with torch.cuda.stream(self.stream):
+            if pipe.args.enriched_samples != 0:
+                masks = pipe._masks_end(mh, image, H, W)
+                di, info = self.planes[j].plane_depth(self.normals[sl], masks, ds, homo, rng=rng)
+                self.pending[j] = (ds, di, info, self.planes[j].read_info_async(info))
+            else:
+                self.dc_depth[sl].copy_(ds, non_blocking=True)
+                self.pending[j] = None
+        self.cur[j] = None
+
+    def enrich(self, j, rng):
+        """main.py:285-294 for slot j: waits for the counts, draws the samples, writes the enriched depth where the lane's next
+        segment 0 reads it."""
+        if self.pending[j] is None:
+            return
+        ds, di, info, info_host = self.pending[j]
+        self.pending[j] = None
+        B = self.shape0[0]
+        with torch.cuda.stream(self.stream):
+            self.planes[j].enrich(ds, di, info, self.pipe.args.enriched_samples, rng=rng, info_host=info_host, out=self.dc_depth[j * B:(j + 1) * B])
