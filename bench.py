@@ -56,8 +56,9 @@ def parse():
                          "+ depth-completion net of frame t-1 as one 4-group program); streams: --in-flight frames on separate HIP "
                          "streams; sequential: back-to-back _call_cnn")
     ap.add_argument("--in-flight", type=int, default=2, help="frames executing concurrently in --mode streams")
-    ap.add_argument("--lanes", type=int, default=2, help="--mode interleaved: software-pipelined frame streams on this many HIP streams, frame i on lane "
-                                                          "i mod L (pipeline.run_interleaved(lanes=L)); results are bit-identical for every L")
+    ap.add_argument("--lanes", type=int, default=0, help="--mode interleaved: software-pipelined frame streams on this many HIP streams, group p on lane "
+                                                          "p mod L (pipeline.run_interleaved(lanes=L)); results are bit-identical for every L.  0 (default): 3 "
+                                                          "for the fp32 leg, 2 for the mixed leg -- what measured fastest for each at 20 steps (DESIGN 4.4)")
     ap.add_argument("--frames-per-launch", type=int, default=2,
                     help="--mode interleaved: this many consecutive items of the stream share every launch of a tick (pipeline.run_interleaved("
                          "frames_per_launch=F): the frame program is recorded for batch F x B; items stay --batch frames each, with their own "
@@ -190,6 +191,7 @@ def measure(args, dev, rank, world, precision):
     import torch.distributed as dist
     os.environ["VIDC_PRECISION"] = precision
     H, W, B = args.height, args.width, args.batch
+    lanes = args.lanes if args.lanes > 0 else (3 if (precision == "fp32" and args.frames_per_launch > 1) else 2)
     pipe, sn_sd, dc_sd, cc, det_sd = build_pipeline(H, W, dev, args.plane_head)
 
     # frame f of the job is a function of (seed, f) only: rank r takes frames r, r+world, ... (round-robin shards)
@@ -224,7 +226,7 @@ def measure(args, dev, rank, world, precision):
             for out in pipe.run_stream(frames(n), in_flight=args.in_flight):
                 pass
         else:       # n frames = n + 1 pipeline ticks, all inside the timed region; outputs stay in the program's buffer (valid until the
-            for out in pipe.run_interleaved(frames(n), copy_outputs=False, lanes=args.lanes, frames_per_launch=args.frames_per_launch):      # next item
+            for out in pipe.run_interleaved(frames(n), copy_outputs=False, lanes=lanes, frames_per_launch=args.frames_per_launch):      # next item
                 pass                                                                                                                      # is requested: documented lifetime)
         return out
 
@@ -249,7 +251,7 @@ def measure(args, dev, rank, world, precision):
         for _ in range(3):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            gen = pipe.run_interleaved(frames(2 * args.lanes * args.frames_per_launch), copy_outputs=False, lanes=args.lanes, frames_per_launch=args.frames_per_launch)
+            gen = pipe.run_interleaved(frames(2 * lanes * args.frames_per_launch), copy_outputs=False, lanes=lanes, frames_per_launch=args.frames_per_launch)
             next(gen)
             torch.cuda.current_stream().synchronize()
             lat.append(time.perf_counter() - t1)
@@ -318,7 +320,7 @@ def measure(args, dev, rank, world, precision):
                  "avg_launch_us": round(1e3 * ms / cnt, 2), "gflop_per_launch": round(fl / cnt / 1e9, 3),
                  "ms_per_frame": round(ms / fpt, 3),
                  "timing_note": "per-launch durations are taken on ONE stream (the frame program alone, HIP events between ops, rescaled to its graph replay time); "
-                                "with --lanes 2 launches of the two streams overlap and a kernel trace of the run shows longer per-kernel durations: "
+                                "with several lanes launches of the streams overlap and a kernel trace of the run shows longer per-kernel durations: "
                                 "profiles/r4_kernel_stats_fp32.csv / r4_kernel_stats_mixed.csv (--lanes 1) are the traces these numbers agree with",
                  "traffic_note": "no PMC pass on file for this instantiation in profiles/pmc_traffic.json (tools/evidence_r3.sh collects them on "
                                  "tools/frame_replay.py: rocprofv3 --pmc on the whole bench process segfaults in rocprofv3 on this pool)"}
@@ -343,7 +345,7 @@ def measure(args, dev, rank, world, precision):
         extra = {"program_ms": ({"frame_program_tick": round(sn_total, 3), "frames_per_tick": fpt} if args.mode == "interleaved" else
                                 {"surface_normal": round(sn_total, 3), "depth_completion": round(dc_total, 3)}),
                  "conv_ms_per_frame": round(conv_ms / fpt, 3), "conv_launches_per_frame": round(n_launch / fpt, 2), "conv_launches_per_tick": n_launch,
-                 "first_item_latency_ms": first_item_ms,
+                 "first_item_latency_ms": first_item_ms, "lanes": (lanes if args.mode == "interleaved" else 1),
                  "conv_stack": {"executed_gflop_per_frame": round(conv_flops / fpt / 1e9, 2),
                                 "tflops_fp32_equivalent": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
                                 "tflops_bf16_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / (conv_ms * 1e-3) / 1e12, 2),
@@ -366,7 +368,7 @@ def measure(args, dev, rank, world, precision):
                 for name, ops in ((("frame_program" if args.mode == "interleaved" else "surface_normal"), sn_ops), ("depth_completion", dc_ops)):
                     for n, t in ops:
                         f.write("%s\t%.2f\t%s\n" % (name, t * 1e3, n))
-    return {"elapsed": elapsed, "pipe": pipe, "sn_sd": sn_sd, "dc_sd": dc_sd, "cc": cc, "det_sd": det_sd, "roofline": roofline, "extra": extra,
+    return {"elapsed": elapsed, "pipe": pipe, "lanes": lanes, "sn_sd": sn_sd, "dc_sd": dc_sd, "cc": cc, "det_sd": det_sd, "roofline": roofline, "extra": extra,
             "frames": frames, "pre": pre}
 
 
@@ -511,7 +513,7 @@ def main():
             dev_hb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in hb.items()}
             if args.mode == "interleaved":
                 partner = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in S.synthetic_batch(B, H, W, 1234, frame0=(rank + world) * B).items()}
-                got = list(pipe.run_interleaved(iter([dev_hb, partner]), lanes=args.lanes, frames_per_launch=args.frames_per_launch))[0].cpu()
+                got = list(pipe.run_interleaved(iter([dev_hb, partner]), lanes=res[m]["lanes"], frames_per_launch=args.frames_per_launch))[0].cpu()
             else:
                 got = pipe._call_cnn(dev_hb).cpu()
             recs[m][2], recs[m][3] = float((got - ref).double().pow(2).sum()), float(ref.numel())
@@ -564,11 +566,11 @@ def main():
                                     "pre-processing (PIL-exact resize to %dx%d, rasterisation) + warp + surface-normal net + plane "
                                     "block/enrichment + depth-completion net" % (args.source, B, "from the Mask R-CNN plane head every frame" if args.plane_head else "fixed", W, H))),
                        "height": H, "width": W, "batch_per_gpu": B, "weights": "seeded random-init (seed 1234)",
-                       "mode": args.mode, "lanes": (args.lanes if args.mode == "interleaved" else 1), "frames_per_launch": F,
+                       "mode": args.mode, "lanes": (lead["lanes"] if args.mode == "interleaved" else 1), "frames_per_launch": F,
                        "frames_per_launch_note": ("one step = one batch-%d item (its own gravity, plane block and draws, main.py:261-298); %d consecutive items of "
                                                   "the stream share every launch of a tick (program recorded for batch %d), an item's result does not depend on "
                                                   "its partner" % (B, F, F * B)) if F > 1 else None,
-                       "frames_in_flight": (2 * args.lanes * F if args.mode == "interleaved" else args.in_flight if args.mode == "streams" else 1),
+                       "frames_in_flight": (2 * lead["lanes"] * F if args.mode == "interleaved" else args.in_flight if args.mode == "streams" else 1),
                        "sharding": "frames round-robin over %d rank(s), no data-path collective" % world},
             "rmse_vs_oracle": (round(job["rmse"], 8) if job["rmse"] is not None else None),
             "roofline": lead["roofline"], "cpu_baseline": cpu_baseline,
@@ -584,7 +586,7 @@ def main():
                                       "(operands split hi + lo in bf16, fp32 accumulate: narrower products than the reference's fp32), fresh pipeline in this "
                                       "process" % args.steps) if m == "mixed" else
                                      ("the same %d steps with every conv on v_mfma_f32_32x32x2_f32 (exact fp32 products and sums), fresh pipeline in this process" % args.steps),
-                             "program_ms": rm["extra"].get("program_ms"), "conv_ms_per_frame": rm["extra"].get("conv_ms_per_frame"),
+                             "lanes": rm["lanes"], "program_ms": rm["extra"].get("program_ms"), "conv_ms_per_frame": rm["extra"].get("conv_ms_per_frame"),
                              "first_item_latency_ms": rm["extra"].get("first_item_latency_ms"),
                              "sequential_call_cnn": rm["extra"].get("sequential_call_cnn"),
                              "conv_stack": rm["extra"].get("conv_stack")}})

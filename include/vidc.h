@@ -468,6 +468,11 @@ int vidc_masked_l1_loss(const float* pred, const float* gt, long long n, int hw,
 /* torch.optim.Adam.step (defaults: no weight decay, no amsgrad) over a flat buffer; step = 1, 2, ... */
 int vidc_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,
                    vidc_stream_t stream);
+/* A range of the flat gradient buffer rounded to bf16 (round to nearest even) for the cross-rank SUM, and widened back afterwards:
+ * halves the bytes a ring all-reduce moves over xGMI (training.GradientBuckets, VIDC_TRAIN_GRAD_BF16=1; the reference sums its
+ * replicas' gradients in fp32 inside DataParallel, network_run.py:97-99 -- this is an opt-in).  Both buffers 16-byte aligned. */
+int vidc_grad_narrow_bf16(const float* x, void* y_bf16, long long n, vidc_stream_t stream);
+int vidc_grad_widen_bf16(const void* x_bf16, float* y, long long n, vidc_stream_t stream);
 /* dgrad: the gradient w.r.t. a conv's input is vidc_conv2d_bn_act of dY (stride 1, pad KH-1-pad) with these weights
  * ([Cin][Cout/32][KH][KW][32], kernel flipped); a stride-s conv first spreads dY over the input grid with vidc_zero_stuff. */
 int vidc_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, vidc_stream_t stream);

@@ -26,7 +26,7 @@ from vi_depth_completion_amd import synthetic as S   # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 SEED = 1234
-DEMO_FRAMES = ("000000", "000068", "000085")
+DEMO_FRAMES = ("000000", "000068", "000085", "000017", "000034", "000051", "000102", "000119")      # all eight frames of demo_dataset (the first is re-used by the dense case)
 PROBES = 64
 
 

@@ -481,7 +481,9 @@ def _intr():
 
 # (demo_000000_dense: demo_000000 + ~1100 extra sparse depths on plane 2, so that the REFERENCE run that produced the fixture took
 #  plane_offset_ransac's > 300-point branch, main.py:75-78 -- oracle/tools/make_golden.py)
-GOLDEN_FRAMES = ["demo_000000", "demo_000068", "demo_000085", "synthetic_f0", "demo_000000_dense"]
+# (all eight frames of the reference's demo_dataset since round 4)
+GOLDEN_FRAMES = ["demo_000000", "demo_000068", "demo_000085", "synthetic_f0", "demo_000000_dense",
+                 "demo_000017", "demo_000034", "demo_000051", "demo_000102", "demo_000119"]
 
 
 @pytest.mark.parametrize("name", GOLDEN_FRAMES)

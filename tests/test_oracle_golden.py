@@ -59,7 +59,8 @@ def _batch_from_golden(f, name):
             "homogeneous_coordinates": S.homogeneous_grid(S.DEMO_FC, S.DEMO_CC, 320, 240)[None]}
 
 
-@pytest.mark.parametrize("name", ["demo_000000", "demo_000068", "demo_000085", "synthetic_f0", "demo_000000_dense"])
+@pytest.mark.parametrize("name", ["demo_000000", "demo_000068", "demo_000085", "synthetic_f0", "demo_000000_dense",
+                                  "demo_000017", "demo_000034", "demo_000051", "demo_000102", "demo_000119"])
 def test_full_path(golden_dir, seeded_weights, name):
     f = np.load(os.path.join(golden_dir, name + ".npz"))
     batch = _batch_from_golden(f, name)

@@ -716,3 +716,83 @@ def test_two_training_iterations_vs_oracle(golden_dir, seeded_weights):
         ref = sd[k].numpy()                                                                  # +-lr sign noise of the first step
         assert np.abs(new[k].cpu().numpy() - ref).max() < 3e-2 * np.abs(ref).max(), k
     assert int(new["resnet_rgb.bn1.num_batches_tracked"]) == 2
+
+
+# ---- two ranks through whole training steps --------------------------------------------------------------------------
+def _run_two_rank_worker(extra_env):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VIDC_TRAIN_PRECISION")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", "2",
+                        os.path.join(root, "tests", "two_rank_training_worker.py")], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "TWO_RANK_TRAINING_OK" in r.stdout, (r.stdout + r.stderr)[-4000:]
+    return r.stdout
+
+
+@gpu
+def test_two_ranks_through_training_steps():
+    """Two ranks (gloo, sharing the GPU), different shards, four `DepthCompletionTrainer.step`s each -- two eager, two as captured graphs,
+    the decoder's gradient buckets all-reduced before the pyramids' backward has run: the all-reduced flat gradient equals the sum of
+    the two shards' single-process gradients bit for bit, and each rank's parameters and per-rank BatchNorm statistics equal those of a
+    single-process replica stepped with that sum (tests/two_rank_training_worker.py; replaces network_run.py:97-99)."""
+    out = _run_two_rank_worker({})
+    assert "bf16_buckets=0" in out
+
+
+@gpu
+def test_two_ranks_with_bf16_gradient_buckets():
+    """The same with VIDC_TRAIN_GRAD_BF16=1: every bucket is narrowed to bf16 on the device, summed, widened back -- exactly
+    round_bf16(round_bf16(g0) + round_bf16(g1)) in every element, half the bytes on the wire."""
+    out = _run_two_rank_worker({"VIDC_TRAIN_GRAD_BF16": "1"})
+    assert "bf16_buckets=1" in out
+
+
+@gpu
+def test_bf16_gradient_buckets_keep_the_loss_curve(seeded_weights):
+    """What rounding the gradients to bf16 before Adam does to training (a world of one sends them through the narrow / widen kernels and
+    the process group just the same): eight steps of the configs[4] workload at batch 2, bf16 convs, with and without -- the losses
+    agree to 1e-3 relative (Adam normalises the step by the gradient's own running magnitude; 8 bits of mantissa per element do not
+    move the direction)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, socket
+sys.path.insert(0, %r)
+import torch
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", VIDC_DIST_WORLD1="1")
+import torch.distributed as dist
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+from vi_depth_completion_amd import synthetic as S
+from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
+from vi_depth_completion_amd.training import DepthCompletionTrainer
+b = S.synthetic_batch(2, 240, 320, 1234, frame0=0)
+image = b["image"].to(dev); normal = torch.nn.functional.normalize(image - 0.5, dim=1)
+depth_in = b["sparse_depth"].to(dev); gt = S.synthetic_ground_truth_depth(b["image"], 1234).to(dev)
+curves = []
+for flag in ("0", "1"):
+    os.environ["VIDC_TRAIN_GRAD_BF16"] = flag
+    cnn = ModifiedFPN().to(dev)
+    cnn.load_state_dict(S.seeded_state_dict(cnn.state_dict(), 1234, device=dev))
+    cnn.train()
+    tr = DepthCompletionTrainer(cnn, 1e-4)
+    assert tr._distributed() and (tr.buckets.compress == "bf16") == (flag == "1")
+    curves.append([float(tr.step(image, normal, depth_in, gt)) for _ in range(8)])
+    del tr, cnn
+print("CURVES", curves)
+rel = max(abs(a - b) / abs(a) for a, b in zip(*curves))
+assert curves[0][0] == curves[1][0] and curves[0][-1] < curves[0][0], curves      # same first loss (same weights), and it trains
+assert rel < 1e-3, (rel, curves)
+assert curves[0] != curves[1], "the switch changed nothing"
+dist.barrier(); dist.destroy_process_group()
+print("BF16_BUCKETS_CURVE_OK", rel)
+''' % root
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", VIDC_TRAIN_PRECISION="bf16")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "BF16_BUCKETS_CURVE_OK" in r.stdout, (r.stdout + r.stderr)[-4000:]

@@ -1103,7 +1103,9 @@ extern "C" int vidc_maxpool3x3s2_backward(const float* x, const float* dy, float
                                           vidc_stream_t stream) {
     VIDC_REQUIRE(x && dy && dx, VIDC_ERR_NULL, "vidc_maxpool3x3s2_backward: null pointer");
     VIDC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, VIDC_ERR_SHAPE, "vidc_maxpool3x3s2_backward: bad shape");
+    const long long Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;      // (the wide kernel indexes x, dx AND dy with 32-bit offsets)
     const bool wide = C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (long long)B * H * W * (ldx > lddx ? ldx : lddx) < (1ll << 31) &&
+                      (long long)B * Ho * Wo * lddy < (1ll << 31) &&
                       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
     if (wide)
         hipLaunchKernelGGL(maxpool_bwd4_kernel, dim3(blocks((long long)B * H * W * (C / 4))), dim3(TT), 0, vidc::as_stream(stream), x, dy, dx, B, H, W, C, ldx, lddy, lddx);
@@ -1174,6 +1176,48 @@ extern "C" int vidc_adam_step(float* p, const float* g, float* m, float* v, long
     hipLaunchKernelGGL(adam_kernel, dim3(blocks(n)), dim3(TT), 0, vidc::as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1,
                        (float)sqrt(bc2));
     VIDC_CHECK_LAUNCH("adam_kernel");
+    return VIDC_OK;
+}
+
+// Gradient buckets in bf16 for the cross-rank SUM (training.GradientBuckets, VIDC_TRAIN_GRAD_BF16=1): 8 values per lane, 32 B in / 16 B out
+// (narrow) and back; HBM-bound, one pass each.
+__global__ void __launch_bounds__(TT) grad_narrow_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long long n) {
+    const long long i = ((long long)blockIdx.x * TT + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(x + i + 4);
+        *reinterpret_cast<uint4*>(y + i) = make_uint4(vidc::bf16_rne(a.x) | ((unsigned)vidc::bf16_rne(a.y) << 16), vidc::bf16_rne(a.z) | ((unsigned)vidc::bf16_rne(a.w) << 16),
+                                                      vidc::bf16_rne(b.x) | ((unsigned)vidc::bf16_rne(b.y) << 16), vidc::bf16_rne(b.z) | ((unsigned)vidc::bf16_rne(b.w) << 16));
+    } else {
+        for (long long j = i; j < n; ++j) y[j] = vidc::bf16_rne(x[j]);
+    }
+}
+
+__global__ void __launch_bounds__(TT) grad_widen_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, long long n) {
+    const long long i = ((long long)blockIdx.x * TT + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x + i);
+        *reinterpret_cast<float4*>(y + i) = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xFFFF0000u));
+        *reinterpret_cast<float4*>(y + i + 4) = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xFFFF0000u), __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xFFFF0000u));
+    } else {
+        for (long long j = i; j < n; ++j) y[j] = __uint_as_float((unsigned)x[j] << 16);
+    }
+}
+
+extern "C" int vidc_grad_narrow_bf16(const float* x, void* y_bf16, long long n, vidc_stream_t stream) {
+    VIDC_REQUIRE(x && y_bf16, VIDC_ERR_NULL, "vidc_grad_narrow_bf16: null pointer");
+    VIDC_REQUIRE(n > 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y_bf16 % 16) == 0, VIDC_ERR_SHAPE, "vidc_grad_narrow_bf16: n > 0 and 16-byte aligned buffers");
+    hipLaunchKernelGGL(grad_narrow_kernel, dim3((unsigned)((n + (long long)TT * 8 - 1) / ((long long)TT * 8))), dim3(TT), 0, vidc::as_stream(stream), x,
+                       reinterpret_cast<unsigned short*>(y_bf16), n);
+    VIDC_CHECK_LAUNCH("grad_narrow_kernel");
+    return VIDC_OK;
+}
+
+extern "C" int vidc_grad_widen_bf16(const void* x_bf16, float* y, long long n, vidc_stream_t stream) {
+    VIDC_REQUIRE(x_bf16 && y, VIDC_ERR_NULL, "vidc_grad_widen_bf16: null pointer");
+    VIDC_REQUIRE(n > 0 && ((uintptr_t)x_bf16 % 16) == 0 && ((uintptr_t)y % 16) == 0, VIDC_ERR_SHAPE, "vidc_grad_widen_bf16: n > 0 and 16-byte aligned buffers");
+    hipLaunchKernelGGL(grad_widen_kernel, dim3((unsigned)((n + (long long)TT * 8 - 1) / ((long long)TT * 8))), dim3(TT), 0, vidc::as_stream(stream),
+                       reinterpret_cast<const unsigned short*>(x_bf16), y, n);
+    VIDC_CHECK_LAUNCH("grad_widen_kernel");
     return VIDC_OK;
 }
 

@@ -74,10 +74,17 @@ def _ld(t):
 
 class GradientBuckets:
     """The flat gradient buffer cut into buckets for the cross-rank SUM (one collective per bucket, ~64 MB each: large enough that a
-    ring all-reduce over xGMI runs at link speed, small enough to start before the whole backward has finished if overlapped)."""
+    ring all-reduce over xGMI runs at link speed, small enough to start before the whole backward has finished if overlapped).
 
-    def __init__(self, n_elements, bucket_elements=16 * 1024 * 1024):
+    compress="bf16" (DepthCompletionTrainer: VIDC_TRAIN_GRAD_BF16=1): every bucket travels rounded to bf16 -- 0.62 GB instead of
+    1.24 GB per step for ModifiedFPN, i.e. ~7 instead of ~14 ms on a ring at 153 GB/s per xGMI link -- and is widened back into the
+    fp32 buffer before Adam reads it (vidc_grad_narrow_bf16 / vidc_grad_widen_bf16; the SUM itself is RCCL's, in bf16).  An opt-in:
+    the reference's DataParallel sums its replicas' gradients in fp32 (network_run.py:97-99)."""
+
+    def __init__(self, n_elements, bucket_elements=16 * 1024 * 1024, compress=None):
         self.ranges = [(a, min(n_elements, a + bucket_elements)) for a in range(0, n_elements, bucket_elements)]
+        self.compress = compress
+        self._narrow = None            # persistent bf16 image of the flat buffer (allocated on first use)
 
     def all_reduce(self, flat):
         for w in self.all_reduce_async(flat):
@@ -95,12 +102,40 @@ class GradientBuckets:
             return []
         hi = flat.numel() if hi is None else hi
         stage = dist.get_backend() == "gloo" and flat.is_cuda
+        bf16 = self.compress == "bf16" and flat.is_cuda
+        if bf16 and (self._narrow is None or self._narrow.numel() != flat.numel() or self._narrow.device != flat.device):
+            self._narrow = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
         waits = []
         for a, b in self.ranges:
             a, b = max(a, lo), min(b, hi)
             if a >= b:
                 continue
-            if stage:
+            if bf16 and a % 8 and b - a > 8:      # a range that starts off the kernels' 16-byte grid (the decoder's first parameter): its first
+                a_up = a + 8 - a % 8              # few elements travel as they are, in fp32
+                head = flat[a:a_up]
+                if stage:
+                    h = head.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                    head.copy_(h)
+                else:
+                    waits.append(dist.all_reduce(head, op=dist.ReduceOp.SUM, async_op=True).wait)
+                a = a_up
+            if bf16 and a % 8 == 0:
+                src, nb = flat[a:b], self._narrow[a:b]
+                L.check(L.lib().vidc_grad_narrow_bf16(L.ptr(src), L.ptr(nb), b - a, L.current_stream()), "grad narrow")
+                if stage:
+                    h = nb.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                    nb.copy_(h)
+                    L.check(L.lib().vidc_grad_widen_bf16(L.ptr(nb), L.ptr(src), b - a, L.current_stream()), "grad widen")
+                else:
+                    work = dist.all_reduce(nb, op=dist.ReduceOp.SUM, async_op=True)
+
+                    def done(work=work, nb=nb, src=src, n=b - a):
+                        work.wait()               # (the current stream waits for the collective; the widening pass follows on it)
+                        L.check(L.lib().vidc_grad_widen_bf16(L.ptr(nb), L.ptr(src), n, L.current_stream()), "grad widen")
+                    waits.append(done)
+            elif stage:
                 h = flat[a:b].cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM)
                 flat[a:b].copy_(h)
@@ -135,7 +170,7 @@ class DepthCompletionTrainer:
             self.param[k], self.grad[k] = p.data, p.grad
             o += k_n
         self.buf = {k: b for k, b in cnn.named_buffers()}
-        self.buckets = GradientBuckets(n)
+        self.buckets = GradientBuckets(n, compress=("bf16" if os.environ.get("VIDC_TRAIN_GRAD_BF16", "0") == "1" else None))
         # the decoder's parameters (feature*_upsamping, feature_concat) form the tail of the flat buffers (named_parameters order): their
         # gradients are complete when the decoder's backward is, long before the pyramids' -- they are all-reduced while those still run
         offs = {k: int((self.grad[k].data_ptr() - self.flat_g.data_ptr()) // 4) for k, _ in self.named}
@@ -252,6 +287,8 @@ class DepthCompletionTrainer:
             if cin % 64:
                 raise RuntimeError("bf16 training needs conv input channels in multiples of 64 (got %d)" % cin)
             xs = x_bf                             # the producer wrote the bf16 copy already (bn / bn backward)
+            if xs is not None and tuple(xs.shape) != (B, H, W, cin // 2):
+                raise RuntimeError("bf16 operand copy of shape %s for an activation of shape %s" % (tuple(xs.shape), (B, H, W, cin)))
             if xs is None:
                 xs = self._empty(B, H, W, cin // 2)
                 L.check(L.lib().vidc_cast_bf16(L.ptr(x_t), L.ptr(xs), B * H * W, cin, ldx, L.current_stream()), "cast")
@@ -360,6 +397,8 @@ class DepthCompletionTrainer:
         if g_t is not None and bf16 and g_t[1] == Mp and g_t[0].numel() == co * Mp // e:
             gt = g_t[0]                           # written by the BatchNorm backward that produced g (vidc_bn_train_backward_t)
         else:
+            if g is None:
+                raise RuntimeError("wgrad %s: neither dY nor a matching dY^T" % key)
             gt = self._empty(co, Mp // e)
             L.check(lib.vidc_im2col_transposed(L.ptr(g), L.ptr(gt), B, Ho, Wo, co, _ld(g), Ho, Wo, 1, 1, 1, 0, Mp, split, st), "transpose dY")
         # rows of Xt in channel-major order (split + 4): the GEMM's output [co][ci*taps + tap] IS the OIHW weight gradient, written in place
@@ -414,6 +453,14 @@ class DepthCompletionTrainer:
 
         def backward():
             g, g_bf, g_t = y.grad, y.grad_bf, y.grad_t
+            if g is None:
+                # the BatchNorm backward skipped the fp32 dY (no_f32_grad): this closure must then find BOTH bf16 forms, in the geometry
+                # its GEMMs expect -- anything else (a second consumer of y, a precision switched between forward and backward) would
+                # read a stand-in tensor as if it were the gradient
+                Mp_ = (B * Ho * Wo + 63) // 64 * 64
+                if not (y.no_f32_grad and not relu and g_bf is not None and g_t is not None and self.precision == L.PREC_BF16 and
+                        g_t[1] == Mp_ and g_t[0].numel() == co * Mp_ // 2):
+                    raise RuntimeError("conv %s: no fp32 gradient and no matching bf16 forms of it (no_f32_grad invariant broken)" % key)
             if relu:                                         # y = relu(conv): mask first
                 gm = self._empty(B, Ho, Wo, co)
                 L.check(L.lib().vidc_relu_backward(L.ptr(g), L.ptr(y.t), L.ptr(gm), y.rows, co, _ld(g), y.ld, co, 0, L.current_stream()), "relu_bwd")
@@ -740,6 +787,13 @@ class DepthCompletionTrainer:
         # other lanes' kernels are still queued -- and inside a captured graph, where the three pyramids are parallel branches and a
         # freed block is reusable at once, the allocating lane's next temporary could overwrite it.  So every closure that has run is
         # kept until all lanes have joined the main stream at the end of the tape.
+        try:
+            self._run_tape_inner(stop_after_decoder)
+        except BaseException:
+            self.tape, self._keepalive = [], []           # a failed step must not pin every activation gradient until the next good one
+            raise
+
+    def _run_tape_inner(self, stop_after_decoder):
         main = torch.cuda.current_stream()
         forked = []
         while self.tape:
