@@ -29,7 +29,8 @@ def seeded_weights():
     man = np.load(os.path.join(GOLDEN, "state_dict_manifest.npz"))
 
     def build(prefix):
-        shapes = {k: torch.empty(eval(s), device="meta") for k, s in zip(man[prefix + "_keys"], man[prefix + "_shapes"])}
+        shapes = {str(k): torch.empty(eval(s), device="meta") for k, s in zip(man[prefix + "_keys"], man[prefix + "_shapes"])}     # (plain str keys: a
+        #                                                  state_dict saved to a file must not carry numpy.str_ objects -- tests/test_checkpoints.py)
         return S.seeded_state_dict(shapes, 1234)
 
     return {"sn": build("sn"), "dc": build("dc")}
