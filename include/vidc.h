@@ -468,6 +468,12 @@ int vidc_masked_l1_loss(const float* pred, const float* gt, long long n, int hw,
 /* torch.optim.Adam.step (defaults: no weight decay, no amsgrad) over a flat buffer; step = 1, 2, ... */
 int vidc_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,
                    vidc_stream_t stream);
+/* Process-wide switch of the training BatchNorms (default 0): with 1 the final reduction of the per-chunk channel sums runs inside the
+ * prologue of the kernel that consumes it (apply / backward-apply: one launch less per BatchNorm pass on the small maps) instead of in a
+ * launch of its own.  Both forms add the same numbers in the same order (bit-identical results); the folded form measured 6 % slower
+ * per step on MI355X (cross-XCD reads of the chunk sums in every workgroup's prologue), so it is an opt-in kept for measurements.
+ * enable < 0: query only.  Returns the previous value. */
+int vidc_train_bn_fold(int enable);
 /* A range of the flat gradient buffer rounded to bf16 (round to nearest even) for the cross-rank SUM, and widened back afterwards:
  * halves the bytes a ring all-reduce moves over xGMI (training.GradientBuckets, VIDC_TRAIN_GRAD_BF16=1; the reference sums its
  * replicas' gradients in fp32 inside DataParallel, network_run.py:97-99 -- this is an opt-in).  Both buffers 16-byte aligned. */

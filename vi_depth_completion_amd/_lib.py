@@ -98,6 +98,7 @@ SIGNATURES = {
     "vidc_head_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vidc_masked_l1_loss": (C.c_int, [_vp, _vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp]),
     "vidc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, _f, _f, _f, _f, _i, _vp]),
+    "vidc_train_bn_fold": (C.c_int, [_i]),
     "vidc_grad_narrow_bf16": (C.c_int, [_vp, _vp, C.c_longlong, _vp]),
     "vidc_grad_widen_bf16": (C.c_int, [_vp, _vp, C.c_longlong, _vp]),
     "vidc_pack_conv_weight_dgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -72,21 +72,33 @@ chan_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, co
 }
 
 // What the per-channel sums become, applied by the thread that finishes a channel in chan_final_kernel (no extra launch).
+// batch mean, biased variance and invstd from the two per-channel sums (shared by chan_final_kernel's FinalStats and the kernels that
+// fold that reduction into their prologue, so that both forms round identically)
+struct BnMoments { double mu, var; float mean, rstd; };
+__device__ inline BnMoments bn_moments(double s0, double s1, long long M, float eps) {
+    BnMoments r;
+    r.mu = s0 / (double)M;
+    r.var = s1 / (double)M - r.mu * r.mu;
+    if (r.var < 0.0) r.var = 0.0;
+    r.mean = (float)r.mu;
+    r.rstd = (float)(1.0 / sqrt(r.var + (double)eps));
+    return r;
+}
+__device__ inline void bn_update_running(float* running_mean, float* running_var, int c, const BnMoments& m, long long M, float momentum) {
+    const double unbiased = M > 1 ? m.var * (double)M / (double)(M - 1) : m.var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m.mu);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+}
+
 struct FinalStats {      // nn.BatchNorm2d.forward in train(): batch mean, biased variance, invstd = 1/sqrt(var + eps); running_mean/var <-
     long long M;         // (1 - momentum) * old + momentum * (mean, unbiased var)
     float eps, momentum;
     float *mean, *rstd, *running_mean, *running_var;
     __device__ void operator()(int c, double s0, double s1) const {
-        const double mu = s0 / (double)M;
-        double var = s1 / (double)M - mu * mu;
-        if (var < 0.0) var = 0.0;
-        mean[c] = (float)mu;
-        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean) {
-            const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mu);
-            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
-        }
+        const BnMoments m = bn_moments(s0, s1, M, eps);
+        mean[c] = m.mean;
+        rstd[c] = m.rstd;
+        if (running_mean) bn_update_running(running_mean, running_var, c, m, M, momentum);
     }
 };
 struct FinalParamGrad {  // dbeta = sum dy, dgamma = sum dy * xhat
@@ -121,6 +133,83 @@ __global__ void __launch_bounds__(TT) chan_final_kernel(const double* __restrict
         sums[c] = s0;
         sums[C + c] = s1;
         fin(c, s0, s1);
+    }
+}
+
+// The chunk sums of one channel added up exactly as chan_final_kernel adds them (lane l takes chunks l, l + 32, ... in order, then the
+// fixed pairwise tree over the 32 lanes), by ONE thread: the kernels below fold that reduction into their prologue -- every workgroup
+// redoes it for its 64 channels from the L2-resident partials -- which removes the chan_final launch between the partial-sum kernel and
+// its consumer (a 5 us kernel at its launch floor, twice per BatchNorm and step) without any cross-workgroup hand-off.  Bit-identical.
+__device__ inline double fold_chunk_sums(const double* __restrict__ partial, int n_chunks, int C, int q, int c) {
+    double lane[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) lane[i] = 0.0;
+    for (int k0 = 0; k0 < n_chunks; k0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            if (k0 + i < n_chunks) lane[i] += partial[((size_t)(k0 + i) * 2 + q) * C + c];
+    }
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+#pragma unroll
+        for (int i = 0; i < w; ++i) lane[i] += lane[i + w];
+    }
+    return lane[0];
+}
+
+// chan_final<FinalStats> + bn_apply_kernel in one launch: 64 pixels x 64 channels per workgroup (the layout of bn_bwd_apply_t64_kernel).
+__global__ void __launch_bounds__(256)
+bn_apply_fold_kernel(const float* __restrict__ x, float* __restrict__ y, int M, int C, int ldx, int ldy, const double* __restrict__ partial, int n_chunks,
+                     float eps, float momentum, float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ running_mean,
+                     float* __restrict__ running_var, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                     unsigned short* __restrict__ y_bf16, const float* __restrict__ res, int ldr) {
+    __shared__ double sum_s[2][64];
+    __shared__ float mean_s[64], rstd_s[64];
+    const int c0 = blockIdx.y * 64, m0 = blockIdx.x * 64;
+    if (threadIdx.x < 128) {
+        const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+        sum_s[q][l] = c0 + l < C ? fold_chunk_sums(partial, n_chunks, C, q, c0 + l) : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int l = threadIdx.x, cc = c0 + l;
+        const BnMoments mo = bn_moments(sum_s[0][l], sum_s[1][l], (long long)M, eps);
+        mean_s[l] = mo.mean; rstd_s[l] = mo.rstd;
+        if (blockIdx.x == 0 && cc < C) {         // one workgroup per channel block publishes what the backward and the module keep
+            save_mean[cc] = mo.mean; save_rstd[cc] = mo.rstd;
+            if (running_mean) bn_update_running(running_mean, running_var, cc, mo, (long long)M, momentum);
+        }
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = c0 + tx * 4;
+    if (c >= C) return;
+    float alpha[4], bb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        alpha[k] = rstd_s[tx * 4 + k] * gamma[c + k];
+        bb[k] = beta[c + k] - mean_s[tx * 4 + k] * alpha[k];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = m0 + ty + 16 * rr;
+        if (r >= M) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+        float in[4] = {v.x, v.y, v.z, v.w}, out[4], add[4] = {0.f, 0.f, 0.f, 0.f};
+        if (res) {
+            const float4 q = *reinterpret_cast<const float4*>(res + (size_t)r * ldr + c);
+            add[0] = q.x; add[1] = q.y; add[2] = q.z; add[3] = q.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float o = in[k] * alpha[k] + bb[k];
+            if (res) o = __fadd_rn(o, add[k]);
+            out[k] = relu ? fmaxf(o, 0.f) : o;
+        }
+        *reinterpret_cast<float4*>(y + (size_t)r * ldy + c) = make_float4(out[0], out[1], out[2], out[3]);
+        if (y_bf16)
+            *reinterpret_cast<uint2*>(y_bf16 + (size_t)r * C + c) = make_uint2(vidc::bf16_rne(out[0]) | ((unsigned)vidc::bf16_rne(out[1]) << 16),
+                                                                               vidc::bf16_rne(out[2]) | ((unsigned)vidc::bf16_rne(out[3]) << 16));
     }
 }
 
@@ -189,22 +278,37 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, c
 // m >= M): dx of the BatchNorm behind a conv is that conv's dY, and its weight-gradient GEMM reads dY^T in exactly this format
 // (vidc_im2col_transposed(..., KH = KW = 1, split = 2) -- one launch and one pass over dY per conv that this kernel makes unnecessary).
 // LDS tile [pixel][channel], pitch 65 floats, both phases as in im2col_t64_kernel; every value is rounded once, from the fp32 result.
+// FOLD: `sums` holds the CHUNK sums of chan_partial_kernel<1> (n_chunks of them) and the workgroup adds them up itself for its 64 channels
+// (fold_chunk_sums: chan_final's order); the workgroups of the first pixel block write dgamma / dbeta.  dx_bf16_t may then be NULL (no
+// transposed copy wanted): the kernel is the folded form of bn_bwd_apply_kernel as well.
+template <bool FOLD>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_t64_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ dx, int M, int C,
                         int lddy, int ldx, int ldy, int lddx, const float* __restrict__ mean, const float* __restrict__ rstd,
                         const float* __restrict__ gamma, const double* __restrict__ sums, unsigned short* __restrict__ dx_bf16,
-                        unsigned short* __restrict__ dx_bf16_t, int Mp) {
+                        unsigned short* __restrict__ dx_bf16_t, int Mp, int n_chunks, float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ float tile[64][65];
+    __shared__ double sum_s[2][64];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int c = c0 + tx * 4;
     const double invM = 1.0 / (double)M;
+    if (FOLD) {
+        if (threadIdx.x < 128) {
+            const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+            const double t = c0 + l < C ? fold_chunk_sums(sums, n_chunks, C, q, c0 + l) : 0.0;
+            sum_s[q][l] = t;
+            if (blockIdx.x == 0 && c0 + l < C) (q ? dgamma : dbeta)[c0 + l] = (float)t;      // FinalParamGrad: dbeta = sum dy', dgamma = sum dy' * xhat
+        }
+        __syncthreads();
+    }
     float mu[4], rs[4], gs[4], m1[4], m2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int ck = c + k < C ? c + k : C - 1;
         mu[k] = mean[ck]; rs[k] = rstd[ck]; gs[k] = gamma[ck] * rs[k];
-        m1[k] = (float)(sums[ck] * invM); m2[k] = (float)(sums[C + ck] * invM);
+        const double t0 = FOLD ? sum_s[0][ck - c0] : sums[ck], t1 = FOLD ? sum_s[1][ck - c0] : sums[C + ck];
+        m1[k] = (float)(t0 * invM); m2[k] = (float)(t1 * invM);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -233,6 +337,7 @@ bn_bwd_apply_t64_kernel(const float* __restrict__ dy, const float* __restrict__ 
         float* t = &tile[ty + 16 * r][tx * 4];
         t[0] = o[0]; t[1] = o[1]; t[2] = o[2]; t[3] = o[3];
     }
+    if (!dx_bf16_t) return;               // (uniform over the launch)
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -998,6 +1103,24 @@ inline int rows_for(long long M, int C) {
 }
 inline int chunks_for(long long M, int C) { const int r = rows_for(M, C); return (int)((M + r - 1) / r); }
 inline unsigned blocks(long long n) { return (unsigned)((n + TT - 1) / TT); }
+// The final reduction of a BatchNorm's chunk sums inside the consuming kernel's prologue (bn_apply_fold_kernel, bn_bwd_apply_t64_kernel<true>)
+// instead of a chan_final launch: every 64 x 64 workgroup re-reads n_chunks x 64 x 2 doubles, so it is only offered where pixel blocks x
+// chunks is small -- the ResNet-101 layer-3 / layer-4 maps and the coarse decoder levels, three quarters of a step's BatchNorms.  Same sums,
+// same order, same bits (tests/test_training.py), and MEASURED SLOWER on MI355X: 29.2 against 27.5 ms per batch-8 bf16 step, 70.9 against
+// 69.0 in fp32 (round 4, same box, alternating runs).  The chunk sums were written by workgroups on all eight XCDs, so the prologue's reads
+// miss the consumer's own L2 and wait on the fabric (~2 us per dependent batch of loads, three batches for 75 chunks) -- more than the 5 us
+// launch they replace, and every workgroup of the consumer pays it instead of the one small kernel.  Hence OFF by default; the switch
+// (vidc_train_bn_fold, VIDC_TRAIN_BN_FOLD=1) stays for measurements.
+int g_bn_fold = 0;
+inline bool fold_bn(long long M, int C) {
+    return g_bn_fold && M < (1ll << 31) && ((M + 63) / 64) * (long long)chunks_for(M, C) <= 4096;
+}
+}
+
+extern "C" int vidc_train_bn_fold(int enable) {
+    const int prev = g_bn_fold;
+    if (enable >= 0) g_bn_fold = enable ? 1 : 0;
+    return prev;
 }
 
 extern "C" size_t vidc_train_scratch_bytes(long long M, int C) {
@@ -1016,6 +1139,12 @@ extern "C" int vidc_bn_train_forward_add(const float* x, float* y, long long M, 
     double* sums = partial + (size_t)nch * 2 * C;
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, x, (const float*)nullptr, (const float*)nullptr, M, C, ldx, 0, 0,
                        (const float*)nullptr, (const float*)nullptr, rows_for(M, C), partial);
+    if (fold_bn(M, C)) {
+        hipLaunchKernelGGL(bn_apply_fold_kernel, dim3((unsigned)((M + 63) / 64), (C + 63) / 64), dim3(256), 0, st, x, y, (int)M, C, ldx, ldy, partial, nch, eps,
+                           momentum, save_mean, save_rstd, running_mean, running_var, gamma, beta, relu, reinterpret_cast<unsigned short*>(y_bf16), residual, ldr);
+        VIDC_CHECK_LAUNCH("bn_train_forward (folded)");
+        return VIDC_OK;
+    }
     hipLaunchKernelGGL(chan_final_kernel<FinalStats>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums,
                        FinalStats{M, eps, momentum, save_mean, save_rstd, running_mean, running_var});
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, x, y, M, C, ldx, ldy, save_mean, save_rstd, gamma, beta, relu,
@@ -1045,10 +1174,19 @@ extern "C" int vidc_bn_train_backward_t(const float* dy, const float* x, const f
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
     hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean, save_rstd, rows_for(M, C), partial);
+    if (fold_bn(M, C)) {
+        const int mp = dx_bf16_t ? Mp : (int)((M + 63) / 64 * 64);
+        hipLaunchKernelGGL(bn_bwd_apply_t64_kernel<true>, dim3(mp / 64, (C + 63) / 64), dim3(256), 0, st, dy, x, y_relu, dx, (int)M, C, lddy, ldx, ldy, lddx,
+                           save_mean, save_rstd, gamma, partial, reinterpret_cast<unsigned short*>(dx_bf16), reinterpret_cast<unsigned short*>(dx_bf16_t), mp, nch,
+                           dgamma, dbeta);
+        VIDC_CHECK_LAUNCH("bn_train_backward (folded)");
+        return VIDC_OK;
+    }
     hipLaunchKernelGGL(chan_final_kernel<FinalParamGrad>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, FinalParamGrad{dgamma, dbeta});
     if (dx_bf16_t)
-        hipLaunchKernelGGL(bn_bwd_apply_t64_kernel, dim3(Mp / 64, (C + 63) / 64), dim3(256), 0, st, dy, x, y_relu, dx, (int)M, C, lddy, ldx, ldy, lddx, save_mean,
-                           save_rstd, gamma, sums, reinterpret_cast<unsigned short*>(dx_bf16), reinterpret_cast<unsigned short*>(dx_bf16_t), Mp);
+        hipLaunchKernelGGL(bn_bwd_apply_t64_kernel<false>, dim3(Mp / 64, (C + 63) / 64), dim3(256), 0, st, dy, x, y_relu, dx, (int)M, C, lddy, ldx, ldy, lddx, save_mean,
+                           save_rstd, gamma, sums, reinterpret_cast<unsigned short*>(dx_bf16), reinterpret_cast<unsigned short*>(dx_bf16_t), Mp, 0,
+                           (float*)nullptr, (float*)nullptr);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, save_mean, save_rstd,
                            gamma, sums, reinterpret_cast<unsigned short*>(dx_bf16));

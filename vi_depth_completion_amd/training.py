@@ -201,6 +201,8 @@ class DepthCompletionTrainer:
         self.bn_add_fused = os.environ.get("VIDC_TRAIN_BN_ADD_FUSED", "1") == "1"   # Bottleneck tail relu(bn3(.) + identity) inside bn3's apply pass
         self.skip_f32_dy = os.environ.get("VIDC_TRAIN_SKIP_F32_DY", "1") == "1"    # the BatchNorm backward writes no fp32 dY where only the bf16 forms are read
         self.xt_from_bf16 = os.environ.get("VIDC_TRAIN_XT_BF16", "1") == "1"      # 1x1 convs: the wgrad GEMM's right operand transposed from the bf16 copy
+        if "VIDC_TRAIN_BN_FOLD" in os.environ:   # (A/B runs) the BatchNorm chunk sums reduced in the consumer's prologue (default) or by a launch of their own
+            L.lib().vidc_train_bn_fold(int(os.environ["VIDC_TRAIN_BN_FOLD"] != "0"))
         self._wgrad_streams, self._wgrad_used = {}, []
         self._retired = []          # outgrown scratch / workspace buffers that captured graphs still address (see _retire)
         self._keepalive = []        # backward closures already run in the current _run_tape, kept until the stream lanes have joined
