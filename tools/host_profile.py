@@ -2,7 +2,7 @@
 """Where the HOST's time goes per frame in the two-lane stream mode (the mode bench.py times): cProfile over N frames of
 pipeline.run_interleaved on device-resident synthetic frames, plus the wall time per frame and the time the host spends blocked in the
 one wait per frame (PlaneBlock.enrich -> event.synchronize).
-    python tools/host_profile.py [frames] [lanes] [batch] [plane-head: 0|1]      (batch > 1: 320x240 frames, BASELINE configs[2] / [3] shapes)"""
+    python tools/host_profile.py [frames] [lanes] [batch] [plane-head: 0|1] [items per launch]     (batch > 1: 320x240 frames, BASELINE configs[2] / [3] shapes)"""
 import cProfile
 import io
 import os
@@ -24,6 +24,7 @@ def main():
     lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     head = len(sys.argv) > 4 and sys.argv[4] == "1"
+    F = int(sys.argv[5]) if len(sys.argv) > 5 else 2
     H, W = (256 if B == 1 else 240), 320
     dev = torch.device("cuda")
     torch.set_grad_enabled(False)
@@ -32,7 +33,7 @@ def main():
     pool = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in S.synthetic_batch(B, H, W, 1234, frame0=j * B).items()} for j in range(4)]
 
     def run(k):
-        for _ in pipe.run_interleaved((pool[i % 4] for i in range(k)), copy_outputs=False, lanes=lanes):
+        for _ in pipe.run_interleaved((pool[i % 4] for i in range(k)), copy_outputs=False, lanes=lanes, frames_per_launch=F):
             pass
         torch.cuda.synchronize()
 
