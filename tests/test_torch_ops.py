@@ -140,3 +140,20 @@ def test_glue_ops_match_torch():
     hd = torch.ops.vidc.head_conv1x1_upsample(xh, hw.cuda(), hb.cuda(), 1, 120, 160, True).cpu()
     ref = F.relu(F.interpolate(F.conv2d(x, hw, hb, padding=1), size=(120, 160), mode="bilinear", align_corners=True))
     assert (hd - ref).abs().max() < 2e-5
+
+
+@pytest.mark.gpu
+def test_raw_stream_accessor_follows_the_current_stream():
+    """`_lib.current_stream()` (the hipStream_t every C entry is handed) reads torch's current stream through the private raw accessor when
+    this torch has it: it must name the same stream as `torch.cuda.current_stream()`, on the default stream and inside stream contexts."""
+    import torch
+    from vi_depth_completion_amd import _lib as L
+    assert L.current_stream() == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert L.current_stream() == side.cuda_stream == torch.cuda.current_stream().cuda_stream
+        inner = torch.cuda.Stream()
+        with torch.cuda.stream(inner):
+            assert L.current_stream() == inner.cuda_stream
+        assert L.current_stream() == side.cuda_stream
+    assert L.current_stream() == torch.cuda.current_stream().cuda_stream

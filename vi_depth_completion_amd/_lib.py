@@ -219,6 +219,19 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = None
+
+
 def current_stream():
+    """Raw hipStream_t of torch's current stream on the current device.  Called once per launch from Python: the private C accessors
+    (no Stream object, no device-index resolution: ~0.3 us instead of ~7 us, 15 calls per frame in the stream modes) when this torch has
+    them, torch.cuda.current_stream() otherwise."""
+    global _raw_stream
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    if _raw_stream is None:
+        get_raw, get_dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if get_raw is not None and get_dev is not None:
+            _raw_stream = lambda: get_raw(get_dev())          # noqa: E731
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream      # noqa: E731
+    return _raw_stream()

@@ -149,21 +149,32 @@ class PlaneBlock:
         self._up1, self._up2 = _Upload(), _Upload()
         self._ctx = None
 
-    def _groups_of(self, id_maps):
+    def _stacked_ids(self, id_maps):
+        """The batch's id maps as ONE (B,H,W) uint8 array, and whether its content differs from the previous batch's (one stack + one
+        comparison of 77 KB per image and batch; `_groups_of` and `_upload_ids` both key on it).  None when a map is not uint8."""
+        if not all(np.asarray(m).dtype == np.uint8 for m in id_maps):
+            return None, True
+        arr = np.stack([np.asarray(m, dtype=np.uint8) for m in id_maps])
+        prev = self._groups_src
+        same = prev is not None and prev.shape == arr.shape and np.array_equal(prev, arr)
+        return arr, not same
+
+    def _groups_of(self, id_maps, stacked=None):
         """plane_groups() of the batch's id maps, recomputed only when their content changed (a fixed mask or a static scene)."""
-        arr = np.stack([np.asarray(m, dtype=np.uint8) for m in id_maps]) if all(np.asarray(m).dtype == np.uint8 for m in id_maps) else None
+        arr, changed = stacked if stacked is not None else self._stacked_ids(id_maps)
         if arr is None:
             return [plane_groups(m) for m in id_maps]
-        if self._groups is None or self._groups_src.shape != arr.shape or not np.array_equal(self._groups_src, arr):
+        if self._groups is None or changed:
             self._groups_src, self._groups = arr, [plane_groups(m) for m in arr]
         return self._groups
 
-    def _upload_ids(self, id_maps, device):
+    def _upload_ids(self, id_maps, device, stacked=None):
         """The (B,H,W) uint8 id maps on the device.  Uploaded only when their CONTENT changed since the last batch (a fixed plane mask, or
         a static scene, costs one 77 KB comparison per batch instead of a host->device copy that waits for the stream), through a pinned
         staging buffer otherwise."""
-        arr = np.stack([np.asarray(m, dtype=np.uint8) for m in id_maps])
-        if self._ids_dev is None or self._ids_dev.device != device or self._ids_host.shape != arr.shape or not np.array_equal(self._ids_host, arr):
+        arr = stacked[0] if (stacked is not None and stacked[0] is not None) else np.stack([np.asarray(m, dtype=np.uint8) for m in id_maps])
+        if self._ids_dev is None or self._ids_dev.device != device or self._ids_host.shape != arr.shape or \
+                (arr is not self._ids_host and not np.array_equal(self._ids_host, arr)):
             if self._ids_dev is None or self._ids_dev.device != device or self._ids_host.shape != arr.shape:
                 self._ids_pinned = torch.empty(arr.shape, dtype=torch.uint8, pin_memory=True)
                 self._ids_dev = torch.empty(arr.shape, dtype=torch.uint8, device=device)
@@ -213,14 +224,17 @@ class PlaneBlock:
         HW = H * W
         dev = normals.device
         ds = ctx["ds"].view(B, HW)
-        slots, hyp, dense_hyp = draw_normal_hypotheses(ctx["ids"], rng, ctx["dense"], groups=self._groups_of(ctx["ids"]))
+        stacked = self._stacked_ids(ctx["ids"])
+        if stacked[0] is not None and not stacked[1]:
+            stacked = (self._groups_src, False)      # unchanged content: the array object both caches already hold
+        slots, hyp, dense_hyp = draw_normal_hypotheses(ctx["ids"], rng, ctx["dense"], groups=self._groups_of(ctx["ids"], stacked))
         n_slots = slots.shape[0]
         bufs = self._buffers(dev, B, HW, n_slots)
         di = bufs["di"]
         di.copy_(ds)
         rec = None
         if n_slots > 0:
-            ids = self._upload_ids(ctx["ids"], dev)
+            ids = self._upload_ids(ctx["ids"], dev, stacked)
             arrays = [slots, hyp]
             if dense_hyp:
                 dh = np.zeros((n_slots, L.MAX_HYP), dtype=np.int32)
