@@ -29,6 +29,10 @@ SHAPES = {  # name: (H, W, cin, cout, k, G, tile, precision)
     "now_l3_3x3_G4_64x64k2d4": (16, 20, 256, 256, 3, 4, 13, 1),
     "f1_3x3_768_128x128d3L": (64, 80, 768, 768, 3, 1, 25, 1),
     "f1_3x3_768_128x128d3": (64, 80, 768, 768, 3, 1, 24, 1),
+    # round 4: two stream items per launch (M = 640), the fp32 leg's tilings (split-K 1 here: the stamps live in the split-K workspace)
+    "b2_l3_1x1_256to1024_G4_fp32": (32, 20, 256, 1024, 1, 4, 29, 0),
+    "b2_l3_1x1_1024to256_G4_fp32": (32, 20, 1024, 256, 1, 4, 32, 0),
+    "b2_l3_3x3_G4_fp32": (32, 20, 256, 256, 3, 4, 28, 0),
 }
 
 

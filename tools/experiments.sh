@@ -448,7 +448,19 @@ import json,sys; d=json.loads(sys.stdin.read()); print('lanes $L K $K:', d['valu
 done; done
 }
 
+r4_waves3() {
+# A/B of a register budget on the 2-deep-ring small conv tiles (csrc/conv_mfma.hip, comment above conv_igemm_f32): build with the
+# amdgpu_waves_per_eu(3) line in place, then:
+python -m pytest tests/test_hip_parity.py -x -q -k "conv_tiles or conv_splitk or conv_is_deterministic or shared_workspace" 2>&1 | tail -3
+for rep in 1 2; do
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sequential-leg --no-extra-legs 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('K20: fp32', d['value'], d['program_ms'], ' mixed', d['value_mixed'], d['mixed_leg']['program_ms'])"
+done
+python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-sequential-leg --no-extra-legs --per-op gpurun_out/r4_per_op_w3.tsv 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('K200: fp32', d['value'], ' mixed', d['value_mixed'])"
+}
+
 case "$1" in
-  list|"") echo "experiments: r3_b r3_c r3_d2 r3_early r3_lds_cap r3_pipelined r3_plane_side r3_prefetch r3_train_add r3_train_bnadd r3_train_dyt r3_train_pack r3_train_retune r3_train_skip r3_train_tail r3_train_tickets r3_train_timeline r3_train_xt r3_train_xt3 r3_tune_b2 r3_tune_b8 r3_tune_b8_lanes r3_tune_detector r3_tune_fp32 r3_tune_fp32_again r3_tune_mixed r3_variants r3_xb r4_bnfold r4_lanes r4_newtests r4_pairing r4_perop r4_stagger r4_timeline" ;;
+  list|"") echo "experiments: r4_waves3 r3_b r3_c r3_d2 r3_early r3_lds_cap r3_pipelined r3_plane_side r3_prefetch r3_train_add r3_train_bnadd r3_train_dyt r3_train_pack r3_train_retune r3_train_skip r3_train_tail r3_train_tickets r3_train_timeline r3_train_xt r3_train_xt3 r3_tune_b2 r3_tune_b8 r3_tune_b8_lanes r3_tune_detector r3_tune_fp32 r3_tune_fp32_again r3_tune_mixed r3_variants r3_xb r4_bnfold r4_lanes r4_newtests r4_pairing r4_perop r4_stagger r4_timeline" ;;
   *) name="$1"; shift; if declare -F "$name" > /dev/null; then "$name" "$@"; else echo "unknown experiment $name (bash tools/experiments.sh list)"; exit 2; fi ;;
 esac
