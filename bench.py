@@ -230,6 +230,8 @@ def measure(args, dev, rank, world, precision):
                 pass                                                                                                                      # is requested: documented lifetime)
         return out
 
+    if args.mode == "interleaved":      # set-up like the weight load above: every lane's program recorded, captured and uploaded before the first step
+        pipe.prepare_interleaved(next(iter(frames(1))), lanes=lanes, frames_per_launch=args.frames_per_launch)
     run(args.warmup)
     torch.cuda.synchronize()
     if world > 1:

@@ -197,3 +197,26 @@ def test_recycled_input_buffers_and_unowned_outputs(seeded_weights, monkeypatch)
         list(pipe.run_interleaved(iter([frames[0], other]), lanes=2, frames_per_launch=2))
     with pytest.raises(ValueError, match="frames_per_launch"):
         list(pipe.run_interleaved(iter(frames[:1]), frames_per_launch=0))
+
+
+def test_prepare_interleaved_builds_every_lane(seeded_weights, monkeypatch):
+    """`prepare_interleaved` records and captures the frame program of every lane up front (bench.py calls it before its warm-up steps:
+    with fewer warm-up items than lanes x items-per-launch a lane's program would otherwise be built inside the timed region); the
+    streams that follow use those programs and give the same bits as before."""
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    monkeypatch.setenv("VIDC_PRECISION", "mixed")
+    p = DepthCompletionPipeline(enriched_samples=200)
+    p.load_state_dicts(seeded_weights["sn"], seeded_weights["dc"])
+    p.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(240, 320))
+    frames = _frames(420, 3)
+    p.prepare_interleaved(frames[0], lanes=3, frames_per_launch=2)
+    cache = p._group_lane_cache
+    progs = [cache[(k, 2)]["prog"] for k in range(3)]
+    assert all(pr.captured for pr in progs) and len({id(pr) for pr in progs}) == 3
+    rng_of = lambda i: np.random.RandomState(31 + i)        # noqa: E731
+    got = [o.cpu() for o in p.run_interleaved(iter(frames), lanes=3, frames_per_launch=2, frame_rng=rng_of)]
+    assert [cache[(k, 2)]["prog"] for k in range(3)] == progs, "the prepared programs are the ones the stream runs"
+    ref = [o.cpu() for o in _pipe(seeded_weights, "mixed").run_interleaved(iter(frames), lanes=1, frames_per_launch=2, frame_rng=rng_of)]
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    p.prepare_interleaved(frames[0], lanes=2, frames_per_launch=1)      # the round-3 scheduler's lanes as well
+    assert p.frame_program(1, 240, 320).captured

@@ -380,6 +380,34 @@ class DepthCompletionPipeline:
             if out is not None:
                 yield out
 
+    @torch.no_grad()
+    def prepare_interleaved(self, sample_batch, lanes=None, frames_per_launch=None):
+        """Builds, captures and uploads the frame programs of EVERY lane of `run_interleaved(lanes, frames_per_launch)` for batches shaped
+        like `sample_batch` (normally that happens when a lane sees its first item).  Set-up, not a step: a stream shorter than
+        lanes x frames_per_launch items would otherwise leave a lane's program to be recorded inside a later stream -- e.g. a timed one."""
+        import os
+        n = int(lanes if lanes is not None else os.environ.get("VIDC_LANES", "1"))
+        fpl = int(frames_per_launch if frames_per_launch is not None else os.environ.get("VIDC_FRAMES_PER_LAUNCH", "1"))
+        if not self.use_gravity:
+            return
+        rgb = sample_batch["image"]
+        if not rgb.is_cuda:
+            rgb = rgb.to(self.device)
+        if fpl > 1 or os.environ.get("VIDC_GROUPED_SCHEDULER", "0") == "1":
+            for k in range(n):
+                lane = _GroupLane(self, k, fpl)
+                with torch.cuda.stream(lane.stream):
+                    lane._prepare(rgb)
+        else:
+            for k in range(n):
+                lane = _Lane(self, k, own_stream=n > 1)
+                if lane.stream is not None:
+                    with torch.cuda.stream(lane.stream):
+                        lane._prepare(rgb)
+                else:
+                    lane._prepare(rgb)
+        torch.cuda.synchronize(self.device)
+
     def _run_grouped(self, batches, copy_outputs, n_lanes, F, frame_rng):
         """run_interleaved with F items per launch (see there).  Group p = items F*p .. F*p+F-1 runs on lane p mod L.  Per lane and group
         the device work is: segment 0 [surface-normal side of group p + depth pyramids of the lane's previous group], the plane kernels
