@@ -460,7 +460,34 @@ python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-sequential-leg --
 import json,sys; d=json.loads(sys.stdin.read()); print('K200: fp32', d['value'], ' mixed', d['value_mixed'])"
 }
 
+r4_schedulers_f1() {
+# round 4: the round-3 scheduler (VIDC_GROUPED_SCHEDULER=0, removed after this run: git history) against the round-4 one at one item per
+# launch -- profiles/r4_schedulers_one_item_per_launch.txt
+for rep in 1 2; do for G in 0 1; do for L in 2 3; do
+VIDC_GROUPED_SCHEDULER=$G python bench.py --steps 20 --warmup 5 --lanes $L --frames-per-launch 1 --no-cpu-baseline --no-sequential-leg --no-extra-legs 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('F=1 grouped=$G lanes $L K20: fp32', d['value'], ' mixed', d['value_mixed'])"
+done; done; done
+for G in 0 1; do
+VIDC_GROUPED_SCHEDULER=$G python bench.py --batch 8 --source 640x480 --height 240 --plane-head --steps 40 --warmup 6 --frames-per-launch 1 --lanes 2 --no-cpu-baseline --no-sequential-leg --no-extra-legs 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('configs[2] grouped=$G: fp32', d['value'], ' mixed', d['value_mixed'])"
+VIDC_GROUPED_SCHEDULER=$G python bench.py --batch 4 --source 1280x720 --height 240 --steps 60 --warmup 6 --frames-per-launch 1 --lanes 2 --no-cpu-baseline --no-sequential-leg --no-extra-legs 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('configs[3] grouped=$G: fp32', d['value'], ' mixed', d['value_mixed'])"
+done
+}
+
+r4_four_items() {
+# round 4: table entries for M = 1280 (isolated tuner), then four items per launch at 20 / 200 / 400 steps -- profiles/r4_four_items_per_launch.txt
+mkdir -p gpurun_out
+timeout 2400 python tools/autotune.py --heights 256 --batches 4 --only-missing --frame-only --out gpurun_out/conv_tuning_f4.json > gpurun_out/r4_autotune_b4_256.log 2>&1
+tail -3 gpurun_out/r4_autotune_b4_256.log
+cp gpurun_out/conv_tuning_f4.json vi_depth_completion_amd/conv_tuning.json
+for L in 2 3; do for K in 20 200 400; do
+python bench.py --steps $K --warmup 8 --lanes $L --frames-per-launch 4 --no-cpu-baseline --no-sequential-leg --no-extra-legs 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('F=4 lanes $L K $K: fp32', d['value'], d['conv_stack']['at_measured_frame_rate']['frac_of_peak_executed'], d['program_ms'], d['first_item_latency_ms'], ' mixed', d['value_mixed'], d['mixed_leg']['program_ms'])"
+done; done
+}
+
 case "$1" in
-  list|"") echo "experiments: r4_waves3 r3_b r3_c r3_d2 r3_early r3_lds_cap r3_pipelined r3_plane_side r3_prefetch r3_train_add r3_train_bnadd r3_train_dyt r3_train_pack r3_train_retune r3_train_skip r3_train_tail r3_train_tickets r3_train_timeline r3_train_xt r3_train_xt3 r3_tune_b2 r3_tune_b8 r3_tune_b8_lanes r3_tune_detector r3_tune_fp32 r3_tune_fp32_again r3_tune_mixed r3_variants r3_xb r4_bnfold r4_lanes r4_newtests r4_pairing r4_perop r4_stagger r4_timeline" ;;
+  list|"") echo "experiments: r4_four_items r4_schedulers_f1 r4_waves3 r3_b r3_c r3_d2 r3_early r3_lds_cap r3_pipelined r3_plane_side r3_prefetch r3_train_add r3_train_bnadd r3_train_dyt r3_train_pack r3_train_retune r3_train_skip r3_train_tail r3_train_tickets r3_train_timeline r3_train_xt r3_train_xt3 r3_tune_b2 r3_tune_b8 r3_tune_b8_lanes r3_tune_detector r3_tune_fp32 r3_tune_fp32_again r3_tune_mixed r3_variants r3_xb r4_bnfold r4_lanes r4_newtests r4_pairing r4_perop r4_stagger r4_timeline" ;;
   *) name="$1"; shift; if declare -F "$name" > /dev/null; then "$name" "$@"; else echo "unknown experiment $name (bash tools/experiments.sh list)"; exit 2; fi ;;
 esac

@@ -748,9 +748,8 @@ template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC, int SPEC>
 __global__ void __launch_bounds__(64 * WMW * WNW * WKW * (SPEC ? 2 : 1))
 // (Round 4 tried a register budget of 168 for the 2-deep-ring small tiles -- amdgpu_waves_per_eu(3): 172 -> 132 VGPRs, no spills, three
 //  workgroups per CU instead of two, so that the 640 workgroups of a layer-3 launch at M = 640 need no second round.  In the frame:
-//  per-op times unchanged within 2 % (layer-3 trio 1687 -> 1715 us per tick in fp32), fp32 stream 362 vs 364 frames/s, and the
-//  three-lane mixed stream fell from 712 to 588 at 20 steps: more small workgroups of OTHER lanes squeeze in beside a lane's large tiles.
-//  Not kept; tools/experiments.sh r4_waves3.)
+//  per-op times unchanged within 2 % (layer-3 trio 1687 -> 1715 us per tick in fp32), fp32 stream 362 vs 364 frames/s: the work per CU
+//  is the same 2.5 workgroups either way.  Not kept; tools/experiments.sh r4_waves3.)
 __attribute__((amdgpu_waves_per_eu((BM == 128 && BN == 128 && NS == 2 && !SPEC) ? 2 : 1)))
 conv_igemm_f32(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

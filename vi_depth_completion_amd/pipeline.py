@@ -256,38 +256,32 @@ class DepthCompletionPipeline:
 
     @torch.no_grad()
     def run_interleaved(self, batches, copy_outputs=True, lanes=None, frames_per_launch=None, frame_rng=None):
-        """Throughput mode, software-pipelined over frames: tick t runs the surface-normal network + plane block of frame
-        t and the depth-completion network of frame t-1 as ONE program (build_frame_program).  Yields the depth map of
-        every batch, in order; n batches take n+1 ticks.  Per frame the arithmetic is that of `_call_cnn` (same kernels;
-        the 4-group launches may use another tile than the 1-/3-group ones, i.e. fp32 sums in a different order), and the
-        RANSAC / enrichment draws come off `self.rng` in the same order as back-to-back `_call_cnn` calls.
+        """Throughput mode, software-pipelined over the items of a stream: a tick runs the surface-normal network + plane block of one
+        group of items and the depth-completion network of the previous group as ONE program (build_frame_program).  Yields the depth
+        map of every batch, in order.  Per item the arithmetic is that of `_call_cnn` (same kernels; the 4-group launches may use
+        another tile than the 1- / 3-group ones, i.e. fp32 sums in a different order), and the RANSAC / enrichment draws come off
+        `self.rng` in the order of back-to-back `_call_cnn` calls.  Scheduler: `_run_grouped`.
 
-        lanes = L > 1 (default: VIDC_LANES, else 1) runs L such pipelines on L HIP streams, frame i on lane i mod L, each with its
-        own program buffers and plane-block scratch: at batch 1 two thirds of a small-layer launch is fixed cost (dispatch, first
-        weight stage from HBM, split-K epilogue, drain) during which most CUs idle, and the launches of another lane fill those
-        holes; the host's one wait per frame (for its enrichment candidate counts) is deferred to the next visit, after that visit's
-        segment has been launched, so the GPU never idles under it (453 -> 617 frames/s with two lanes at 320x256,
-        batch 1; a third lane adds 1 %).  Ticks are issued strictly in frame order from this one host thread, so the random draws
-        come off `self.rng` exactly as with one lane and every frame's result is bit-identical to the single-lane stream's (tested).
-        Outputs are still yielded in frame order, a lane's one round (L requests) later than with one lane; the caller's current
-        stream waits (on the device) for the tick that produced one.
+        lanes = L (default: VIDC_LANES, else 1): L such pipelines on L HIP streams, group p on lane p mod L, each with its own program
+        buffers and plane-block scratch: the fixed cost of a small-layer launch (dispatch, first weight stage from HBM, split-K
+        epilogue, drain) and the launch-bound plane kernels between a lane's segments are filled by the other lanes' launches.  The
+        draws are issued strictly in item order from this one host thread, so every item's result is bit-identical for every L.
 
-        Data movement per tick: the frame is copied into the program's input buffer once (and from there to the depth
-        network's image input one tick later, device to device); the normals and the enriched sparse depth are WRITTEN where the
-        next tick reads them (no copies).  The caller's tensors are not referenced after the call that consumed them (with L > 1 a
-        device-resident `sparse_depth` is copied once: its enrichment is finished one visit later, when the caller may have refilled
-        the buffer).
-        copy_outputs=False hands out the program's own output buffer: valid ONLY until the next item is requested, for every L (the
-        yielding lane's next visit relaunches its depth decoder into that buffer).
+        frames_per_launch = F (default: VIDC_FRAMES_PER_LAUNCH, else 1): F consecutive items share every launch of a tick: the lane's
+        frame program is recorded for batch F x B and items F*p .. F*p+F-1 occupy its batch slots, so a batch-1 stream runs its
+        ResNet-101 layer-3 convolutions at M = 640 (F = 2) instead of 320 -- half the launches per frame, each above the per-launch
+        floor that bounds them at batch 1.  The items stay what the API hands in (main.py:261-298 semantics per item: own
+        gravity, own plane block, own draws); a stream whose length is not a multiple of F runs its tail through the SAME program with
+        the unused slots holding stale frames, so an item's bits do not depend on whether it had a partner, on which slot it took, or
+        on the shard it was part of (rows of an implicit GEMM do not interact; tile, split-K and K order are the launch's).
 
-        frames_per_launch = F > 1 (default: VIDC_FRAMES_PER_LAUNCH, else 1): F consecutive items of the stream share every launch of a
-        tick (`_run_grouped`): the lane's frame program is recorded for batch F x B and items F*p .. F*p+F-1 occupy its batch slots, so
-        a batch-1 stream runs its ResNet-101 layer-3 convolutions at M = 640 instead of 320 -- half the launches per frame, each above
-        the per-launch floor that bounds them at batch 1.  The items stay what the API hands in (main.py:261-298 semantics
-        per item: own gravity, own plane block, own draws in `_call_cnn` order); a stream whose length is not a multiple of F runs its
-        tail through the SAME program with the unused slots holding stale frames, so an item's bits do not depend on whether it had
-        a partner, on which slot it took, or on the shard it was part of (rows of an implicit GEMM do not interact; tile, split-K and K
-        order are the launch's).  frame_rng(i) -> generator: item i draws from its own generator instead of `self.rng`."""
+        frame_rng(i) -> generator: item i draws from its own generator instead of `self.rng`.
+
+        Data movement: an item is copied into its batch slot when it is pulled from `batches` (image, gravity, alignment, sparse depth,
+        homogeneous grid: the caller may refill its tensors as soon as the next item is requested); the normals and the enriched
+        sparse depth are WRITTEN where the lane's next tick reads them (no copies).  Outputs come out in item order, a group at a
+        time, one lane round after their inputs went in; the caller's current stream waits (on the device) for the tick that produced
+        them.  copy_outputs=False hands out views of the lane's own output buffer: valid ONLY until the next item is requested."""
         import os
         if not self.use_gravity:
             yield from self._run_interleaved_two_programs(batches, copy_outputs)
@@ -298,87 +292,7 @@ class DepthCompletionPipeline:
         fpl = int(frames_per_launch if frames_per_launch is not None else os.environ.get("VIDC_FRAMES_PER_LAUNCH", "1"))
         if fpl < 1:
             raise ValueError("run_interleaved: frames_per_launch must be >= 1")
-        if fpl > 1 or frame_rng is not None or os.environ.get("VIDC_GROUPED_SCHEDULER", "0") == "1":
-            yield from self._run_grouped(batches, copy_outputs, n, fpl, frame_rng)
-            return
-        lane_objs = [_Lane(self, k, own_stream=n > 1) for k in range(n)]
-        k = 0
-        if n == 1:                              # on the caller's stream; an output is handed out by the tick that computed it
-            for batch in batches:
-                out = lane_objs[0]._tick(batch, copy_outputs)
-                if out is not None:
-                    yield out
-            out = lane_objs[0]._tick(None, copy_outputs)
-            if out is not None:
-                yield out
-            return
-        # L lanes: a lane's output is handed out at the START of its next visit (the caller's stream then waits for a tick that was
-        # issued a whole round ago and has mostly run), never right after its own tick -- a wait for the tick just issued, sitting on
-        # the caller's stream, would make the next lane (which must wait for the caller's stream: its inputs come from there) wait for
-        # it too and serialise the lanes.
-        # The one host synchronisation of a frame -- reading its enrichment candidate counts -- is also DEFERRED by one visit: frame i's
-        # surface-normal segment is launched in visit i, its counts are awaited in visit i+1 AFTER frame i+1's surface-normal segment
-        # has been launched (on the other lane), so the GPU always has a segment queued while the host waits.  The draws keep their
-        # order -- hypotheses(i), enrichment(i), hypotheses(i+1), ... -- because enrichment(i) is drawn before hypotheses(i+1) in that
-        # visit; the enrichment kernel only has to precede frame i+L's segment on its own lane, which is launched L - 1 visits later.
-        waiting = None                          # the lane whose last frame still needs its enrichment
-        # Start of the stream: the first frame of EVERY lane is taken at once and its first segment launched (no random numbers, no host
-        # wait in phase_a) before the host turns to the hypothesis draws of frame 0 -- otherwise lane 1 would sit idle through them.
-        batches = iter(batches)
-        first = []
-        for _ in range(n):
-            try:
-                first.append(next(batches))
-            except StopIteration:
-                break
-        for j, batch in enumerate(first):
-            lane_objs[j].phase_a(batch)
-        # ... and a lane whose first frame has just been enriched takes its NEXT frame at once (segment 0 needs nothing else), before the
-        # host turns to the next lane's hypothesis draws: during the fill a lane has no depth decoder queued that would cover them.
-        started = []                            # batches whose phase_a has already run (in stream order)
-        early = os.environ.get("VIDC_EARLY_SECOND_FRAME", "1") == "1" and len(first) == n
-        for j in range(len(first)):
-            lane = lane_objs[j]
-            k += 1
-            if waiting is not None:
-                waiting.finish_enrich()
-                if early:
-                    nxt = next(batches, None)
-                    if nxt is not None:
-                        waiting.phase_a(nxt)    # (the lane has no output to hand out yet: this is its second frame)
-                        started.append(nxt)
-                    else:
-                        early = False
-            lane.phase_b(copy_outputs)
-            waiting = lane if lane.pending_enrich is not None else None
-        import itertools
-        for idx, batch in enumerate(itertools.chain(list(started), batches)):
-            lane = lane_objs[k % n]
-            k += 1
-            if idx >= len(started):             # (else: segment 0 of this frame is already running)
-                out = lane.collect()
-                if out is not None:
-                    yield out
-                lane.phase_a(batch)
-            if waiting is not None:
-                waiting.finish_enrich()
-            lane.phase_b(copy_outputs)
-            waiting = lane if lane.pending_enrich is not None else None
-        for j in range(n):                      # drain ticks, oldest pending frame first
-            lane = lane_objs[(k + j) % n]
-            if lane is waiting:                 # (the lane of the LAST frame, drained last: the other lanes' drain ticks -- which draw
-                waiting.finish_enrich()         #  nothing and whose frames are already enriched -- are queued before the host waits for
-                waiting = None                  #  that frame's counts, so its surface-normal segment does not run alone)
-            out = lane.collect()
-            if out is not None:
-                yield out
-            lane.launch(None, copy_outputs)
-        if waiting is not None:
-            waiting.finish_enrich()
-        for j in range(n):
-            out = lane_objs[(k + j) % n].collect()
-            if out is not None:
-                yield out
+        yield from self._run_grouped(batches, copy_outputs, n, fpl, frame_rng)
 
     @torch.no_grad()
     def prepare_interleaved(self, sample_batch, lanes=None, frames_per_launch=None):
@@ -393,19 +307,10 @@ class DepthCompletionPipeline:
         rgb = sample_batch["image"]
         if not rgb.is_cuda:
             rgb = rgb.to(self.device)
-        if fpl > 1 or os.environ.get("VIDC_GROUPED_SCHEDULER", "0") == "1":
-            for k in range(n):
-                lane = _GroupLane(self, k, fpl)
-                with torch.cuda.stream(lane.stream):
-                    lane._prepare(rgb)
-        else:
-            for k in range(n):
-                lane = _Lane(self, k, own_stream=n > 1)
-                if lane.stream is not None:
-                    with torch.cuda.stream(lane.stream):
-                        lane._prepare(rgb)
-                else:
-                    lane._prepare(rgb)
+        for k in range(n):
+            lane = _GroupLane(self, k, fpl)
+            with torch.cuda.stream(lane.stream):
+                lane._prepare(rgb)
         torch.cuda.synchronize(self.device)
 
     def _run_grouped(self, batches, copy_outputs, n_lanes, F, frame_rng):
@@ -586,202 +491,6 @@ class DepthCompletionPipeline:
             out, sj["out"] = sj["out"], None
             main.wait_stream(sj["stream"])
             yield out
-
-
-class _Lane:
-    """One software-pipelined frame stream of `DepthCompletionPipeline.run_interleaved`: its frame program (cached on the pipeline per
-    lane index), its plane-block scratch, optionally its own HIP stream, and the one frame whose depth network is still pending."""
-
-    def __init__(self, pipe, index, own_stream):
-        self.pipe, self.index = pipe, index
-        self.prog, self.shape0, self.have_prev, self.pending_out, self.pending_enrich, self._frame = None, None, False, None, None, None
-        self._ds_own = None
-        self._stage = pipe.__dict__.setdefault("_lane_stagers", {}).setdefault(index, _Stager())
-        cache = pipe.__dict__.setdefault("_lane_cache", {})
-        ent = cache.setdefault(index, {})
-        self.cache = ent
-        if "planes" not in ent:
-            ent["planes"] = pipe.planes if index == 0 else PlaneBlock()
-        if own_stream and "stream" not in ent:
-            ent["stream"] = torch.cuda.Stream(device=pipe.device)
-        self.planes = ent["planes"]
-        self.stream = ent.get("stream") if own_stream else None
-
-    def _program(self, B, H, W):
-        p = self.pipe
-        if self.index == 0:
-            return p.frame_program(B, H, W)
-        key = (B, H, W, p.surface_normal_cnn._version, p.cnn._version, p.surface_normal_cnn.warp_2dof_alignment.align_corners)
-        if self.cache.get("prog_key") != key:
-            self.cache["prog"] = build_frame_program(p.surface_normal_cnn, p.cnn, B, H, W, p.device)
-            self.cache["prog_key"] = key
-        return self.cache["prog"]
-
-    def launch(self, batch, copy_outputs):
-        """(lanes > 1) one whole tick on this lane's stream (the drain ticks); the output it computes, if any, is kept for `collect`."""
-        self.stream.wait_stream(torch.cuda.current_stream())      # the batch comes from the caller's stream, and whoever read the
-        with torch.cuda.stream(self.stream):                      # previous output out of the program's buffer did so there
-            self._keep_output(self._tick(batch, copy_outputs))
-
-    def _keep_output(self, out):
-        if out is not None:
-            ev = torch.cuda.Event()
-            ev.record()
-            self.pending_out = (out, ev)
-
-    def phase_a(self, batch):
-        """(lanes > 1) first half of a tick: the frame into the program's inputs and segment 0 (all four pyramids + the surface-normal
-        decoder) launched.  Nothing here draws random numbers or waits for the device."""
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            pipe, dev = self.pipe, self.pipe.device
-            rgb = self._stage("image", batch["image"], dev)
-            ds = self._stage("sparse_depth", batch["sparse_depth"], dev)
-            if ds is batch["sparse_depth"]:               # the caller's own device tensor: finish_enrich reads it one visit later, by when a
-                if self._ds_own is None or self._ds_own.shape != ds.shape:      # caller that refills a fixed input buffer holds the NEXT frame
-                    self._ds_own = torch.empty_like(ds)
-                self._ds_own.copy_(ds, non_blocking=True)
-                ds = self._ds_own
-            self._prepare(rgb)
-            prog = self.prog
-            if self.have_prev:
-                self.dc_image.copy_(self.sn_image, non_blocking=True)
-            mh = pipe._masks_begin(rgb, key=("lane", self.index)) if pipe.args.enriched_samples != 0 else None
-            self.sn_image.copy_(rgb, non_blocking=True)
-            self.grav.copy_(self._stage("gravity", batch["gravity"], dev).reshape(-1), non_blocking=True)
-            self.algn.copy_(self._stage("aligned_direction", batch["aligned_direction"], dev).reshape(-1), non_blocking=True)
-            self._segment0(new_frame=True)
-            self._frame = (batch, rgb, ds, mh)
-
-    def phase_b(self, copy_outputs):
-        """Second half: hypothesis draws + plane kernels of the frame, the asynchronous read of its candidate counts, then segment 1
-        (the depth decoder of the lane's previous frame).  The enrichment itself waits for `finish_enrich`."""
-        with torch.cuda.stream(self.stream):
-            pipe, prog = self.pipe, self.prog
-            batch, rgb, ds, mh = self._frame
-            self._frame = None
-            _, _, H, W = rgb.shape
-            if pipe.args.enriched_samples != 0:
-                normals = prog.tensor(prog.outputs["normals"])
-                homo = self._stage("homogeneous_coordinates", batch["homogeneous_coordinates"], pipe.device)
-                masks = pipe._masks_end(mh, batch["image"], H, W)
-                di, info = self.planes.plane_depth(normals, masks, ds, homo, rng=pipe.rng)
-                self.pending_enrich = (ds, di, info, self.planes.read_info_async(info))
-            else:
-                self.dc_depth.copy_(ds, non_blocking=True)
-            out = None
-            if self.have_prev:
-                prog.launch_segment(1) if prog.captured else prog.run_segment(1)
-                out = prog.tensor(prog.outputs["depth"])
-                out = out.clone() if copy_outputs else out
-            self.have_prev = True
-            self._keep_output(out)
-
-    def finish_enrich(self):
-        """Waits for the frame's candidate counts, draws its enrichment samples and writes the enriched depth where the lane's next
-        segment 0 reads it."""
-        if self.pending_enrich is None:
-            return
-        ds, di, info, info_host = self.pending_enrich
-        self.pending_enrich = None
-        with torch.cuda.stream(self.stream):
-            self.planes.enrich(ds, di, info, self.pipe.args.enriched_samples, rng=self.pipe.rng, info_host=info_host, out=self.dc_depth)
-
-    def _prepare(self, rgb):
-        """Builds / captures the lane's frame program at the first frame, checks the shape afterwards."""
-        import os
-        pipe = self.pipe
-        B, _, H, W = rgb.shape
-        if self.prog is not None:
-            if (B, H, W) != self.shape0:
-                raise ValueError("run_interleaved: all batches of a stream must have the same shape (got %s after %s); "
-                                 "start a new stream for the remainder" % ((B, H, W), self.shape0))
-            return
-        self.shape0 = (B, H, W)
-        prog = self.prog = self._program(B, H, W)
-        pipe.surface_normal_cnn._check(rgb)
-        pipe.cnn._check(rgb)
-        if not prog.captured and os.environ.get("VIDC_EXEC", "graph") == "graph":
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                prog.run()            # warm-up outside capture (sets kernel attributes)
-                prog.check_chains()
-                prog.capture_segments()
-                for vname in ("head", "tail"):
-                    if prog.has_variant(vname):
-                        prog.capture_variant(vname)
-            torch.cuda.current_stream().wait_stream(side)
-        self.sn_image, self.dc_image = prog.tensor(prog.inputs["sn_image"]), prog.tensor(prog.inputs["dc_image"])
-        self.dc_depth = prog.tensor(prog.inputs["dc_depth"])
-        self.grav = prog.storage[prog.inputs["gravity"].buf][: B * 3]
-        self.algn = prog.storage[prog.inputs["aligned"].buf][: B * 3]
-
-    def _segment0(self, new_frame):
-        """Segment 0 of the tick on the current stream: all four pyramids + the surface-normal decoder -- or, at the two ends of a
-        stream, only the part that has work: the surface-normal side when no previous frame waits for its depth network (first tick),
-        the three depth-completion pyramids when no new frame came (drain tick).  Bit-identical per frame (engine.group_variant)."""
-        prog = self.prog
-        if new_frame and not self.have_prev and prog.has_variant("head"):
-            prog.launch_variant("head") if prog.captured else prog.run_variant("head")
-        elif not new_frame and prog.has_variant("tail"):
-            prog.launch_variant("tail") if prog.captured else prog.run_variant("tail")
-        else:
-            prog.launch_segment(0) if prog.captured else prog.run_segment(0)
-
-    def collect(self):
-        if self.pending_out is None:
-            return None
-        out, ev = self.pending_out
-        self.pending_out = None
-        torch.cuda.current_stream().wait_event(ev)                # device-side: readers on the caller's stream find `out` complete
-        return out
-
-    def _tick(self, batch, copy_outputs):
-        import os
-        pipe = self.pipe
-        dev = pipe.device
-        if batch is not None:
-            rgb = self._stage("image", batch["image"], dev)
-            ds = self._stage("sparse_depth", batch["sparse_depth"], dev)
-            B, _, H, W = rgb.shape
-            self._prepare(rgb)
-        elif self.prog is None or not self.have_prev:
-            return None
-        prog = self.prog
-        graph = prog.captured
-        have_prev = self.have_prev
-        if have_prev:             # frame t-1's image is still in the surface-normal input buffer; its normals and its enriched
-            self.dc_image.copy_(self.sn_image, non_blocking=True)       # depth were written in place by the previous tick
-        pending = None
-        if batch is not None:
-            mh = pipe._masks_begin(rgb) if pipe.args.enriched_samples != 0 else None    # ids reach the host while segment 0 runs
-            self.sn_image.copy_(rgb, non_blocking=True)
-            self.grav.copy_(self._stage("gravity", batch["gravity"], dev).reshape(-1), non_blocking=True)
-            self.algn.copy_(self._stage("aligned_direction", batch["aligned_direction"], dev).reshape(-1), non_blocking=True)
-            self._segment0(new_frame=True)
-            normals = prog.tensor(prog.outputs["normals"])
-            if pipe.args.enriched_samples != 0:
-                homo = self._stage("homogeneous_coordinates", batch["homogeneous_coordinates"], dev)
-                masks = pipe._masks_end(mh, batch["image"], H, W)
-                di, info = self.planes.plane_depth(normals, masks, ds, homo, rng=pipe.rng)
-                pending = (di, info, self.planes.read_info_async(info))
-            else:
-                self.dc_depth.copy_(ds, non_blocking=True)     # (segment 0 above has read the previous frame's depth input)
-        elif have_prev:
-            # drain tick: no new frame; only the three depth-completion pyramids of segment 0 run (the "tail" variant)
-            self._segment0(new_frame=False)
-        if have_prev:
-            prog.launch_segment(1) if graph else prog.run_segment(1)
-        if pending is not None:
-            di, info, info_host = pending       # the host waits for the counts while segment 1 keeps the GPU busy;
-            self.planes.enrich(ds, di, info, pipe.args.enriched_samples, rng=pipe.rng, info_host=info_host, out=self.dc_depth)   # written in place
-        out = None
-        if have_prev:
-            out = prog.tensor(prog.outputs["depth"])
-            out = out.clone() if copy_outputs else out
-        self.have_prev = batch is not None
-        return out
 
 
 class _GroupLane:
