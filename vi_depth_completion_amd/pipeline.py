@@ -394,7 +394,12 @@ class DepthCompletionPipeline:
         the depth network of frame t-1.  Host order per visit: launch normals(t) [no random numbers], wait for frame t-1's candidate
         counts, draw enrichment(t-1), launch depth(t-1), draw hypotheses(t), launch planes(t) -- the generator is consumed in the order
         hypotheses(0), enrichment(0), hypotheses(1), ... of back-to-back `_call_cnn` calls, and the programs are `_call_cnn`'s own, so
-        every frame's depth map is bit-identical to the sequential path's (tests/test_dorn.py)."""
+        every frame's depth map is bit-identical to the sequential path's (tests/test_dorn.py).
+        Measured (round 4, tools/dorn_stream_rate.py, after depth(t-1) was made to wait for frame t-1's own work only instead of for all
+        of stream A): 243 frames/s against 249 for back-to-back `_call_cnn` -- NO gain.  Two different batch-1 programs side by side
+        alternate on the CUs rather than share them (a conv workgroup reserves 48-128 KB of LDS), and what the joint 4-group program of
+        the gravity path gains comes from sharing LAUNCHES, which these two networks cannot.  The mode is kept for the API (a stream
+        of batches in, depth maps out, draw order preserved); it is not a throughput mode."""
         dev = self.device
         if getattr(self, "_two", None) is None:
             self._two = {"a": torch.cuda.Stream(device=dev), "b": torch.cuda.Stream(device=dev), "planes": [PlaneBlock(), PlaneBlock()]}
