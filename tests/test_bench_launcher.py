@@ -133,3 +133,45 @@ print("RCCL_WORLD1_OK")
 ''' % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=_env(HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout + r.stderr)[-4000:]
+
+
+def test_extra_legs_can_never_take_the_headline_down(monkeypatch):
+    """`bench.run_extra_legs` (the driver-visible configs[4] / configs[2] numbers appended to the default N = 1 line) runs each leg as a
+    child process and records whatever happens -- a crash, a hang past the timeout, unparsable output, an exhausted wall-clock budget --
+    as data; nothing is raised into the process that is about to print the headline.  No GPU: the child is faked."""
+    import argparse
+    import importlib
+    import time
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    calls = []
+
+    def fake_run(cmd, **kw):
+        calls.append((cmd, kw))
+        k = len(calls)
+        if k == 1:
+            return subprocess.CompletedProcess(cmd, 0, stdout='noise\n{"metric": "training frames/sec", "value": 290.4, "unit": "frames/s", "steps": 5, "warmup": 3, '
+                                               '"ms_per_step": 27.5, "dtype": "bf16", "losses": [1.0, 0.9], "roofline": {"bound": "mfma", "achieved": 216.0, "peak": 2500.0, '
+                                               '"unit": "TFLOP/s", "frac": 0.0864}, "config": {"workload": "w"}}\n', stderr="")
+        raise subprocess.TimeoutExpired(cmd, kw.get("timeout"))
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(bench, "_T0", time.perf_counter())
+    out = bench.run_extra_legs(argparse.Namespace(extra_legs_budget=75.0))
+    names = list(out)
+    assert len(names) == 2 and "configs[4]" in names[0] and "configs[2]" in names[1]
+    assert out[names[0]]["value"] == 290.4 and out[names[0]]["dtype"] == "bf16" and out[names[0]]["roofline"]["frac"] == 0.0864
+    assert "--train" in out[names[0]]["command"] and "VIDC_TRAIN_PRECISION=bf16" in out[names[0]]["command"]
+    assert "TimeoutExpired" in out[names[1]]["error"]
+    assert all(kw.get("timeout") and kw.get("capture_output") for _c, kw in calls)
+    assert all("--no-extra-legs" in c or "--train" in c for c, _kw in calls), "a child must not start grandchildren"
+    for env in (kw["env"] for _c, kw in calls):
+        assert "RANK" not in env and "VIDC_PRECISION" not in env
+    # a failing child and an exhausted budget
+    calls.clear()
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: subprocess.CompletedProcess(cmd, 139, stdout="", stderr="Segmentation fault"))
+    out = bench.run_extra_legs(argparse.Namespace(extra_legs_budget=75.0))
+    assert all("exit code 139" in v["error"] for v in out.values())
+    monkeypatch.setattr(bench, "_T0", time.perf_counter() - 1000.0)
+    out = bench.run_extra_legs(argparse.Namespace(extra_legs_budget=75.0))
+    assert all("skipped" in v for v in out.values())
