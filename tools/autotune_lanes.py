@@ -34,6 +34,7 @@ def main():
                     help="fp32: tune the exact-fp32 configuration of a signature (entries [3], [4] of the table; VIDC_PRECISION=fp32 programs)")
     ap.add_argument("--max-bm", type=int, default=0, help="only tiles whose BM is at most this (0: the default M-based bound)")
     ap.add_argument("--tiles", default="", help="comma-separated tile ids: only these are tried (default: all)")
+    ap.add_argument("--streams", type=int, default=2, help="frame programs replayed side by side (round 4: bench.py's fp32 leg runs 3 lanes)")
     ap.add_argument("--out", default=OUT)
     a = ap.parse_args()
     os.environ["VIDC_PRECISION"] = a.precision
@@ -44,7 +45,7 @@ def main():
     pipe = DepthCompletionPipeline(enriched_samples=200, cc_img=cc, device=dev)
     table = engine.tuning_table()
     ws = engine.JointWeightStore({"sn": pipe.surface_normal_cnn, "dc": pipe.cnn})
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    streams = [torch.cuda.Stream() for _ in range(a.streams)]
     t_start = time.perf_counter()
 
     def build():
@@ -70,13 +71,13 @@ def main():
         for _ in range(2):
             t0 = time.perf_counter()
             burst(iters)
-            ms = 1e3 * (time.perf_counter() - t0) / (2 * iters)
+            ms = 1e3 * (time.perf_counter() - t0) / (len(streams) * iters)
             best = ms if best is None else min(best, ms)
         return best
 
     progs = build()
     base = pair_ms(progs, a.iters)
-    print("two lanes: %.3f ms per frame with the committed table" % base, flush=True)
+    print("%d lanes: %.3f ms per program execution (batch %d) with the committed table" % (len(streams), base, B), flush=True)
     total, per = progs[0].time(iters=5, use_graph=False, per_op=True, stream=streams[0].cuda_stream)
     by_sig = {}
     for n, t in zip(progs[0].op_names, per):
