@@ -79,7 +79,11 @@ enum vidc_conv_flags {
     VIDC_ACCUM = 32,       /* y += result (z1+z2+z3+z4, surface_normal.py:168)                */
     VIDC_SPLIT_OUT = 64,   /* also write the split-bf16 image of the result to y_split (layout of y,
                               same channel stride) so a following bf16x3 conv needs no split pass */
-    VIDC_NO_F32_OUT = 128  /* with SPLIT_OUT: skip the fp32 store (nobody reads it)              */
+    VIDC_NO_F32_OUT = 128, /* with SPLIT_OUT: skip the fp32 store (nobody reads it)              */
+    VIDC_STATS_OUT = 256   /* training, VIDC_PREC_BF16 only, groups == 1, no second affine / residual / accumulate / split output:
+                              `y_split` points to ceil(M / 32) x 2 x Cout doubles and receives, per block of 32 output rows, the
+                              per-channel sum and sum of squares of the fp32 result -- the partials vidc_bn_train_forward_stats
+                              reduces, so the train-mode BatchNorm behind the conv needs no pass of its own over the tensor */
 };
 
 /* Fused nn.Conv2d(+bias) -> BatchNorm2d(eval) -> ReLU [-> BatchNorm2d -> ReLU] [+ identity -> ReLU].
@@ -110,7 +114,7 @@ typedef struct vidc_conv_desc {
                               hi|lo bf16 images made by vidc_split_bf16x3 /
                               vidc_pack_conv_weight_bf16x3 (same strides as fp32)     */
     int32_t dilation;      /* tap spacing of the kernel (nn.Conv2d dilation); 0 or 1 = dense                  */
-    void* y_split;         /* split-bf16 image of y (VIDC_SPLIT_OUT), or NULL         */
+    void* y_split;         /* split-bf16 image of y (VIDC_SPLIT_OUT), the channel-sum partials (VIDC_STATS_OUT), or NULL */
 } vidc_conv_desc;
 
 /* Workgroup tilings (BM x BN output tile; _Kn = n k-slices reduced inside the workgroup through LDS). */
@@ -427,6 +431,11 @@ int vidc_bn_train_forward(const float* x, float* y, long long M, int C, int ldx,
 int vidc_bn_train_forward_add(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
                               void* y_bf16, const float* residual, int ldr, void* scratch, vidc_stream_t stream);
+/* vidc_bn_train_forward_add for an x that is the output of a conv launched with VIDC_STATS_OUT: `conv_stats` = that conv's partials
+ * (ceil(M / 32) x 2 x C doubles); the partial-sum pass over x is skipped.  scratch: 2 * C doubles. */
+int vidc_bn_train_forward_stats(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
+                                void* y_bf16, const float* residual, int ldr, const void* conv_stats, void* scratch, vidc_stream_t stream);
 /* Its backward.  y_relu: the forward output when a ReLU followed (its mask is applied to dy), else NULL.  dx may alias dy.
  * dx_bf16 (may be NULL): dx as dense bf16 rows as well (the dgrad conv of the layer in front reads it). */
 int vidc_bn_train_backward(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,

@@ -867,3 +867,117 @@ def test_folded_batchnorm_reduction_is_bit_identical(golden_dir, seeded_weights,
             assert torch.equal(v, runs[0][2][k]), k
     finally:
         lib.vidc_train_bn_fold(0)
+
+
+@gpu
+@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,tile,splitk", [(64, 64, 3, 1, 1, 12, 20, 4, 1), (128, 128, 1, 1, 0, 9, 7, 6, 1), (192, 64, 3, 2, 1, 11, 13, 2, 1),
+                                                                   (64, 128, 3, 1, 1, 16, 16, 1, 2), (128, 96, 3, 1, 1, 15, 20, 29, 3), (64, 256, 1, 1, 0, 15, 20, 28, 1),
+                                                                   (128, 128, 3, 1, 1, 17, 19, 33, 1), (192, 128, 3, 2, 1, 21, 13, 36, 2), (64, 64, 3, 1, 1, 30, 40, 26, 1)])
+def test_conv_epilogue_channel_sums(cin, cout, k, stride, pad, H, W, tile, splitk):
+    """VIDC_STATS_OUT (round 4, plain-bf16 training mode): the conv's epilogue also writes, per block of 32 output rows, the per-channel
+    sum and sum of squares of the fp32 values it stores -- the partials of the train-mode BatchNorm behind it.  Against fp64 sums of the
+    conv's OWN output (bias included), block by block: equal up to fp64 rounding (the summation order inside a block differs), for M not
+    a multiple of 32 / of the tile, split-K (only the workgroup that finishes a tile contributes), loader-wave and pipelined tilings.
+    Then `vidc_bn_train_forward_stats` on those partials against `vidc_bn_train_forward_add` on the same tensor."""
+    from vi_depth_completion_amd import _lib as L
+    import ctypes as C
+    lib, st = L.lib(), L.current_stream()
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    bias = torch.randn(cout, generator=g).to(DEV)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    M = B * Ho * Wo
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    xb = torch.empty(B, H, W, cin // 2, device=DEV)
+    L.check(lib.vidc_cast_bf16(L.ptr(xd), L.ptr(xb), B * H * W, cin, cin, st), "cast")
+    wd = w.to(DEV)
+    wp = torch.empty(w.numel() // 2, device=DEV)
+    item = (L.PackItem * 1)()
+    item[0].w, item[0].packed, item[0].Cout, item[0].Cin, item[0].KH, item[0].KW, item[0].kind, item[0].block_begin = L.ptr(wd), L.ptr(wp), cout, cin, k, k, 4, 0
+    dev = torch.frombuffer(bytearray(bytes(item)), dtype=torch.uint8).to(DEV)
+    L.check(lib.vidc_pack_conv_weights_batched(L.ptr(dev), 1, lib.vidc_pack_item_blocks(cout, cin, k, k, 4), st), "pack")
+    ones = torch.ones(cout, device=DEV)
+    nch = (M + 31) // 32
+    outs = []
+    for with_stats in (False, True):
+        y = torch.empty(B, Ho, Wo, cout, device=DEV)
+        stats = torch.full((nch, 2, cout), float("nan"), dtype=torch.float64, device=DEV)
+        d = L.ConvDesc()
+        d.x, d.w, d.y, d.scale1, d.shift1 = L.ptr(xb), L.ptr(wp), L.ptr(y), L.ptr(ones), L.ptr(bias)
+        d.B, d.H, d.W, d.Cin, d.ldx = B, H, W, cin // 2, cin // 2
+        d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, cout, cout
+        d.KH, d.KW, d.stride, d.pad = k, k, stride, pad
+        d.flags = L.STATS_OUT if with_stats else 0
+        d.y_split = L.ptr(stats) if with_stats else None
+        d.groups, d.splitk, d.precision, d.tile = 1, splitk, L.PREC_BF16, tile
+        d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin // 2, cout * k * k * cin // 2, cout, cout
+        if splitk > 1:
+            ws = torch.zeros(lib.vidc_conv2d_workspace_bytes(C.byref(d)) // 4 + 4, device=DEV)
+            d.workspace = L.ptr(ws)
+        L.check(lib.vidc_conv2d_bn_act(C.byref(d), st), "conv bf16 + stats")
+        outs.append((y.cpu(), stats.cpu()))
+    (y0, _), (y1, stats) = outs
+    assert torch.equal(y0, y1), "the flag must not change the conv's output"
+    assert torch.isfinite(stats).all(), "every block of every channel is written exactly by the workgroup that finishes its tile"
+    rows = y1.reshape(M, cout).double()
+    pad_rows = torch.cat([rows, torch.zeros(nch * 32 - M, cout, dtype=torch.float64)]).reshape(nch, 32, cout)
+    want = torch.stack([pad_rows.sum(1), (pad_rows * pad_rows).sum(1)], dim=1)
+    scale = want.abs().max().item()
+    assert float((stats - want).abs().max()) < 1e-12 * max(scale, 1.0), float((stats - want).abs().max())
+    # the BatchNorm forward on the conv's partials against the one that makes its own
+    yd = y1.to(DEV)
+    gamma, beta = (torch.rand(cout, generator=g) + 0.5).to(DEV), torch.randn(cout, generator=g).to(DEV) * 0.1
+    res = []
+    for use_stats in (False, True):
+        z = torch.empty_like(yd)
+        mean, rstd = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+        rm, rv = torch.full((cout,), 0.25, device=DEV), torch.full((cout,), 1.5, device=DEV)
+        sc = torch.empty(lib.vidc_train_scratch_bytes(M, cout), dtype=torch.uint8, device=DEV)
+        if use_stats:
+            L.check(lib.vidc_bn_train_forward_stats(L.ptr(yd), L.ptr(z), M, cout, cout, cout, L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), 1e-5, 0.1, 1,
+                                                    L.ptr(mean), L.ptr(rstd), None, None, 0, L.ptr(stats.to(DEV)), L.ptr(sc), st), "bn stats")
+        else:
+            L.check(lib.vidc_bn_train_forward_add(L.ptr(yd), L.ptr(z), M, cout, cout, cout, L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), 1e-5, 0.1, 1,
+                                                  L.ptr(mean), L.ptr(rstd), None, None, 0, L.ptr(sc), st), "bn")
+        res.append([t.cpu() for t in (z, mean, rstd, rm, rv)])
+    for name, a, b in zip(("y", "mean", "rstd", "running_mean", "running_var"), *res):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), (name, float((a - b).abs().max()))
+    with pytest.raises(RuntimeError, match="STATS_OUT"):       # not offered outside the plain-bf16 mode
+        d.precision = L.PREC_FP32
+        L.check(lib.vidc_conv2d_bn_act(C.byref(d), st), "conv")
+
+
+@gpu
+def test_training_step_with_conv_epilogue_statistics(golden_dir, seeded_weights, monkeypatch):
+    """One whole bf16 training step with the BatchNorm statistics taken from the convs' epilogues (the default) against the same step
+    with every BatchNorm summing its input itself (VIDC_TRAIN_CONV_STATS=0).  The sums are the same numbers added in another order
+    (fp64): loss equal to 1e-6 relative, flat gradient within 2e-3 of its scale in every element and 1e-5 in the mean (the bf16 convs
+    amplify a last-bit difference of a mean / invstd; same magnitudes as between two legal fp64 orders), running statistics 1e-6."""
+    from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
+    from vi_depth_completion_amd.training import DepthCompletionTrainer
+    f, image, normal, depth_in, gt = _train_fixture(golden_dir)
+    ins = [t.to(DEV) for t in (image, normal, depth_in, gt)]
+    monkeypatch.setenv("VIDC_TRAIN_PRECISION", "bf16")
+    runs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("VIDC_TRAIN_CONV_STATS", flag)
+        cnn = ModifiedFPN().to(DEV)
+        st = cnn.state_dict()
+        st.update({k: v.to(DEV) for k, v in seeded_weights["dc"].items()})
+        cnn.load_state_dict(st)
+        cnn.train()
+        tr = DepthCompletionTrainer(cnn, float(f["lr"]))
+        assert tr.conv_stats == (flag == "1")
+        loss, _ = tr.forward_backward(*ins)
+        runs[flag] = (float(loss), tr.flat_g.clone().cpu(), {k: v.clone().cpu() for k, v in cnn.state_dict().items() if "running" in k})
+        del tr, cnn
+        torch.cuda.empty_cache()
+    la, lb = runs["1"][0], runs["0"][0]
+    assert abs(la - lb) <= 1e-6 * abs(lb), (la, lb)
+    ga, gb = runs["1"][1], runs["0"][1]
+    scale = float(gb.abs().max())
+    assert float((ga - gb).abs().max()) < 2e-3 * scale and float((ga - gb).abs().mean()) < 1e-5 * scale, (float((ga - gb).abs().max()), float((ga - gb).abs().mean()), scale)
+    for k, v in runs["1"][2].items():
+        assert float((v - runs["0"][2][k]).abs().max()) <= 1e-6 * max(1.0, float(v.abs().max())), k

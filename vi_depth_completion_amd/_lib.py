@@ -18,7 +18,7 @@ MAX_STREAMS = 4
 MAX_SEGMENTS = 4
 
 # vidc_conv_flags / vidc_up_flags / vidc_op_kind / vidc_conv_tile
-RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM, SPLIT_OUT, NO_F32_OUT = 1, 2, 4, 8, 16, 32, 64, 128
+RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM, SPLIT_OUT, NO_F32_OUT, STATS_OUT = 1, 2, 4, 8, 16, 32, 64, 128, 256
 UP_RELU, UP_ACCUM, UP_NO_F32_OUT = 1, 2, 4
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY, OP_SPLIT, OP_AVGPOOL, OP_NORMALIZE, OP_DET_IM2COL, OP_NEAREST2X, OP_CHAIN, OP_MASK = range(1, 17)
 TILE_AUTO = 0
@@ -86,6 +86,7 @@ SIGNATURES = {
     "vidc_train_scratch_bytes": (C.c_size_t, [C.c_longlong, _i]),
     "vidc_bn_train_forward": (C.c_int, [_vp, _vp, C.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "vidc_bn_train_forward_add": (C.c_int, [_vp, _vp, C.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "vidc_bn_train_forward_stats": (C.c_int, [_vp, _vp, C.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "vidc_bn_train_backward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vidc_bn_train_backward_t": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "vidc_colsum": (C.c_int, [_vp, C.c_longlong, _i, _i, _vp, _vp, _vp]),

@@ -619,6 +619,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
     const bool aff2 = a.flags & VIDC_AFFINE2, has_res = a.flags & VIDC_RESIDUAL, accum = a.flags & VIDC_ACCUM;
     const bool st_f32 = !(a.flags & VIDC_NO_F32_OUT), st_split = a.flags & VIDC_SPLIT_OUT;
     unsigned short* ysp = st_split ? a.y_split + (size_t)g * a.y_gs * 2 : nullptr;
+    double* stats_out = (PREC == 2 && (a.flags & VIDC_STATS_OUT)) ? reinterpret_cast<double*>(a.y_split) : nullptr;   // (groups == 1, host-checked)
 #ifndef VIDC_CONV_TIMING
     // ---- split-K without a second launch: every k-slice workgroup stores its fp32 partial tile, takes a ticket on the tile's
     //      counter (head of the workspace; device-scope atomic), and the LAST one to arrive sums the splitk partials in slice
@@ -710,6 +711,27 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
             // `full_tag` = true_type: all 32 rows of the tile exist (every tile but the last m-tile): no per-row predicate
             auto finish = [&](auto full_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;
+                if constexpr (PREC == 2 && !CHAIN) {
+                    // VIDC_STATS_OUT (training, plain-bf16 mode): per-channel sum and sum of squares of this 32-row block of the OUTPUT
+                    // (the fp32 values stored below), as the fp64 partials the train-mode BatchNorm behind this conv reduces
+                    // (csrc/train.hip chan_final_kernel): saves that BatchNorm's partial-sum launch and its pass over the tensor.
+                    // Lane order is fixed (16 rows of this lane in r order, then the lane holding the other 4-row phases), block order
+                    // is the chunk index m / 32: bit-reproducible.
+                    if (stats_out) {
+                        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int dm = (r & 3) + 8 * (r >> 2);
+                            if (FULL || mrow + dm < a.M) { const double t = (double)v[r]; s0 += t; s1 += t * t; }
+                        }
+                        const double o0s = __shfl_xor(s0, 32), o1s = __shfl_xor(s1, 32);
+                        if (lh == 0 && n < a.Cout && mb < a.M) {
+                            double* sp = stats_out + ((size_t)(mb >> 5) * 2) * (size_t)a.Cout + n;
+                            sp[0] = s0 + o0s;
+                            sp[a.Cout] = s1 + o1s;
+                        }
+                    }
+                }
                 if (accum) {
                     float old[16];
 #pragma unroll
@@ -1060,6 +1082,9 @@ int validate(const vidc_conv_desc* d) {
     VIDC_REQUIRE(!(d->flags & VIDC_SPLIT_OUT) || (d->y_split && d->Cout % 32 == 0 && d->ldy % 32 == 0), VIDC_ERR_NULL,
                  "conv: SPLIT_OUT needs y_split and Cout, ldy multiples of 32");
     VIDC_REQUIRE(!(d->flags & VIDC_NO_F32_OUT) || (d->flags & VIDC_SPLIT_OUT), VIDC_ERR_SHAPE, "conv: NO_F32_OUT without SPLIT_OUT writes nothing");
+    VIDC_REQUIRE(!(d->flags & VIDC_STATS_OUT) || (d->precision == VIDC_PREC_BF16 && d->y_split && d->groups == 1 &&
+                                                  !(d->flags & (VIDC_AFFINE2 | VIDC_RESIDUAL | VIDC_ACCUM | VIDC_SPLIT_OUT | VIDC_NO_F32_OUT))),
+                 VIDC_ERR_SHAPE, "conv: STATS_OUT needs VIDC_PREC_BF16, one group, y_split = the partials buffer and a plain epilogue");
     VIDC_REQUIRE((long long)d->B * d->Ho * d->Wo < (1ll << 31), VIDC_ERR_SHAPE, "conv: M overflows int32");
     VIDC_REQUIRE((long long)d->Cout * d->KH * d->KW * d->Cin * 4 < (1ll << 31), VIDC_ERR_SHAPE,
                  "conv: one group's weights must stay below 2 GiB (32-bit buffer offsets)");

@@ -1153,6 +1153,26 @@ extern "C" int vidc_bn_train_forward_add(const float* x, float* y, long long M, 
     return VIDC_OK;
 }
 
+// The same with the per-channel partial sums ALREADY written by the conv that produced x (VIDC_STATS_OUT: one pair of rows of C doubles per
+// block of 32 output rows, in chan_partial_kernel's layout): only the final reduction and the apply pass run here.
+extern "C" int vidc_bn_train_forward_stats(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
+                                           float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean,
+                                           float* save_rstd, void* y_bf16, const float* residual, int ldr, const void* conv_stats, void* scratch,
+                                           vidc_stream_t stream) {
+    VIDC_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && conv_stats && scratch, VIDC_ERR_NULL, "vidc_bn_train_forward_stats: null pointer");
+    VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || (ldr >= C && ldr % 4 == 0)),
+                 VIDC_ERR_SHAPE, "vidc_bn_train_forward_stats: bad shape");
+    hipStream_t st = vidc::as_stream(stream);
+    const int nch = (int)((M + 31) / 32);
+    double* sums = reinterpret_cast<double*>(scratch);      // [2][C]
+    hipLaunchKernelGGL(chan_final_kernel<FinalStats>, dim3((C + 7) / 8), dim3(TT), 0, st, reinterpret_cast<const double*>(conv_stats), nch, C, sums,
+                       FinalStats{M, eps, momentum, save_mean, save_rstd, running_mean, running_var});
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, x, y, M, C, ldx, ldy, save_mean, save_rstd, gamma, beta, relu,
+                       reinterpret_cast<unsigned short*>(y_bf16), residual, ldr);
+    VIDC_CHECK_LAUNCH("bn_train_forward_stats");
+    return VIDC_OK;
+}
+
 extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
                                      float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
                                      void* y_bf16, void* scratch, vidc_stream_t stream) {

@@ -37,12 +37,13 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 class Act:
     """An activation: NHWC rows `t` (B,H,W,C view, possibly a channel slice of a wider buffer) + its gradient (same geometry)."""
-    __slots__ = ("t", "grad", "bf", "grad_bf", "grad_t", "conv_out", "no_f32_grad")      # bf / grad_bf: bf16 operand copies (dense rows) written by the producing kernel
+    __slots__ = ("t", "grad", "bf", "grad_bf", "grad_t", "conv_out", "no_f32_grad", "stats")      # bf / grad_bf: bf16 operand copies (dense rows) written by the producing kernel
     # grad_t: (tensor, Mp) -- the gradient transposed as bf16 rows [C][Mp], written by the BatchNorm backward behind a conv (conv_out): the
     # left operand of that conv's weight-gradient GEMM
 
     def __init__(self, t):
         self.t, self.grad, self.bf, self.grad_bf, self.grad_t, self.conv_out = t, None, None, None, None, False
+        self.stats = None             # conv output in the plain-bf16 mode: per-32-row-block channel sums written by the conv's epilogue (VIDC_STATS_OUT)
         self.no_f32_grad = False      # conv output whose conv reads dY only through grad_bf / grad_t: the BatchNorm backward skips the fp32 form
 
     @property
@@ -201,6 +202,9 @@ class DepthCompletionTrainer:
         self.bn_add_fused = os.environ.get("VIDC_TRAIN_BN_ADD_FUSED", "1") == "1"   # Bottleneck tail relu(bn3(.) + identity) inside bn3's apply pass
         self.skip_f32_dy = os.environ.get("VIDC_TRAIN_SKIP_F32_DY", "1") == "1"    # the BatchNorm backward writes no fp32 dY where only the bf16 forms are read
         self.xt_from_bf16 = os.environ.get("VIDC_TRAIN_XT_BF16", "1") == "1"      # 1x1 convs: the wgrad GEMM's right operand transposed from the bf16 copy
+        # Round 4: the train-mode BatchNorm behind a conv takes its per-channel sums from the conv's epilogue (VIDC_STATS_OUT, plain-bf16 mode)
+        # instead of a partial-sum pass of its own over the conv output: one launch and one read of the tensor less per conv + BatchNorm.
+        self.conv_stats = os.environ.get("VIDC_TRAIN_CONV_STATS", "1") == "1"
         if "VIDC_TRAIN_BN_FOLD" in os.environ:   # (A/B runs) the BatchNorm chunk sums reduced in the consumer's prologue (default) or by a launch of their own
             L.lib().vidc_train_bn_fold(int(os.environ["VIDC_TRAIN_BN_FOLD"] != "0"))
         self._wgrad_streams, self._wgrad_used = {}, []
@@ -275,7 +279,7 @@ class DepthCompletionTrainer:
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
     # ---- conv: forward, dgrad, wgrad --------------------------------------------------------------------------------------------
-    def _conv_call(self, x_t, w_packed, shift, y_t, kh, kw, stride, pad, relu, accumulate, x_bf=None):
+    def _conv_call(self, x_t, w_packed, shift, y_t, kh, kw, stride, pad, relu, accumulate, x_bf=None, stats=None):
         """One launch of the inference conv kernel.  In bf16x3 mode the activations are split here (one extra pass over x); `w_packed`
         must already be in the matching format (`_pack`)."""
         B, H, W, cin = x_t.shape
@@ -303,6 +307,9 @@ class DepthCompletionTrainer:
         d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, cout, _ld(y_t)
         d.KH, d.KW, d.stride, d.pad = kh, kw, stride, pad
         d.flags = (L.RELU1 if relu else 0) | (L.ACCUM if accumulate else 0)
+        if stats is not None:                 # (the descriptor's y_split field carries the partials buffer: include/vidc.h VIDC_STATS_OUT)
+            d.flags |= L.STATS_OUT
+            d.y_split = L.ptr(stats)
         d.groups, d.splitk, d.precision, d.tile = 1, 1, self.precision, 0
         d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, cout * kh * kw * cin, cout, cout
         self._plan(d, "conv")
@@ -451,7 +458,9 @@ class DepthCompletionTrainer:
         # stride 1, no bias, bf16 operands, GEMM weight gradient: this conv's backward reads dY only as bf16 rows (dgrad) and as dY^T (wgrad)
         y.no_f32_grad = (y.conv_out and self.skip_f32_dy and self.precision == L.PREC_BF16 and stride == 1 and bias is None and co % 64 == 0 and
                          B * Ho * Wo < (1 << 31) and self._wgrad_fits((B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad)))
-        self._conv_call(x.t, wp, bias if bias is not None else self._const(self._zeros, co, 0.0), y.t, kh, kw, stride, pad, relu, False, x_bf=x.bf)
+        if self.conv_stats and self.precision == L.PREC_BF16 and not relu and out is None and co % 32 == 0:
+            y.stats = torch.empty(((B * Ho * Wo + 31) // 32) * 2 * co, dtype=torch.float64, device=self.device)
+        self._conv_call(x.t, wp, bias if bias is not None else self._const(self._zeros, co, 0.0), y.t, kh, kw, stride, pad, relu, False, x_bf=x.bf, stats=y.stats)
 
         def backward():
             g, g_bf, g_t = y.grad, y.grad_bf, y.grad_t
@@ -509,10 +518,19 @@ class DepthCompletionTrainer:
         bf16 = self.precision == L.PREC_BF16 and Cc % 64 == 0
         if bf16:
             y.bf = self._empty(*x.t.shape[:-1], Cc // 2)
-        L.check(L.lib().vidc_bn_train_forward_add(L.ptr(x.t), L.ptr(y.t), x.rows, Cc, x.ld, y.ld, L.ptr(gamma), L.ptr(beta), L.ptr(self.buf[key + ".running_mean"]),
-                                                  L.ptr(self.buf[key + ".running_var"]), BN_EPS, BN_MOMENTUM, int(relu), L.ptr(mean), L.ptr(rstd),
-                                                  L.ptr(y.bf) if y.bf is not None else None, L.ptr(residual.t) if residual is not None else None,
-                                                  residual.ld if residual is not None else 0, L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_forward")
+        if x.stats is not None and x.stats.numel() == ((x.rows + 31) // 32) * 2 * Cc and x.ld == Cc:
+            # x is a conv's output and the conv's epilogue has written its channel sums: final reduction + apply pass only
+            L.check(L.lib().vidc_bn_train_forward_stats(L.ptr(x.t), L.ptr(y.t), x.rows, Cc, x.ld, y.ld, L.ptr(gamma), L.ptr(beta), L.ptr(self.buf[key + ".running_mean"]),
+                                                        L.ptr(self.buf[key + ".running_var"]), BN_EPS, BN_MOMENTUM, int(relu), L.ptr(mean), L.ptr(rstd),
+                                                        L.ptr(y.bf) if y.bf is not None else None, L.ptr(residual.t) if residual is not None else None,
+                                                        residual.ld if residual is not None else 0, L.ptr(x.stats), L.ptr(self._train_scratch(x.rows, Cc)),
+                                                        L.current_stream()), "bn_forward (conv stats)")
+            x.stats = None                    # (consumed; the buffer goes back to the allocator with the activation's other temporaries)
+        else:
+            L.check(L.lib().vidc_bn_train_forward_add(L.ptr(x.t), L.ptr(y.t), x.rows, Cc, x.ld, y.ld, L.ptr(gamma), L.ptr(beta), L.ptr(self.buf[key + ".running_mean"]),
+                                                      L.ptr(self.buf[key + ".running_var"]), BN_EPS, BN_MOMENTUM, int(relu), L.ptr(mean), L.ptr(rstd),
+                                                      L.ptr(y.bf) if y.bf is not None else None, L.ptr(residual.t) if residual is not None else None,
+                                                      residual.ld if residual is not None else 0, L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_forward")
         self._nbt.append(self.buf[key + ".num_batches_tracked"])
         y_in = y               # what the BatchNorm part of the backward takes dy from
         if residual is not None:
