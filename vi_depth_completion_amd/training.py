@@ -806,7 +806,10 @@ class DepthCompletionTrainer:
         # lanes 2 and 3).  Dropping a closure right after it ran would hand such a block back to the allocating lane's pool while the
         # other lanes' kernels are still queued -- and inside a captured graph, where the three pyramids are parallel branches and a
         # freed block is reusable at once, the allocating lane's next temporary could overwrite it.  So every closure that has run is
-        # kept until all lanes have joined the main stream at the end of the tape.
+        # kept until all lanes have joined the main stream at the end of the tape.  Cost: the backward's peak memory is the SUM of the
+        # activation gradients and their bf16 / transposed forms instead of the live set (not measured; bounded by the gradient volume of
+        # one backward, i.e. of the order of the forward's activations -- a few GB at batch 8, 320x240, of 288 GB);
+        # a step that raises drops them at once (the except below), so a failed step does not pin them until the next good one.
         try:
             self._run_tape_inner(stop_after_decoder)
         except BaseException:
