@@ -583,6 +583,17 @@ def _assert_only_borderline(diff, normals, ids, homo, trace, max_px=5):
     px = np.argwhere(diff.numpy())
     assert len(px) <= max_px, "too many differing pixels: %s" % px[:20].tolist()
     by_cls = {r["cls"]: r for r in trace}
+    # how many pixels of the scene sit on a threshold at all (fp64, every pixel of every traced plane): a scene with none must agree exactly
+    n_borderline = 0
+    for rec in trace:
+        sel = torch.from_numpy(np.asarray(ids) == rec["cls"])
+        if not sel.any() or rec.get("winner_normal") is None:
+            continue
+        n_all = normals[0][:, sel].double()                                   # (3, n)
+        ang_all = torch.acos(torch.clamp(rec["winner_normal"].double() @ n_all, -1.0, 1.0)) * (180.0 / np.pi)
+        dot_all = homo[0][sel].double() @ rec["n_bar"].double()
+        n_borderline += int((((ang_all - 20.0).abs() < 2e-3) | ((dot_all.abs() - 1e-3).abs() < 1e-6)).sum())
+    assert len(px) <= n_borderline, "%d pixels differ but only %d pixels of the scene are borderline in fp64" % (len(px), n_borderline)
     for r_, c_ in px:
         rec = by_cls.get(int(ids[r_, c_]))
         assert rec is not None, "pixel (%d,%d) differs outside every plane" % (r_, c_)
