@@ -155,3 +155,36 @@ def test_unowned_outputs_mark_the_lane_consumed(monkeypatch):
     assert all(v[0] is False and all(v[1:]) for v in per_lane.values()) and all(len(v) >= 2 for v in per_lane.values()), per_lane
     log, outs = _run(12, 2, 2, monkeypatch, copy_outputs=True)
     assert outs == list(range(12)) and not any(had for _l, had in consumed_log)
+
+
+def test_plane_block_id_map_cache_keys_on_content():
+    """`PlaneBlock._stacked_ids` / `_groups_of` (host side of the plane block, numpy only): the per-plane pixel groups are recomputed
+    when the CONTENT of the id maps changes -- not their identity -- and exactly once per change; maps that are not uint8 bypass the
+    cache.  (One stack + one comparison per item since round 4; the device upload keys on the same array object.)"""
+    import numpy as np
+    from vi_depth_completion_amd import plane
+    pb = plane.PlaneBlock()
+    a = np.zeros((4, 6), dtype=np.uint8)
+    a[1:3, 1:4] = 2
+    a[3, :] = 1
+    st = pb._stacked_ids([a])
+    assert st[1] is True and st[0].shape == (1, 4, 6)
+    g1 = pb._groups_of([a], st)
+    assert [c for c, _ in g1[0]] == [1, 2] and g1[0][1][1].tolist() == [7, 8, 9, 13, 14, 15]
+    st2 = pb._stacked_ids([a.copy()])                      # another object, same content
+    assert st2[1] is False
+    assert pb._groups_of([a.copy()], st2) is g1            # cached
+    b = a.copy()
+    b[0, 0] = 2                                            # content changed in one pixel
+    st3 = pb._stacked_ids([b])
+    assert st3[1] is True
+    g3 = pb._groups_of([b], st3)
+    assert g3 is not g1 and g3[0][1][1].tolist() == [0, 7, 8, 9, 13, 14, 15]
+    a[0, 0] = 2                                            # the FIRST array mutated in place to the same content: unchanged vs the cache
+    assert pb._stacked_ids([a])[1] is False
+    wide = a.astype(np.int64)
+    st4 = pb._stacked_ids([wide])
+    assert st4[0] is None and st4[1] is True
+    g4 = pb._groups_of([wide], st4)
+    assert [c for c, _ in g4[0]] == [1, 2]
+    assert plane.plane_groups(np.zeros((3, 3), dtype=np.uint8)) == []        # only background: main.py:135-137
