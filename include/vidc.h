@@ -256,6 +256,15 @@ int vidc_plane_info_count(int B, int HW);
 int vidc_plane_finalize(const float* depth, float* plane_depth, int B, int HW, const float* records, int n_slots,
                         int32_t* info, vidc_stream_t stream);
 
+/* extract_plane_images_from_normal_image (main.py:130-190) for a whole batch as ONE call: plane_depth <- depth, then
+ * vidc_plane_ransac_normal, vidc_plane_offset (vidc_plane_offset_dense when any dense_* is given), vidc_plane_project_depth and
+ * vidc_plane_finalize with these arguments, in that order on `stream` (n_slots == 0: copy + finalize).  Same kernels, same results;
+ * the stream modes use it so that an item's launch-bound plane kernels are enqueued back to back. */
+int vidc_plane_block(const float* normals, const uint8_t* ids, const int32_t* slots, int n_slots, const int32_t* hyp_pix, int B, int HW,
+                     const float* homo, const float* depth, uint8_t* inlier_mask, int32_t* counts, void* scratch, float* records,
+                     const int32_t* dense_hyp, const int32_t* dense_n, float* dense_dots, float* plane_depth, int32_t* info,
+                     vidc_stream_t stream);
+
 /* main.py:290-294: for image b the sub[k]-th nonzeros (row-major, like torch.nonzero) of plane_depth[b] are copied
  * into enriched[b] (a clone of the sparse depth).  sub: sorted unique indices drawn on the host with
  * np.unique(np.random.randint(...)); image b owns sub[sub_offsets[b] .. sub_offsets[b+1]); chunk_base: [B][chunks]

@@ -135,6 +135,7 @@ SIGNATURES = {
     "vidc_plane_project_depth": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "vidc_plane_info_count": (C.c_int, [_i, _i]),
     "vidc_plane_finalize": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    "vidc_plane_block": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vidc_enrich_scatter": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "vidc_enrich_scatter_from": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "vidc_resize_coeffs": (C.c_int, [_i, _i, _vp, _vp, _i, C.POINTER(C.c_int)]),

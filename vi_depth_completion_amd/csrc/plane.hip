@@ -591,6 +591,32 @@ extern "C" int vidc_plane_finalize(const float* depth, float* plane_depth, int B
     return VIDC_OK;
 }
 
+// The plane block of one batch as ONE call: plane_depth <- depth (device copy), vidc_plane_ransac_normal, vidc_plane_offset[_dense],
+// vidc_plane_project_depth, vidc_plane_finalize, in that order on `stream` -- the same kernels with the same arguments as the five
+// separate entries (bit-identical results); what it saves is four trips through the caller's language per item of a frame stream, during
+// which the lane's stream has nothing queued (round 4: the stream modes enqueue these launch-bound kernels between two graph segments).
+// n_slots == 0 (only background): copy + finalize.  dense_* all NULL: the ordinary offset pass.
+extern "C" int vidc_plane_block(const float* normals, const uint8_t* ids, const int32_t* slots, int n_slots, const int32_t* hyp_pix, int B, int HW,
+                                const float* homo, const float* depth, uint8_t* inlier_mask, int32_t* counts, void* scratch, float* records,
+                                const int32_t* dense_hyp, const int32_t* dense_n, float* dense_dots, float* plane_depth, int32_t* info,
+                                vidc_stream_t stream) {
+    VIDC_REQUIRE(depth && plane_depth && info, VIDC_ERR_NULL, "vidc_plane_block: null pointer");
+    VIDC_REQUIRE(B > 0 && HW > 0 && n_slots >= 0, VIDC_ERR_SHAPE, "vidc_plane_block: bad shape");
+    VIDC_HIP(hipMemcpyAsync(plane_depth, depth, (size_t)B * HW * sizeof(float), hipMemcpyDeviceToDevice, vidc::as_stream(stream)));
+    if (n_slots > 0) {
+        int rc = vidc_plane_ransac_normal(normals, ids, slots, n_slots, hyp_pix, HW, inlier_mask, counts, scratch, stream);
+        if (rc != VIDC_OK) return rc;
+        if (dense_hyp || dense_n || dense_dots)
+            rc = vidc_plane_offset_dense(homo, depth, slots, n_slots, B, inlier_mask, counts, HW, scratch, records, dense_hyp, dense_n, dense_dots, stream);
+        else
+            rc = vidc_plane_offset(homo, depth, slots, n_slots, B, inlier_mask, counts, HW, scratch, records, stream);
+        if (rc != VIDC_OK) return rc;
+        rc = vidc_plane_project_depth(homo, slots, n_slots, inlier_mask, HW, scratch, records, plane_depth, stream);
+        if (rc != VIDC_OK) return rc;
+    }
+    return vidc_plane_finalize(depth, plane_depth, B, HW, records, n_slots, info, stream);
+}
+
 extern "C" int vidc_enrich_scatter(const float* plane_depth, const int32_t* sub, const int32_t* sub_offsets, const int32_t* chunk_base,
                                    int B, int HW, float* enriched, vidc_stream_t stream) {
     VIDC_REQUIRE(plane_depth && sub && sub_offsets && chunk_base && enriched, VIDC_ERR_NULL, "vidc_enrich_scatter: null pointer");

@@ -231,8 +231,10 @@ class PlaneBlock:
         n_slots = slots.shape[0]
         bufs = self._buffers(dev, B, HW, n_slots)
         di = bufs["di"]
-        di.copy_(ds)
         rec = None
+        info = bufs["info"]
+        ids = slots_p = hyp_p = dh_p = dn_p = None
+        dots = None
         if n_slots > 0:
             ids = self._upload_ids(ctx["ids"], dev, stacked)
             arrays = [slots, hyp]
@@ -244,23 +246,17 @@ class PlaneBlock:
                 arrays += [dh, dn]
             ptrs = self._up1(arrays, dev)
             slots_p, hyp_p = ptrs[0], ptrs[1]
-            mask, counts, rec, scratch = bufs["mask"], bufs["counts"], bufs["rec"][:n_slots], bufs["scratch"]
-            L.check(lib.vidc_plane_ransac_normal(L.ptr(normals), L.ptr(ids), slots_p, n_slots, hyp_p, HW, L.ptr(mask), L.ptr(counts),
-                                                 L.ptr(scratch), st), "plane_ransac_normal")
+            rec = bufs["rec"][:n_slots]
             if dense_hyp:
                 if bufs.get("dense_dots") is None or bufs["dense_dots"].shape[0] < n_slots:
                     bufs["dense_dots"] = torch.empty((bufs["cap"], HW), dtype=torch.float32, device=dev)
-                L.check(lib.vidc_plane_offset_dense(L.ptr(homo), L.ptr(ds), slots_p, n_slots, B, L.ptr(mask), L.ptr(counts), HW,
-                                                    L.ptr(scratch), L.ptr(rec), ptrs[2], ptrs[3], L.ptr(bufs["dense_dots"]), st),
-                        "plane_offset_dense")
-            else:
-                L.check(lib.vidc_plane_offset(L.ptr(homo), L.ptr(ds), slots_p, n_slots, B, L.ptr(mask), L.ptr(counts), HW, L.ptr(scratch),
-                                              L.ptr(rec), st), "plane_offset")
-            L.check(lib.vidc_plane_project_depth(L.ptr(homo), slots_p, n_slots, L.ptr(mask), HW, L.ptr(scratch), L.ptr(rec), L.ptr(di), st),
-                    "plane_project_depth")
+                dh_p, dn_p, dots = ptrs[2], ptrs[3], bufs["dense_dots"]
+        # ONE native call for the whole block (copy of the sparse depth, RANSAC, offset, projection, finalize): its launch-bound kernels
+        # go out back to back instead of one trip through Python apiece (the stream modes enqueue them between two graph segments)
+        L.check(lib.vidc_plane_block(L.ptr(normals), L.ptr(ids), slots_p, n_slots, hyp_p, B, HW, L.ptr(homo), L.ptr(ds), L.ptr(bufs["mask"]),
+                                     L.ptr(bufs["counts"]), L.ptr(bufs["scratch"]), L.ptr(rec), dh_p, dn_p, L.ptr(dots), L.ptr(di), L.ptr(info), st),
+                "plane_block")
         self.last_records, self.last_slots, self.last_mask = rec, slots, (bufs["mask"][:n_slots] if n_slots > 0 else None)
-        info = bufs["info"]
-        L.check(lib.vidc_plane_finalize(L.ptr(ds), L.ptr(di), B, HW, L.ptr(rec), n_slots, L.ptr(info), st), "plane_finalize")
         return di.view(B, 1, H, W), info
 
     def read_info_async(self, info):
