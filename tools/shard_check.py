@@ -30,15 +30,10 @@ def make():
 def run_shard(ids, taps):
     p = make()
 
-    def feed():
-        for f in ids:
-            p.rng = np.random.RandomState(1000 + f)
-            yield frames[f]
     out = {}
-    gen = p.run_interleaved(feed())
-    for f, o in zip(ids, gen):
+    gen = p.run_interleaved(iter([frames[f] for f in ids]), frame_rng=lambda i: np.random.RandomState(1000 + ids[i]))      # (items are pulled ahead of
+    for f, o in zip(ids, gen):                                                                                                #  their draws since round 4)
         out[f] = o.cpu()
-        prog = p._frame_prog
     return out
 
 
