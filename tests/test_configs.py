@@ -214,11 +214,8 @@ def test_frame_output_does_not_depend_on_the_shard(seeded_weights):
             p.rng = np.random.RandomState(1000 + f)
             seq[f] = p._call_cnn(frames[f]).cpu()
 
-        def feed():
-            for f in ids:
-                p.rng = np.random.RandomState(1000 + f)      # the draws of frame f happen in the tick that pulled it
-                yield frames[f]
-        inter = dict(zip(ids, (o.cpu() for o in p.run_interleaved(feed()))))
+        # one item per launch, one lane (frame f draws from its own generator: `frame_rng`, whatever the scheduler pulls ahead)
+        inter = dict(zip(ids, (o.cpu() for o in p.run_interleaved(iter([frames[f] for f in ids]), frame_rng=lambda i: np.random.RandomState(1000 + ids[i])))))
         # the mode bench.py times: two lanes, two consecutive frames of the shard per launch (rank 0 of 1 pairs (0,1) (2,3); rank 1 of 2
         # pairs (1,3): frame 1 changes batch slot and partner, frame 3 its partner)
         paired = dict(zip(ids, (o.cpu() for o in p.run_interleaved(iter([frames[f] for f in ids]), lanes=2, frames_per_launch=2,
