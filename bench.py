@@ -420,7 +420,9 @@ def train_leg(args, dev, rank, world):
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32+bf16x3", "bf16": "bf16"}[mode], "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: ModifiedFPN training step (train-mode BatchNorm, masked L1 / (H*W), Adam), %dx%d, batch %d per "
                                    "GPU, seeded weights and ground truth" % (W, H, B), "height": H, "width": W, "batch_per_gpu": B,
-                       "sharding": "frames over %d rank(s); gradients summed by a bucketed all-reduce overlapped with the backward" % world},
+                       "sharding": "frames over %d rank(s); gradients summed by a bucketed all-reduce overlapped with the backward" % world,
+                       "gradient_buckets": ("bf16" if os.environ.get("VIDC_TRAIN_GRAD_BF16", "0") == "1" else "f32"),
+                       "collectives": ("through the backend" if sharding.collectives_active() else "none (one rank)")},
             "roofline": {"bound": "mfma", "achieved": round(tf * (3 if mode == "bf16x3" else 1), 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tf * (3 if mode == "bf16x3" else 1) / peak, 4), "traffic": None,
                          "note": "whole step: 3 x forward conv FLOPs per frame / step time (fwd + dgrad + wgrad launches of the conv kernel; "
@@ -461,12 +463,24 @@ def main():
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
         import torch.distributed as dist
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    elif os.environ.get("VIDC_DIST_WORLD1", "0") == "1":
+        # a world of ONE that still sends every collective through the backend (sharding.collectives_active): the RCCL code paths of the
+        # N-GPU job -- metric gather, the training step's bucketed gradient all-reduce -- on a one-GPU box
+        import socket
+        import torch.distributed as dist
+        if "MASTER_PORT" not in os.environ:
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+            sock.close()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": dev} if backend == "nccl" else {}))
 
     if args.train:
         if args.height == 256 and "--height" not in " ".join(sys.argv):
             args.height = 240                      # the training fixtures and BASELINE configs[4] use the reference's own 320x240
         train_leg(args, dev, rank, world)
-        if world > 1:
+        if world > 1 or os.environ.get("VIDC_DIST_WORLD1", "0") == "1":
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -596,7 +610,7 @@ def main():
         if extra_legs is not None:
             line["extra_legs"] = extra_legs
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or os.environ.get("VIDC_DIST_WORLD1", "0") == "1":
         dist.barrier()
         dist.destroy_process_group()
 
