@@ -220,3 +220,31 @@ def test_prepare_interleaved_builds_every_lane(seeded_weights, monkeypatch):
     assert all(torch.equal(a, b) for a, b in zip(got, ref))
     p.prepare_interleaved(frames[0], lanes=2, frames_per_launch=1)      # the round-3 scheduler's lanes as well
     assert p.frame_program(1, 240, 320).captured
+
+
+@pytest.mark.parametrize("precision", ["fp32", "mixed"])
+def test_bench_shape_paired_stream_vs_oracle(seeded_weights, precision, monkeypatch):
+    """The configuration bench.py times -- 320x256, batch-1 items, three lanes, two items per launch, plane mask fixed -- against the CPU
+    oracle frame by frame, the stream drawing from ONE generator like the oracle's back-to-back `call_cnn` calls do: depth RMSE per
+    frame < 2e-5 in the fp32 mode (the headline leg), < 1e-3 in the mixed mode; 5 items = two full groups and a tail."""
+    from oracle import vidc_oracle as O
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    monkeypatch.setenv("VIDC_PRECISION", precision)
+    H, W = 256, 320
+    cc = (0.5 * 319.87654, 0.5 * 239.87603 * H / 240.0)
+    pipe = DepthCompletionPipeline(enriched_samples=200, cc_img=cc, rng=np.random.RandomState(2024))
+    pipe.load_state_dicts(seeded_weights["sn"], seeded_weights["dc"])
+    ids = S.plane_id_map(H, W)
+    pipe.plane_masks_extraction = FixedPlaneMask(ids)
+    host = [S.synthetic_batch(1, H, W, 1234, frame0=500 + i) for i in range(5)]
+    dev = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()} for b in host]
+    pipe.prepare_interleaved(dev[0], lanes=3, frames_per_launch=2)
+    outs = [o.cpu() for o in pipe.run_interleaved(iter(dev), lanes=3, frames_per_launch=2)]
+    intr = O.Intrinsics(202.0, 202.0, cc[0], cc[1])
+    rng = np.random.RandomState(2024)
+    bar = 2e-5 if precision == "fp32" else 1e-3
+    for i, (b, got) in enumerate(zip(host, outs)):
+        want = O.call_cnn(seeded_weights["sn"], seeded_weights["dc"], b, [ids], intr, 200, rng=rng)
+        rmse = float((got - want).pow(2).mean().sqrt())
+        assert rmse < bar, (precision, i, rmse)
+    assert rng.get_state()[2] == pipe.rng.get_state()[2] and np.array_equal(rng.get_state()[1], pipe.rng.get_state()[1]), "same draws as the oracle's sequence"
