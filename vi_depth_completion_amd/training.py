@@ -205,6 +205,7 @@ class DepthCompletionTrainer:
         # Round 4: the train-mode BatchNorm behind a conv takes its per-channel sums from the conv's epilogue (VIDC_STATS_OUT, plain-bf16 mode)
         # instead of a partial-sum pass of its own over the conv output: one launch and one read of the tensor less per conv + BatchNorm.
         self.conv_stats = os.environ.get("VIDC_TRAIN_CONV_STATS", "1") == "1"
+        self.conv_stats_max_m = int(os.environ.get("VIDC_TRAIN_CONV_STATS_MAX_M", str(1 << 30)))
         if "VIDC_TRAIN_BN_FOLD" in os.environ:   # (A/B runs) the BatchNorm chunk sums reduced in the consumer's prologue (default) or by a launch of their own
             L.lib().vidc_train_bn_fold(int(os.environ["VIDC_TRAIN_BN_FOLD"] != "0"))
         self._wgrad_streams, self._wgrad_used = {}, []
@@ -458,7 +459,9 @@ class DepthCompletionTrainer:
         # stride 1, no bias, bf16 operands, GEMM weight gradient: this conv's backward reads dY only as bf16 rows (dgrad) and as dY^T (wgrad)
         y.no_f32_grad = (y.conv_out and self.skip_f32_dy and self.precision == L.PREC_BF16 and stride == 1 and bias is None and co % 64 == 0 and
                          B * Ho * Wo < (1 << 31) and self._wgrad_fits((B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad)))
-        if self.conv_stats and self.precision == L.PREC_BF16 and not relu and out is None and co % 32 == 0:
+        # (VIDC_TRAIN_CONV_STATS_MAX_M bounds the output rows it is used for: one partial per 32 rows makes the final reduction of a large
+        #  map long -- 4800 partials at M = 153 600 -- but limiting it to 16 384 or 3 000 rows measured the same step time within 0.2 ms)
+        if self.conv_stats and self.precision == L.PREC_BF16 and not relu and out is None and co % 32 == 0 and B * Ho * Wo <= self.conv_stats_max_m:
             y.stats = torch.empty(((B * Ho * Wo + 31) // 32) * 2 * co, dtype=torch.float64, device=self.device)
         self._conv_call(x.t, wp, bias if bias is not None else self._const(self._zeros, co, 0.0), y.t, kh, kw, stride, pad, relu, False, x_bf=x.bf, stats=y.stats)
 
