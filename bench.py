@@ -57,9 +57,8 @@ def parse():
                          "streams; sequential: back-to-back _call_cnn")
     ap.add_argument("--in-flight", type=int, default=2, help="frames executing concurrently in --mode streams")
     ap.add_argument("--lanes", type=int, default=0, help="--mode interleaved: software-pipelined frame streams on this many HIP streams, group p on lane "
-                                                          "p mod L (pipeline.run_interleaved(lanes=L)); results are bit-identical for every L.  0 (default): 3 for "
-                                                          "the fp32 leg with --frames-per-launch > 1, else 2 (the mixed leg with 3 lanes measured 562..712 frames/s "
-                                                          "at 20 steps depending on the box -- its host side is then the limit -- against 652..681 with 2; DESIGN 4.5)")
+                                                          "p mod L (pipeline.run_interleaved(lanes=L)); results are bit-identical for every L.  0 (default): 3 with "
+                                                          "--frames-per-launch > 1 (both legs: DESIGN 4.5), else 2")
     ap.add_argument("--frames-per-launch", type=int, default=2,
                     help="--mode interleaved: this many consecutive items of the stream share every launch of a tick (pipeline.run_interleaved("
                          "frames_per_launch=F): the frame program is recorded for batch F x B; items stay --batch frames each, with their own "
@@ -192,7 +191,7 @@ def measure(args, dev, rank, world, precision):
     import torch.distributed as dist
     os.environ["VIDC_PRECISION"] = precision
     H, W, B = args.height, args.width, args.batch
-    lanes = args.lanes if args.lanes > 0 else (3 if (precision == "fp32" and args.frames_per_launch > 1 and args.mode == "interleaved") else 2)
+    lanes = args.lanes if args.lanes > 0 else (3 if (args.frames_per_launch > 1 and args.mode == "interleaved") else 2)
     pipe, sn_sd, dc_sd, cc, det_sd = build_pipeline(H, W, dev, args.plane_head)
 
     # frame f of the job is a function of (seed, f) only: rank r takes frames r, r+world, ... (round-robin shards)
