@@ -498,6 +498,21 @@ class DepthCompletionPipeline:
             yield out
 
 
+_LANE_STREAMS = {}
+
+
+def _lane_stream(device, index):
+    """The HIP stream of lane `index` on `device`, ONE per process: every pipeline object's lane k runs on the same stream.  The runtime
+    multiplexes streams onto a few hardware queues (4 by default); a second pipeline that created three fresh streams after the first one's
+    (bench.py's mixed leg after its fp32 leg) got two of its lanes onto one queue, where their kernels serialise: 588 frames/s against 734
+    for the same leg in a process of its own.  Streams created once, early, keep the mapping they were measured with."""
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), index)
+    st = _LANE_STREAMS.get(key)
+    if st is None:
+        st = _LANE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class _GroupLane:
     """One lane of `DepthCompletionPipeline._run_grouped`: a frame program recorded for batch F x B whose batch slots hold F consecutive
     items of the stream, a plane block per slot (an item's plane buffers live from its hypothesis draws to its enrichment, which for the
@@ -507,7 +522,7 @@ class _GroupLane:
         self.pipe, self.index, self.F = pipe, index, F
         ent = pipe.__dict__.setdefault("_group_lane_cache", {}).setdefault((index, F), {})
         if "stream" not in ent:
-            ent["stream"] = torch.cuda.Stream(device=pipe.device)
+            ent["stream"] = _lane_stream(pipe.device, index)
             ent["planes"] = [PlaneBlock() for _ in range(F)]
             ent["stagers"] = [_Stager() for _ in range(F)]
         self.cache, self.stream, self.planes, self.stagers = ent, ent["stream"], ent["planes"], ent["stagers"]
