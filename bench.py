@@ -25,6 +25,12 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 _T0 = time.perf_counter()
+if "--train" in sys.argv:
+    # The training step runs on five HIP streams (main + up to four lanes); the runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
+    # queues (default 4), so two lanes share a queue and their kernels serialise: 26.3-26.5 against 26.7-26.9 ms per step with 8 queues.
+    # (The inference stream mode, three lanes + the caller's stream, is FASTER with the default 4: 362 against 311 frames/s -- not set there.)
+    # Read by the runtime when it initialises, i.e. at the first device call of this process.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from vi_depth_completion_amd import sharding, synthetic as S   # noqa: E402
 
