@@ -25,9 +25,18 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 _T0 = time.perf_counter()
-if "--train" in sys.argv:
+
+
+def _one_rank_job():
+    gpus = [a.split("=", 1)[1] if "=" in a else (sys.argv[i + 1] if i + 1 < len(sys.argv) else "1") for i, a in enumerate(sys.argv) if a == "--gpus" or a.startswith("--gpus=")]
+    return int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("VIDC_DIST_WORLD1", "0") != "1" and (not gpus or gpus[-1] == "1")
+
+
+if "--train" in sys.argv and _one_rank_job():
     # The training step runs on five HIP streams (main + up to four lanes); the runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
-    # queues (default 4), so two lanes share a queue and their kernels serialise: 26.3-26.5 against 26.7-26.9 ms per step with 8 queues.
+    # queues (default 4), so two lanes share a queue and their kernels serialise: 26.3-26.5 against 26.7-27.4 ms per step with 8 queues.
+    # ONE rank without a process group only: across ranks the step is two captured graphs with the decoder's all-reduce in between, and
+    # that form runs ~2x slower with more than 4 queues (50-57 against 27.3-28.3 ms; profiles/r4_train_side_stream_experiments.txt).
     # (The inference stream mode, three lanes + the caller's stream, is FASTER with the default 4: 362 against 311 frames/s -- not set there.)
     # Read by the runtime when it initialises, i.e. at the first device call of this process.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
