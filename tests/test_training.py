@@ -442,6 +442,44 @@ def test_batched_weight_packing_equals_the_per_layer_packs():
 
 
 @gpu
+@pytest.mark.parametrize("offset", [0, 1, 3])
+def test_batched_pack_plain_bf16_layouts(offset):
+    """Kinds 4 / 5 of the batched re-packing (plain bf16, the training mode of configs[4]) against the layouts include/vidc.h states,
+    written out with torch: forward [co][ci/64][kh][kw][64] and dgrad [ci][co/64][KH-1-kh][KW-1-kw][64], round-to-nearest-even.  The
+    parameters sit at 4-, 8- and 16-byte alignments (views of one flat buffer, as in the trainer), several items per launch."""
+    from vi_depth_completion_amd import _lib as L
+    lib, st = L.lib(), L.current_stream()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 64, 1), (128, 64, 3), (64, 192, 1), (192, 128, 3), (256, 1024, 1), (1024, 256, 1), (64, 8, 3), (128, 72, 1), (64, 24, 3)]
+    flat = torch.randn(offset + sum(co * ci * k * k + 5 for co, ci, k in shapes), generator=g).to(DEV)
+    items, want, o = [], [], offset
+    for co, ci, k in shapes:
+        w = flat[o:o + co * ci * k * k].view(co, ci, k, k)
+        o += w.numel() + 5
+        for kind in (4, 5):
+            if (ci if kind == 4 else co) % 64:
+                assert lib.vidc_pack_item_blocks(co, ci, k, k, kind) == 0
+                continue
+            if kind == 4:
+                ref = w.view(co, ci // 64, 64, k, k).permute(0, 1, 3, 4, 2)
+            else:
+                ref = w.flip(2, 3).reshape(co // 64, 64, ci, k, k).permute(2, 0, 3, 4, 1)
+            want.append(ref.contiguous().to(torch.bfloat16).reshape(-1))
+            items.append((w, co, ci, k, kind))
+    outs = [torch.full((w.numel() // 2,), float("nan"), device=DEV) for w, *_ in items]
+    table = (L.PackItem * len(items))()
+    blocks = 0
+    for t, (w, co, ci, k, kind), out in zip(table, items, outs):
+        t.w, t.packed, t.Cout, t.Cin, t.KH, t.KW, t.kind, t.block_begin = L.ptr(w), L.ptr(out), co, ci, k, k, kind, blocks
+        blocks += lib.vidc_pack_item_blocks(co, ci, k, k, kind)
+    dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(DEV)
+    L.check(lib.vidc_pack_conv_weights_batched(L.ptr(dev), len(items), blocks, st), "batched pack")
+    for (w, co, ci, k, kind), out, ref in zip(items, outs, want):
+        got = out.view(torch.bfloat16)
+        assert torch.equal(got.view(torch.int16).cpu(), ref.view(torch.int16).cpu()), "kind %d of %s" % (kind, tuple(w.shape))
+
+
+@gpu
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 def test_training_iteration_vs_reference(golden_dir, seeded_weights, monkeypatch, precision):
     """(precision: the arithmetic of the forward / dgrad convs.  fp32 = exact products like the reference, the trainer's default: the
