@@ -471,6 +471,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.set_grad_enabled(False)
+    if not args.train:
+        # the stream mode's lanes take their hardware queues before RCCL makes its streams (else a lane shares the caller's queue: 324 instead
+        # of 363 frames/s in fp32 with a process group present -- the N > 1 runs would read as a scaling loss that is none)
+        from vi_depth_completion_amd.pipeline import reserve_lane_streams
+        reserve_lane_streams(dev, args.lanes if args.lanes > 0 else 3)
     if world > 1:
         # N ranks share the host: keep every rank's torch CPU pool (synthetic inputs are generated on the CPU before the timed region)
         # to its share of the cores, so that N pools of spinning OpenMP workers do not slow the N launching threads down

@@ -222,6 +222,23 @@ def test_prepare_interleaved_builds_every_lane(seeded_weights, monkeypatch):
     assert p.frame_program(1, 240, 320).captured
 
 
+def test_reserved_lane_streams_are_the_ones_the_lanes_run_on(seeded_weights, monkeypatch):
+    """`reserve_lane_streams` (called by bench.py before the process group exists, so that the lanes take their hardware queues before
+    RCCL's streams) creates the process-wide streams; every pipeline's lane k then runs on exactly that stream."""
+    from vi_depth_completion_amd import pipeline as P
+    monkeypatch.setenv("VIDC_PRECISION", "mixed")
+    P.reserve_lane_streams("cuda", 3)
+    mine = [P._lane_stream("cuda", k) for k in range(3)]
+    assert len({s.cuda_stream for s in mine}) == 3 and all(s.cuda_stream != torch.cuda.default_stream().cuda_stream for s in mine)
+    P.reserve_lane_streams(torch.device("cuda", torch.cuda.current_device()), 2)           # idempotent
+    assert [P._lane_stream("cuda", k).cuda_stream for k in range(3)] == [s.cuda_stream for s in mine]
+    p = _pipe(seeded_weights, "mixed")
+    p.prepare_interleaved(_frames(430, 1)[0], lanes=3, frames_per_launch=2)
+    assert [p._group_lane_cache[(k, 2)]["stream"].cuda_stream for k in range(3)] == [s.cuda_stream for s in mine]
+    with pytest.raises(RuntimeError, match="GPU"):
+        P.reserve_lane_streams("cpu", 2)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "mixed"])
 def test_bench_shape_paired_stream_vs_oracle(seeded_weights, precision, monkeypatch):
     """The configuration bench.py times -- 320x256, batch-1 items, three lanes, two items per launch, plane mask fixed -- against the CPU

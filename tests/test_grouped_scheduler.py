@@ -188,3 +188,10 @@ def test_plane_block_id_map_cache_keys_on_content():
     g4 = pb._groups_of([wide], st4)
     assert [c for c, _ in g4[0]] == [1, 2]
     assert plane.plane_groups(np.zeros((3, 3), dtype=np.uint8)) == []        # only background: main.py:135-137
+
+
+def test_reserving_lane_streams_needs_a_gpu():
+    """(the GPU side is in test_frames_per_launch.py) no silent no-op on a CPU device: the product path has no CPU fallback"""
+    from vi_depth_completion_amd import pipeline as P
+    with pytest.raises(RuntimeError, match="GPU"):
+        P.reserve_lane_streams("cpu", 3)

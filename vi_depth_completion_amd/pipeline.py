@@ -513,6 +513,23 @@ def _lane_stream(device, index):
     return st
 
 
+def reserve_lane_streams(device, lanes=3):
+    """Creates the process-wide lane streams of `device` and runs one launch on each, so that they take their hardware queues NOW.  The
+    runtime binds a stream to the least-used of its 4 hardware queues at the stream's first launch; streams that came first keep a queue
+    of their own.  Call this before anything else makes streams on the device -- in particular before `init_process_group("nccl")` / the
+    first RCCL collective: with RCCL's streams in place first, the third lane shares the caller's queue and the stream mode measured
+    324 instead of 363 frames/s (fp32) and 577 instead of 733 (mixed) on one MI355X (profiles/r4_lane_streams_hw_queues.txt)."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("reserve_lane_streams: a GPU device is required (no CPU fallback)")
+    probe = torch.zeros(64, device=dev)
+    torch.cuda.current_stream(dev).synchronize()
+    for i in range(int(lanes)):
+        with torch.cuda.stream(_lane_stream(dev, i)):
+            probe.add_(1.0)
+    torch.cuda.synchronize(dev)
+
+
 class _GroupLane:
     """One lane of `DepthCompletionPipeline._run_grouped`: a frame program recorded for batch F x B whose batch slots hold F consecutive
     items of the stream, a plane block per slot (an item's plane buffers live from its hypothesis draws to its enrichment, which for the
