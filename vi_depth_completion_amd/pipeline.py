@@ -122,6 +122,7 @@ class DepthCompletionPipeline:
             raise RuntimeError("DepthCompletionPipeline needs a GPU: the HIP path has no CPU fallback")
         self.args = argparse.Namespace(enriched_samples=enriched_samples)
         self.device = torch.device(device)
+        reserve_lane_streams(self.device, 3)         # (process-wide, idempotent: the stream mode's lanes take their hardware queues as early as possible)
         self.cnn = network_class_creator().to(self.device)                                   # network_run.py:422-424
         self.use_gravity = bool(use_gravity)
         if self.use_gravity:
@@ -522,9 +523,13 @@ def reserve_lane_streams(device, lanes=3):
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("reserve_lane_streams: a GPU device is required (no CPU fallback)")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    fresh = [i for i in range(int(lanes)) if (idx, i) not in _LANE_STREAMS]
+    if not fresh:
+        return
     probe = torch.zeros(64, device=dev)
     torch.cuda.current_stream(dev).synchronize()
-    for i in range(int(lanes)):
+    for i in fresh:
         with torch.cuda.stream(_lane_stream(dev, i)):
             probe.add_(1.0)
     torch.cuda.synchronize(dev)
