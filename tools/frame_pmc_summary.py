@@ -26,7 +26,7 @@ def load(path):
 
 def main():
     f, w, c = load(sys.argv[1]), load(sys.argv[2]), load(sys.argv[3])
-    ticks = 20
+    ticks = int(sys.argv[4]) if len(sys.argv) > 4 else 20      # replays of tools/frame_replay.py (its argument)
     rows = []
     for name in f:
         if name.startswith("at::") or name.startswith("__amd") or "elementwise" in name:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Builds the software-pipelined frame program (320x256; batch = VIDC_REPLAY_BATCH, default 2 = what run_interleaved(frames_per_launch=2)
+"""Builds the software-pipelined frame program (320x256; batch = VIDC_REPLAY_BATCH, default 4 = what run_interleaved(frames_per_launch=4)
 records for a batch-1 stream since round 4) and replays its two hipGraph segments N times: the smallest process
 that runs the frame's kernels in their real order with HBM-cold weights -- a target for `rocprofv3 --pmc` passes (counter collection on
 the whole bench.py process crashes inside rocprofv3 on this pool).
@@ -18,7 +18,7 @@ from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, build_fram
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    H, W, B = 256, 320, int(os.environ.get("VIDC_REPLAY_BATCH", "2"))
+    H, W, B = 256, 320, int(os.environ.get("VIDC_REPLAY_BATCH", "4"))
     dev = torch.device("cuda")
     torch.set_grad_enabled(False)
     cc = (0.5 * 319.87654, 0.5 * 239.87603 * H / 240.0)

@@ -4,7 +4,7 @@ for every conv kernel instantiation of a leg -- per-launch FETCH_SIZE x 2 + WRIT
 the ALGORITHMIC bytes of its average launch -- what the fused op has to move at 4 bytes per element: input pixels x Cin, weights, the
 residual it adds (VIDC_RESIDUAL), the tensor it accumulates into (VIDC_ACCUM), the fp32 output unless VIDC_NO_F32_OUT and the split-bf16
 image of the output if VIDC_SPLIT_OUT -- from the signatures and flags of the ops that run on it (the frame program recorded in dry-run
-mode on the CPU, 320x256, batch VIDC_REPLAY_BATCH (default 2: two stream items per launch): the same op list the counters were taken on).  bench.py reports the entry of a leg's dominant kernel
+mode on the CPU, 320x256, batch VIDC_REPLAY_BATCH (default 4: four stream items per launch): the same op list the counters were taken on).  bench.py reports the entry of a leg's dominant kernel
 as roofline.traffic.
 
     python tools/pmc_to_json.py profiles/r3_frame_pmc_mixed.txt mixed "rocprofv3 ... frame_replay.py 20" [--out profiles/pmc_traffic.json]
@@ -28,7 +28,7 @@ def frame_op_names(mode):
     H = 256
     sn = SurfaceNormalPrediction(fc_img=np.array([202.0, 202.0]), cc_img=np.array([0.5 * 319.87654, 0.5 * 239.87603 * H / 240.0]), output_size=(H, 320)).eval()
     dc = ModifiedFPN().eval()
-    return build_frame_program(sn, dc, int(os.environ.get("VIDC_REPLAY_BATCH", "2")), H, 320, torch.device("cpu"), dry_run=True).op_names
+    return build_frame_program(sn, dc, int(os.environ.get("VIDC_REPLAY_BATCH", "4")), H, 320, torch.device("cpu"), dry_run=True).op_names
 
 
 def main():
@@ -66,7 +66,7 @@ def main():
         if kern not in alg:
             continue
         wkb = float(wk) if wk.lower() != "nan" else 0.0
-        table[kern] = {"round": 4, "program_batch": int(os.environ.get("VIDC_REPLAY_BATCH", "2")), "launches_per_tick": calls, "avg_us_under_counter_collection": us,
+        table[kern] = {"round": 4, "program_batch": int(os.environ.get("VIDC_REPLAY_BATCH", "4")), "launches_per_tick": calls, "avg_us_under_counter_collection": us,
                        "fetch_bytes": int(fk * 1024), "write_bytes": int(wkb * 1024), "traffic_bytes": int((fk + wkb) * 1024),
                        "algorithmic_bytes": int(alg[kern] / cnt[kern]), "traffic_over_algorithmic": round((fk + wkb) * 1024 / (alg[kern] / cnt[kern]), 3),
                        "mfma_busy_fraction": (round(float(busy) / 100.0, 4) if busy.lower() != "nan" else None),
