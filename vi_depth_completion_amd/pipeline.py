@@ -298,8 +298,10 @@ class DepthCompletionPipeline:
     @torch.no_grad()
     def prepare_interleaved(self, sample_batch, lanes=None, frames_per_launch=None):
         """Builds, captures and uploads the frame programs of EVERY lane of `run_interleaved(lanes, frames_per_launch)` for batches shaped
-        like `sample_batch` (normally that happens when a lane sees its first item).  Set-up, not a step: a stream shorter than
-        lanes x frames_per_launch items would otherwise leave a lane's program to be recorded inside a later stream -- e.g. a timed one."""
+        like `sample_batch` (normally that happens when a lane sees its first item), and -- if `sample_batch` is a whole batch -- runs it
+        once through every batch slot of every lane (the slots' plane blocks allocate on first use; `self.rng` is not touched).  Set-up, not
+        a step: a stream shorter than lanes x frames_per_launch items would otherwise leave a lane's program to be recorded, and its
+        slots' buffers to be allocated, inside a later stream -- e.g. a timed one."""
         import os
         n = int(lanes if lanes is not None else os.environ.get("VIDC_LANES", "1"))
         fpl = int(frames_per_launch if frames_per_launch is not None else os.environ.get("VIDC_FRAMES_PER_LAUNCH", "1"))
@@ -313,6 +315,14 @@ class DepthCompletionPipeline:
             with torch.cuda.stream(lane.stream):
                 lane._prepare(rgb)
         torch.cuda.synchronize(self.device)
+        if all(k in sample_batch for k in ("sparse_depth", "gravity", "aligned_direction", "homogeneous_coordinates")):
+            # ... and one item through every batch slot of every lane, with a generator of its own: a slot's plane block allocates its device
+            # buffers and its pinned host buffers when it sees its first item -- for the slots a short warm-up does not reach (5 items touch 5
+            # of the 12 slots of 3 lanes x 4 items) that was inside the caller's timed region, several host allocations of ~0.5 ms each
+            throwaway = np.random.RandomState(0)
+            for _ in self._run_grouped(iter([sample_batch] * (n * fpl)), True, n, fpl, lambda i: throwaway):
+                pass
+            torch.cuda.synchronize(self.device)
 
     def _run_grouped(self, batches, copy_outputs, n_lanes, F, frame_rng):
         """run_interleaved with F items per launch (see there).  Group p = items F*p .. F*p+F-1 runs on lane p mod L.  Per lane and group
