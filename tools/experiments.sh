@@ -487,7 +487,34 @@ import json,sys; d=json.loads(sys.stdin.read()); print('F=4 lanes $L K $K: fp32'
 done; done
 }
 
+r4_hw_queues() {
+# round 4: GPU_MAX_HW_QUEUES against the inference stream mode and the training step (one graph / two graphs through a one-rank RCCL group)
+# -- profiles/r4_lane_streams_hw_queues.txt, r4_train_side_stream_experiments.txt
+line() { grep '^{' | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d.get('value'), d.get('value_mixed'), d.get('ms_per_step'))"; }
+for Q in 2 3 4 5 6 8; do GPU_MAX_HW_QUEUES=$Q python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs --no-sequential-leg 2>/dev/null | line "inference Q=$Q:"; done
+for Q in 3 4 5 6 8 12; do
+GPU_MAX_HW_QUEUES=$Q VIDC_TRAIN_PRECISION=bf16 python bench.py --train --batch 8 --steps 10 --warmup 3 2>/dev/null | line "train, one graph Q=$Q:"
+GPU_MAX_HW_QUEUES=$Q VIDC_DIST_WORLD1=1 VIDC_TRAIN_PRECISION=bf16 python bench.py --train --batch 8 --steps 10 --warmup 3 2>/dev/null | line "train, two graphs + RCCL world 1 Q=$Q:"
+done
+}
+
+r4_rccl_group() {
+# round 4: the stream mode with and without a (one-rank) RCCL process group in the process -- profiles/r4_lane_streams_hw_queues.txt
+for rep in 1 2; do for w in 0 1; do
+VIDC_DIST_WORLD1=$w python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs --no-sequential-leg 2>/dev/null | grep '^{' | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('RCCL world-1 group $w:', d['value'], d['value_mixed'])"
+done; done
+}
+
+r4_items_and_lanes() {
+# round 4: items per launch x lanes at 20 / 200 steps (DESIGN 5.1's table)
+for K in 20 200; do for FL in "2 3" "4 2" "4 3"; do set -- $FL
+python bench.py --gpus 1 --steps $K --warmup $((K/10+3)) --no-cpu-baseline --no-extra-legs --no-sequential-leg --frames-per-launch $1 --lanes $2 2>/dev/null | grep '^{' | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('F=$1 lanes=$2 K=$K:', d['value'], d['value_mixed'], d['first_item_latency_ms'])"
+done; done
+}
+
 case "$1" in
-  list|"") echo "experiments: r4_four_items r4_schedulers_f1 r4_waves3 r3_b r3_c r3_d2 r3_early r3_lds_cap r3_pipelined r3_plane_side r3_prefetch r3_train_add r3_train_bnadd r3_train_dyt r3_train_pack r3_train_retune r3_train_skip r3_train_tail r3_train_tickets r3_train_timeline r3_train_xt r3_train_xt3 r3_tune_b2 r3_tune_b8 r3_tune_b8_lanes r3_tune_detector r3_tune_fp32 r3_tune_fp32_again r3_tune_mixed r3_variants r3_xb r4_bnfold r4_lanes r4_newtests r4_pairing r4_perop r4_stagger r4_timeline" ;;
+  list|"") echo "experiments: r4_hw_queues r4_rccl_group r4_items_and_lanes r4_four_items r4_schedulers_f1 r4_waves3 r3_b r3_c r3_d2 r3_early r3_lds_cap r3_pipelined r3_plane_side r3_prefetch r3_train_add r3_train_bnadd r3_train_dyt r3_train_pack r3_train_retune r3_train_skip r3_train_tail r3_train_tickets r3_train_timeline r3_train_xt r3_train_xt3 r3_tune_b2 r3_tune_b8 r3_tune_b8_lanes r3_tune_detector r3_tune_fp32 r3_tune_fp32_again r3_tune_mixed r3_variants r3_xb r4_bnfold r4_lanes r4_newtests r4_pairing r4_perop r4_stagger r4_timeline" ;;
   *) name="$1"; shift; if declare -F "$name" > /dev/null; then "$name" "$@"; else echo "unknown experiment $name (bash tools/experiments.sh list)"; exit 2; fi ;;
 esac
