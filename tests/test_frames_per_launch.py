@@ -124,19 +124,20 @@ def _golden_names(golden_dir):
     return sorted(n[:-4] for n in os.listdir(golden_dir) if (n.startswith("demo_0") or n == "synthetic_f0.npz") and n.endswith(".npz"))
 
 
-def test_paired_stream_vs_the_reference_golden_depth(pipe_mode, golden_dir):
+@pytest.mark.parametrize("F,lanes", [(2, 2), (4, 3)])
+def test_paired_stream_vs_the_reference_golden_depth(pipe_mode, golden_dir, F, lanes):
     """Every golden frame (real images, real VI-SLAM points; host-resident batches like the reference's DataLoader hands out) through
-    the paired two-lane stream, each frame drawing from the generator state of its golden run: depth RMSE against the REFERENCE's
-    output below the `_call_cnn` bars -- mixed 1e-3 (north_star), fp32 2e-5."""
+    the grouped stream (two items per launch on two lanes; four on three lanes, what bench.py runs), each frame drawing from the
+    generator state of its golden run: depth RMSE against the REFERENCE's output below the `_call_cnn` bars -- mixed 1e-3 (north_star), fp32 2e-5."""
     pipe, mode = pipe_mode
     names = _golden_names(golden_dir)
     fs = [np.load(os.path.join(golden_dir, n + ".npz")) for n in names]
     frames = [_golden_batch(f, n) for f, n in zip(fs, names)]
-    outs = [o.cpu() for o in pipe.run_interleaved(iter(frames), lanes=2, frames_per_launch=2, frame_rng=lambda i: np.random.RandomState(int(fs[i]["np_seed"])))]
+    outs = [o.cpu() for o in pipe.run_interleaved(iter(frames), lanes=lanes, frames_per_launch=F, frame_rng=lambda i: np.random.RandomState(int(fs[i]["np_seed"])))]
     assert len(outs) == len(names) >= 5
     for n, f, o in zip(names, fs, outs):
         rmse = float(np.sqrt(np.mean((o[0, 0].numpy() - f["depth"]) ** 2)))
-        assert rmse < (2e-5 if mode == "fp32" else 1e-3), (mode, n, rmse)
+        assert rmse < (2e-5 if mode == "fp32" else 1e-3), (mode, F, n, rmse)
         assert float(o.min()) >= 0.0
 
 
