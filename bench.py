@@ -637,7 +637,7 @@ def main():
 
 
 def run_extra_legs(args):
-    """Driver-visible numbers for BASELINE configs[4] and configs[2]: each one is THIS script started as a child process
+    """Driver-visible numbers for BASELINE configs[4] and configs[2] and for the stream mode's two-items-per-launch setting: each one is THIS script started as a child process
     (its own GPU context, its own environment; a crash or a hang there cannot take the headline down) after both main legs have been
     measured and before the line is printed.  Skipped once the wall clock of this run passes --extra-legs-budget."""
     import subprocess
@@ -647,7 +647,11 @@ def run_extra_legs(args):
               ["--train", "--batch", "8", "--steps", "5", "--warmup", "3"]),
              ("configs[2] 640x480 stream, batch 8, Mask R-CNN plane head every frame", {},
               ["--batch", "8", "--source", "640x480", "--height", "240", "--plane-head", "--steps", "20", "--warmup", "4", "--frames-per-launch", "1",
-               "--no-cpu-baseline", "--no-sequential-leg", "--no-extra-legs"])]
+               "--no-cpu-baseline", "--no-sequential-leg", "--no-extra-legs"]),
+             # the headline runs four items per launch (first depth map of a stream after ~26 ms); this is the same workload at the
+             # lower-latency setting of the knob (two items per launch, ~15 ms), in the headline's arithmetic
+             ("configs[1] with two items per launch (lower first-item latency), fp32", {},
+              ["--steps", "20", "--warmup", "5", "--frames-per-launch", "2", "--no-mixed-leg", "--no-cpu-baseline", "--no-sequential-leg", "--no-extra-legs"])]
     for name, env_add, flags in specs:
         if time.perf_counter() - t_start > args.extra_legs_budget:
             out[name] = {"skipped": "wall-clock budget of the run (%.0f s) used up" % args.extra_legs_budget}
@@ -663,7 +667,7 @@ def run_extra_legs(args):
                 continue
             d = json.loads(lines[-1])
             out[name] = {k: d.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "rmse_vs_oracle", "value_mixed", "ms_per_step_mixed",
-                                                       "dtype_mixed", "losses", "config")
+                                                       "dtype_mixed", "losses", "first_item_latency_ms", "config")
                          if d.get(k) is not None}
             out[name]["roofline"] = {k: (d.get("roofline") or {}).get(k) for k in ("bound", "achieved", "peak", "unit", "frac")}
             out[name]["command"] = "bench.py --gpus 1 " + " ".join(flags) + ("  [" + " ".join("%s=%s" % kv for kv in env_add.items()) + "]" if env_add else "")

@@ -159,7 +159,7 @@ def test_extra_legs_can_never_take_the_headline_down(monkeypatch):
     monkeypatch.setattr(bench, "_T0", time.perf_counter())
     out = bench.run_extra_legs(argparse.Namespace(extra_legs_budget=75.0))
     names = list(out)
-    assert len(names) == 2 and "configs[4]" in names[0] and "configs[2]" in names[1]
+    assert len(names) == 3 and "configs[4]" in names[0] and "configs[2]" in names[1] and "two items per launch" in names[2]
     assert out[names[0]]["value"] == 290.4 and out[names[0]]["dtype"] == "bf16" and out[names[0]]["roofline"]["frac"] == 0.0864
     assert "--train" in out[names[0]]["command"] and "VIDC_TRAIN_PRECISION=bf16" in out[names[0]]["command"]
     assert "TimeoutExpired" in out[names[1]]["error"]
