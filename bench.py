@@ -74,10 +74,11 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0, help="--mode interleaved: software-pipelined frame streams on this many HIP streams, group p on lane "
                                                           "p mod L (pipeline.run_interleaved(lanes=L)); results are bit-identical for every L.  0 (default): 3 with "
                                                           "--frames-per-launch > 1 (both legs: DESIGN 4.5), else 2")
-    ap.add_argument("--frames-per-launch", type=int, default=4,
+    ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="--mode interleaved: this many consecutive items of the stream share every launch of a tick (pipeline.run_interleaved("
                          "frames_per_launch=F): the frame program is recorded for batch F x B; items stay --batch frames each, with their own "
-                         "gravity, plane block and draws in _call_cnn order).  1 = one item per launch (rounds 1-3).  The throughput / latency "
+                         "gravity, plane block and draws in _call_cnn order).  1 = one item per launch (rounds 1-3); 0 (default) = 4 for batch-1 items, 1 for "
+                         "items that are batches themselves (--batch > 1: the measured tile table covers those program batches).  The throughput / latency "
                          "knob of the stream mode: 4 (default; ResNet-101 layer 3 at M = 1280 = exactly 5 workgroups per CU) measures 373-377 "
                          "frames/s in fp32 at 20 steps with the first item complete after 26 ms, 2 measures 361-364 with 15 ms (DESIGN 5.1)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="only the mixed-mode leg (bf16x3 MFMA on the layers the measured table selects): it becomes "
@@ -98,7 +99,10 @@ def parse():
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no GPU work: every rank only joins the process group and gathers a fake record (tests/test_bench_launcher.py runs "
                          "`bench.py --gpus 2 --launcher-selftest` under gloo on the CPU: spawn, rendezvous, gather, the n_gpus check)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.frames_per_launch <= 0:
+        args.frames_per_launch = 4 if args.batch == 1 else 1
+    return args
 
 
 def launch_ranks(args):
