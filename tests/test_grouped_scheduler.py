@@ -135,12 +135,13 @@ def test_draw_order_launch_order_and_outputs(n_items, lanes, F, monkeypatch):
     assert sorted(d[2] for d in decs) == [b[2] for b in begins], "every group's depth decoder runs exactly once"
     assert sum(1 for e in log if e[0] == "drain") == min(lanes, n_groups), "every lane that ran is drained once"
     for d in (e for e in log if e[0] == "decoder"):
-        # in the lane's next visit: after that visit's first hypotheses, before its first enrichment wait
+        # in the lane's next visit: after that visit's LAST hypotheses (no item's plane kernels queue behind the decoder on the lane's
+        # stream), before the wait for that item's counts
         grp = d[2]
         p = grp[0] // F
-        first_next = F * (p + lanes)
+        last_next = min(n_items, F * (p + lanes) + F) - 1
         k = log.index(d)
-        assert log[k - 1] == ("hyp", d[1], first_next) and log[k + 1] == ("enrich", d[1], first_next)
+        assert log[k - 1] == ("hyp", d[1], last_next) and log[k + 1] == ("enrich", d[1], last_next)
 
 
 def test_unowned_outputs_mark_the_lane_consumed(monkeypatch):

@@ -333,8 +333,12 @@ class DepthCompletionPipeline:
             hypotheses(i+1), ... -- which is the order back-to-back `_call_cnn` calls consume the generator in;
           * the LAUNCH sequence, which runs ahead of it: segment 0 of group p+L is launched as soon as group p is enriched (it needs
             nothing else), i.e. before the draw sequence turns to group p+1 on the next lane -- so whenever the host waits for an item's
-            counts, the other lane has a whole segment 0 queued.  Segment 1 of a visit is launched after the first item's plane
-            kernels and before the wait for their counts, so the lane itself stays busy under the wait as well."""
+            counts, the other lane has a whole segment 0 queued.  Segment 1 of a visit (the previous group's decoder) is launched
+            after the LAST item's plane kernels and before the wait for their counts: launched earlier (after the first item's, as until
+            the end of round 4) the later items' plane kernels queued behind ~1.5 ms of decoder on the lane's stream and the host sat in
+            their count waits -- mixed leg 856-874 -> 917-918 frames/s at 200 steps, fp32 395-398 -> 400-401 (VIDC_DECODER_AFTER_LAST=0:
+            the old order; same programs, same bits)."""
+        import os
         lanes = [_GroupLane(self, k, F) for k in range(n_lanes)]
         it = iter(batches)
         state = {"taken": 0}
@@ -380,10 +384,11 @@ class DepthCompletionPipeline:
         while p in groups:
             lane = lanes[p % n_lanes]
             items = groups.pop(p)
+            dec_at = (len(items) - 1) if os.environ.get("VIDC_DECODER_AFTER_LAST", "1") == "1" else 0
             for j, i in enumerate(items):
                 rng = frame_rng(i) if frame_rng is not None else self.rng
                 lane.hypotheses(j, rng)
-                if j == 0 and lane.have_prev:
+                if j == dec_at and lane.have_prev:
                     ready[p - n_lanes] = lane.decoder(copy_outputs) + (lane,)
                 lane.enrich(j, rng)
             lane.have_prev, lane.prev_n = True, len(items)
