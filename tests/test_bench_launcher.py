@@ -175,3 +175,15 @@ def test_extra_legs_can_never_take_the_headline_down(monkeypatch):
     monkeypatch.setattr(bench, "_T0", time.perf_counter() - 1000.0)
     out = bench.run_extra_legs(argparse.Namespace(extra_legs_budget=75.0))
     assert all("skipped" in v for v in out.values())
+
+
+def test_items_per_launch_default_follows_the_item_size(monkeypatch):
+    """`bench.py` without `--frames-per-launch`: four stream items per launch for batch-1 items (the configuration the metric is quoted
+    on), one for items that are batches themselves (the measured tile table covers those program batches); an explicit value wins."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    for argv, want in ((["bench.py"], 4), (["bench.py", "--batch", "8"], 1), (["bench.py", "--frames-per-launch", "2"], 2),
+                       (["bench.py", "--batch", "4", "--frames-per-launch", "2"], 2)):
+        monkeypatch.setattr(sys, "argv", argv)
+        assert bench.parse().frames_per_launch == want, argv
