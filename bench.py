@@ -174,8 +174,6 @@ TILE_TEMPLATE = {"128x128": (128, 128, 2, 2, 1, 2), "128x64": (128, 64, 2, 2, 1,
 
 
 def kernel_name(tile, prec):
-    if tile == "chain64x64k2d4":
-        return "conv_chain_kernel<4, %d>" % prec
     return "conv_igemm_f32<%s, %d, %d>" % (", ".join(str(v) for v in TILE_TEMPLATE[tile]), prec, 2 if tile.endswith("P") else int(tile.endswith("L")))
 
 
@@ -193,11 +191,6 @@ def conv_stack_times(prog, iters=5):
         total = graph_ms
     out = {}
     for n, t in zip(prog.op_names, per):
-        if n.startswith("chain:"):        # one persistent launch over a run of convs: "chain:<n convs>:<first key>:<mode>:F<flops> ..."
-            _c, n_convs, _key, mode, rest = n.split(":", 4)
-            kern = ("chain64x64k2d4", mode)
-            ms, cnt, fl = out.get(kern, (0.0, 0, 0.0))
-            out[kern] = (ms + t, cnt + 1, fl + float(rest.split(" ")[0][1:]))
         if n.startswith("conv:"):
             _c, _key, tile, _sk, rest = n.split(":", 4)
             kern = (tile, "bf16x3" if rest.startswith("bf16x3 ") else "fp32")

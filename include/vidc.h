@@ -163,6 +163,30 @@ size_t vidc_conv2d_workspace_bytes(const vidc_conv_desc* d);
 /* Fills d->tile / d->splitk with the heuristic choice for this shape on the current device. */
 int vidc_conv2d_plan(vidc_conv_desc* d);
 
+/* ---- Winograd F(m x m, 3x3), m = 2 or 4, for the 3x3 / stride 1 / pad 1 Conv2d + BatchNorm2d + ReLU layers (the decoders'
+ * `nn.Conv2d(c, c, 3, 1, 1)`: surface_normal.py:75,84,96,104,116,124,132,141; depth_completion.py:77,86,98,106,118,126,134,143) --------
+ * conv = output_transform( GEMM( input_transform(x), weight_transform(w) ) ) with a = m + 2:
+ *   V, M : [tile][gg][pos][Cin | Cout] rows of a*a*C values (C = G * Cin resp. G * Cout; group gg of the NHWC tensor sits at channel
+ *          gg * Cin), tile = (b * th + ty) * tw + tx, th = ceil(H / m), tw = ceil(W / m) (vidc_winograd_tiles), pos = xi * a + nu;
+ *   U    : [pos][Cout][Cin] per group.
+ * The GEMM is vidc_conv2d_bn_act as a 1x1 conv over B = 1, H = 1, W = tiles with groups = G * a*a, x_gs = Cin, w_gs = Cout * Cin,
+ * y_gs = Cout, ldx = a*a*G*Cin, ldy = a*a*G*Cout and an identity epilogue (scale 1, shift 0, flags 0); 4 (m = 2) resp. 2.25 (m = 4)
+ * multiply-adds per output and input channel instead of 9.  fp32 throughout (U in fp64, rounded once): the oracle's whole-frame depth
+ * moves by RMSE 1.0e-6 / 1.3e-6 against the direct form (bar 1e-3). */
+int vidc_winograd_tiles(int H, int W, int m, int* th, int* tw);
+/* OIHW [Cout][Cin][3][3] -> U [a*a][Cout][Cin] = G g G^T (one group per call). */
+int vidc_winograd_weight_transform(const float* w_oihw, float* u, int Cout, int Cin, int m, vidc_stream_t stream);
+/* x NHWC [B][H][W][ldx] (C = G * Cin channels) -> V = B^T d B, zero padding 1.  split != 0: V is written as the split-bf16 image
+ * (the operand format of VIDC_PREC_BF16X3; Cin % 32 == 0) instead of fp32.  ldv: values per row of V (0 = dense, a*a*C; larger when
+ * x / v address a contiguous range of the groups of a wider tensor). */
+int vidc_winograd_input_transform(const float* x, void* v, int B, int H, int W, int C, int ldx, int Cin, int m, int split, int ldv,
+                                  vidc_stream_t stream);
+/* M -> y NHWC [B][Ho][Wo][ldy] = epilogue(A^T M A): flags = VIDC_RELU1 | VIDC_AFFINE2 | VIDC_RELU2 | VIDC_SPLIT_OUT | VIDC_NO_F32_OUT with the
+ * meaning they have in vidc_conv_desc; scale / shift: [C] (group-major, as the conv's); ldm: values per row of M (0 = dense). */
+int vidc_winograd_output_transform(const float* mm, float* y, void* y_split, const float* scale1, const float* shift1,
+                                   const float* scale2, const float* shift2, int B, int Ho, int Wo, int C, int Cout, int ldy, int m,
+                                   int flags, int ldm, vidc_stream_t stream);
+
 /* Stem conv 3x3 stride 2 pad 1, Cin in {1,3}, no BN, optional ReLU (conv1_1, surface_normal.py:17-18).
  * x: NCHW [B][Cin][H][W] -> y: NHWC [B][Ho][Wo][ldy].  w: OIHW as in the checkpoint. */
 int vidc_stem_conv3x3s2(const float* x, const float* w_oihw, float* y, int B, int Cin, int H, int W, int Cout, int ldy,
@@ -549,34 +573,15 @@ size_t vidc_stem_wgrad_scratch_bytes(int B, int Cin, int H, int W, int Cout);
 int vidc_stem_wgrad(const float* dy, const float* x_nchw, float* dw_oihw, int B, int Cin, int H, int W, int Cout, int lddy, void* scratch,
                     vidc_stream_t stream);
 
-/* ------------------------------------------------------------------------------------------------
- * Persistent conv chains.  A run of consecutive small fused convs (vidc_conv_desc, same `groups` <= 8 and precision; e.g. the 22
- * identical Bottlenecks of torchvision ResNet-101 layer3, networks/surface_normal.py:27-35) as ONE launch: group g runs entirely on
- * XCD g, layers hand over through that XCD's L2 with per-XCD item counters (no grid barrier), and the weights of the next item
- * stream in while the previous layer finishes.  Same arithmetic as vidc_conv2d_bn_act with tile VIDC_TILE_64x64_K2_D4, splitk 1
- * (bit-identical).  descs[i] may read what descs[j < i] wrote; inputs produced outside the chain must be complete before the launch.
- * create() uploads the layer table (synchronous); run() enqueues the kernel (capturable; it leaves its counters at zero); status() synchronises
- * and returns in *failed_layer the layer whose dependency wait timed out, VIDC_CHAIN_UNCLAIMED when a group's item list was not walked to its
- * end (no workgroup of the launch ran on that group's XCD), or -1.  Operands: fp32 or bf16x3 (plain bf16 is refused by create()). */
-#define VIDC_CHAIN_UNCLAIMED 0x7FFFFFFE
-typedef struct vidc_chain vidc_chain;
-int vidc_chain_create(const vidc_conv_desc* descs, int n, vidc_chain** out);
-int vidc_chain_run(vidc_chain* chain, vidc_stream_t stream);
-int vidc_chain_status(vidc_chain* chain, int* failed_layer);
-int vidc_chain_info(const vidc_chain* chain, int* n_layers, int* total_items);
-/* Debug: per-item time stamps.  enable != 0 allocates the trace buffer (later launches fill it); host_out != NULL copies it out
- * (synchronous): [workgroup][160 items][8] int64 = 100 MHz clock at item start / dependency wait begin / end / main loop end / outputs
- * drained / done counted, (layer << 32 | item), 0.  Returns the number of int64 words of the buffer. */
-int vidc_chain_trace(vidc_chain* chain, int enable, long long* host_out, int max_words);
-int vidc_chain_destroy(vidc_chain* chain);
-
 enum vidc_op_kind { VIDC_OP_CONV = 1, VIDC_OP_STEM = 2, VIDC_OP_MAXPOOL = 3, VIDC_OP_UPSAMPLE = 4, VIDC_OP_HEAD = 5,
                     VIDC_OP_WARP_PARAMS = 6, VIDC_OP_WARP_FWD = 7, VIDC_OP_WARP_INV = 8, VIDC_OP_COPY = 9, VIDC_OP_SPLIT = 10,
                     VIDC_OP_AVGPOOL = 11, VIDC_OP_NORMALIZE = 12, VIDC_OP_DET_IM2COL = 13, VIDC_OP_NEAREST2X = 14,
-                    VIDC_OP_CHAIN = 15 /* g.p[0] = vidc_chain* */, VIDC_OP_MASK = 16 /* vidc_mask_scale: p = x, image, y; i = B,h,w,C,ldx,ldy,H,W */ };
+                    /* 15: retired (persistent conv chain, removed in round 5) */ VIDC_OP_MASK = 16 /* vidc_mask_scale: p = x, image, y; i = B,h,w,C,ldx,ldy,H,W */,
+                    VIDC_OP_WINO_IN = 17  /* vidc_winograd_input_transform: p = x, v; i = B,H,W,C,ldx,Cin,m,split,ldv */,
+                    VIDC_OP_WINO_OUT = 18 /* vidc_winograd_output_transform: p = mm, y, y_split, scale1, shift1, scale2, shift2; i = B,Ho,Wo,C,Cout,ldy,m,flags,ldm */ };
 
 typedef struct vidc_generic_args {   /* arguments of the non-conv launchers, in declaration order */
-    const void* p[6];
+    const void* p[8];
     int32_t i[16];
     float f[8];
 } vidc_generic_args;

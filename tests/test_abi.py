@@ -33,7 +33,7 @@ def test_header_symbols_exported(lib):
 def test_struct_layout_matches_header():
     # vidc_conv_desc: 9 pointers, 16 int32, 5 int64, 4 int32, 1 pointer  (natural alignment)
     assert C.sizeof(L.ConvDesc) == 9 * 8 + 16 * 4 + 5 * 8 + 4 * 4 + 8
-    assert C.sizeof(L.GenericArgs) == 6 * 8 + 16 * 4 + 8 * 4
+    assert C.sizeof(L.GenericArgs) == 8 * 8 + 16 * 4 + 8 * 4
     assert C.sizeof(L.Op) == 16 + max(C.sizeof(L.ConvDesc), C.sizeof(L.GenericArgs))
 
 
@@ -111,16 +111,19 @@ import contextlib
 
 
 @contextlib.contextmanager
-def _no_chains():
-    old = os.environ.get("VIDC_CHAIN")
-    os.environ["VIDC_CHAIN"] = "0"
+def _direct_convs():
+    """Record with one direct-form launch per conv: no Winograd triples (tests/test_winograd.py::test_recorded_program_has_winograd_triples
+    covers that recording)."""
+    old = {k: os.environ.get(k) for k in ("VIDC_WINOGRAD",)}
+    os.environ["VIDC_WINOGRAD"] = "0"
     try:
         yield
     finally:
-        if old is None:
-            os.environ.pop("VIDC_CHAIN", None)
-        else:
-            os.environ["VIDC_CHAIN"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.fixture(scope="module")
@@ -132,7 +135,7 @@ def recorded_programs(lib):
     from vi_depth_completion_amd.networks.surface_normal import SurfaceNormalPrediction
     sn = SurfaceNormalPrediction(fc_img=np.array([202.0, 202.0])).eval()
     dc = ModifiedFPN().eval()
-    with _no_chains():        # the recording itself is under test here; the chain fusion pass has tests/test_chain.py
+    with _direct_convs():
         return sn.build_program(1, torch.device("cpu"), dry_run=True), dc.build_program(1, 240, 320, torch.device("cpu"), dry_run=True)
 
 
@@ -147,7 +150,7 @@ def recorded_frame_program(lib):
     from vi_depth_completion_amd.pipeline import build_frame_program
     sn = SurfaceNormalPrediction(fc_img=np.array([202.0, 202.0])).eval()
     dc = ModifiedFPN().eval()
-    with _no_chains():
+    with _direct_convs():
         return build_frame_program(sn, dc, 1, 240, 320, torch.device("cpu"), dry_run=True)
 
 

@@ -37,8 +37,8 @@ def run_shard(ids, taps):
     return out
 
 
-for label, env in (("chain graph", {}), ("chain eager", {"VIDC_EXEC": "eager"}), ("nochain graph", {"VIDC_CHAIN": "0"})):
-    for k in ("VIDC_EXEC", "VIDC_CHAIN"):
+for label, env in (("graph", {}), ("eager", {"VIDC_EXEC": "eager"}), ("graph, direct 3x3", {"VIDC_WINOGRAD": "0"})):
+    for k in ("VIDC_EXEC", "VIDC_WINOGRAD"):
         os.environ.pop(k, None)
     os.environ.update(env)
     a = run_shard([0, 1, 2, 3], None)

@@ -20,7 +20,7 @@ MAX_SEGMENTS = 4
 # vidc_conv_flags / vidc_up_flags / vidc_op_kind / vidc_conv_tile
 RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM, SPLIT_OUT, NO_F32_OUT, STATS_OUT = 1, 2, 4, 8, 16, 32, 64, 128, 256
 UP_RELU, UP_ACCUM, UP_NO_F32_OUT = 1, 2, 4
-OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY, OP_SPLIT, OP_AVGPOOL, OP_NORMALIZE, OP_DET_IM2COL, OP_NEAREST2X, OP_CHAIN, OP_MASK = range(1, 17)
+OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY, OP_SPLIT, OP_AVGPOOL, OP_NORMALIZE, OP_DET_IM2COL, OP_NEAREST2X, _OP_RETIRED_15, OP_MASK, OP_WINO_IN, OP_WINO_OUT = range(1, 19)
 TILE_AUTO = 0
 TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "64x64k2", 6: "32x64k2", 7: "32x32k4", 8: "32x128",
               9: "32x32k8", 10: "32x64k2d5", 11: "32x32k4d4", 12: "32x128d6", 13: "64x64k2d4", 14: "32x64k2L", 15: "32x64k2d5L", 16: "32x32k4d4L", 17: "64x64L", 18: "64x64k2d4L",
@@ -56,7 +56,7 @@ class ConvDesc(C.Structure):
 
 
 class GenericArgs(C.Structure):
-    _fields_ = [("p", C.c_void_p * 6), ("i", C.c_int32 * 16), ("f", C.c_float * 8)]
+    _fields_ = [("p", C.c_void_p * 8), ("i", C.c_int32 * 16), ("f", C.c_float * 8)]
 
 
 class _OpUnion(C.Union):
@@ -116,12 +116,10 @@ SIGNATURES = {
     "vidc_im2col_transposed_bf16": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_stem_wgrad_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "vidc_stem_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "vidc_chain_create": (C.c_int, [C.POINTER(ConvDesc), _i, C.POINTER(_vp)]),
-    "vidc_chain_run": (C.c_int, [_vp, _vp]),
-    "vidc_chain_status": (C.c_int, [_vp, C.POINTER(C.c_int)]),
-    "vidc_chain_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    "vidc_chain_trace": (C.c_int, [_vp, _i, _vp, _i]),
-    "vidc_chain_destroy": (C.c_int, [_vp]),
+    "vidc_winograd_tiles": (C.c_int, [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vidc_winograd_weight_transform": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
+    "vidc_winograd_input_transform": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vidc_winograd_output_transform": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_stem_conv3x3s2": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "vidc_maxpool3x3s2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vidc_upsample_bilinear_ac": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -22,10 +22,6 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;       // K-step (floats)
-#ifndef VIDC_FP32_XB
-#define VIDC_FP32_XB 0       // fp32 mode: read the first fragment set of stage s + 1 under the last MFMAs of stage s (see conv_tile).  Built,
-#endif                       // bit-identical, measured SLOWER (round 3, same box: tick 3.62 vs 3.57 ms, 321.6 vs 325.0 frames/s): off.
-constexpr int LDS_LD = 36;   // padded LDS row (floats): 144 B keeps b128 reads of 16 consecutive rows conflict-free
 
 struct ConvArgs {
     const float* x; const float* w; float* y;
@@ -149,20 +145,9 @@ __device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
 // 90 %).  For that the barrier of iteration s must also guarantee that stage s + 1 has landed: the loaders wait one stage further
 // ahead (wait_landed(s + 1)), which costs one stage of DMA look-ahead -- the ring is one slot deeper (NS = 4 for the 128x128 tile).
 // Per accumulator the MFMA order is unchanged (lo*hi, hi*lo, hi*hi of k-half 0, then of k-half 1), so results are bit-identical to SPEC 1.
-struct NoDep {
-    __device__ __forceinline__ void operator()() const {}
-    __device__ __forceinline__ void mark(int) const {}
-};
-
-// CHAIN = true: the tile runs inside the persistent chain kernel (conv_chain_kernel below), where the activations it reads were
-// written by OTHER workgroups of the same launch: `dep()` (a workgroup-wide wait) is called after the weight prologue is in flight
-// and before the first activation / residual access, and those accesses bypass the per-CU L1 (sc1), which another CU's stores never
-// refresh.  CHAIN = false: the stand-alone kernel, `dep` is a no-op.
-template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC, int SPEC, bool CHAIN, typename Dep>
-__device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const int tile_m, const int tile_n, const int kz, float* smem,
-                                          Dep&& dep) {
+template <int BM, int BN, int WMW, int WNW, int WKW, int NS, int PREC, int SPEC>
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const int tile_m, const int tile_n, const int kz, float* smem) {
     constexpr int NW = WMW * WNW * WKW, WPK = WMW * WNW;
-    constexpr int A_AUX = CHAIN ? 16 : 0;      // cache policy of the activation DMAs: sc1 = served by L2, never by a stale L1 line
     constexpr int TM = BM / (32 * WMW), TN = BN / (32 * WNW);
     constexpr int A_J = (BM / 8) / WPK, B_J = (BN / 8) / WPK;      // DMA instructions per wave per stage
     constexpr int LPS = A_J + B_J;
@@ -183,15 +168,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
     const int tid = threadIdx.x;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     constexpr int SPEC_EFF = (SPEC == 2 && PREC == 0) ? 1 : SPEC;      // the pipelined loop exists for the 16-k bf16 MFMAs only
-    // fp32 mode, "cross-barrier" fragment prefetch: a stage is 4 sub-steps of TM*TN*4 MFMAs of 64 clk, whose fragments are double-buffered
-    // from one sub-step to the next -- but the first set used to be read AFTER the stage barrier, in front of an idle matrix pipe
-    // (~150-200 clk per stage, 5-10 % of an MFMA-bound kernel).  Now the last sub-step of stage s reads the first set of stage s + 1, so
-    // the barrier of stage s must also cover stage s + 1's DMA: every wave waits one stage further ahead (wait_landed).  fp32 stages
-    // last 1000-4000 clk; needs NS >= 3 (a 2-deep ring refills the slot it would read).  Same MFMA order per accumulator: bit-identical.
-    // Measured: 1.4 % SLOWER in the frame -- with the 3-deep rings of the fp32 tilings the wait one stage further ahead drains the wave's
-    // whole DMA queue every stage, and an HBM-cold weight stage takes longer to land (~2500 clk under load) than the 3/4 stage it is now
-    // given; a 4-deep ring would cost the second workgroup per CU.  Compiled out (VIDC_FP32_XB=0); `make xb` / VIDC_LIB_NAME=libvidc_xb.so for A/B.
-    constexpr bool XB = VIDC_FP32_XB && PREC == 0 && NS >= 3 && !CHAIN;
     const bool is_loader = SPEC && wave_all >= NW;              // wave-uniform
     const bool loads = !SPEC || is_loader;                      // this wave issues DMA
     const int wave = is_loader ? wave_all - NW : wave_all;      // role-local index: loader l feeds what compute wave l would load
@@ -304,7 +280,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
         for (int j = 0; j < A_J; ++j) {
             const unsigned voff = (a_taps[j] & tapbit) ? (unsigned)(a_off[j] + tap_off) : OOB;
             float* dst = sbase + (kq * BM + (j * WPK + wq) * 8) * BK;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void_t*)dst, 16, (int)voff, 0, 0, A_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void_t*)dst, 16, (int)voff, 0, 0, 0);
         }
     };
     auto issue_b = [&](int slot) {
@@ -344,9 +320,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
         if (a.flags & VIDC_AFFINE2) { e_s2[j] = a.scale2[ni]; e_b2[j] = a.shift2[ni]; }
     }
     VIDC_STAMP(11);     // scale/shift loads issued
-    dep.mark(1);
-    dep();              // chain: everything this tile reads from earlier layers is complete (the weight prologue is already in flight)
-    dep.mark(2);
     float e_res[TM][TN][16];
     if ((a.flags & VIDC_RESIDUAL) && a.splitk == 1 && !is_loader) {    // uniform branch; indices clamped so every load is unconditional
 #pragma unroll
@@ -357,8 +330,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = min(m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.M - 1);
-                    if constexpr (CHAIN) e_res[i][j][r] = __hip_atomic_load(res + (size_t)m * a.ldr + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else e_res[i][j][r] = res[(size_t)m * a.ldr + n];
+                    e_res[i][j][r] = res[(size_t)m * a.ldr + n];
                 }
             }
     } else {
@@ -390,7 +362,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
             for (int s = 0; s < PRO; ++s) { issue_a(s); advance(); }
             int slot = 0;
             for (int s = 0; s < nst; ++s) {
-                if constexpr (SPEC_EFF == 2 || XB) wait_landed<NS, A_J, LPS>(s + 1 < nst ? s + 1 : nst - 1, s, nst);      // ... and stage s + 1
+                if constexpr (SPEC_EFF == 2) wait_landed<NS, A_J, LPS>(s + 1 < nst ? s + 1 : nst - 1, s, nst);      // ... and stage s + 1
                 else wait_stage<NS, A_J, LPS>(s, nst);
                 __builtin_amdgcn_s_barrier();     // stage s is in LDS (every loader waited for its pieces); stage s-1 has been read
                 int fill = slot + NS - 1; if (fill >= NS) fill -= NS;
@@ -420,15 +392,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
     // between MFMAs); false_type: the last NS-1 iterations, which consume what is already in flight and issue nothing --
     // so no DMA is outstanding when the loop ends and the epilogue does not have to drain any.
     int slot = 0;
-    f32x4 fa[2][TM], fb[2][TN];            // fp32 fragments (live across stages with XB)
+    f32x4 fa[2][TM], fb[2][TN];            // fp32 fragments, double-buffered from one 8-k sub-step to the next
     auto iteration = [&](int s, auto issue_tag) {
         // DMA issue order: prologue B_0..B_{PRO-1}, A_0..A_{PRO-1}, then per iteration A, B.  Stage s < PRO has landed when
         // only the (PRO-1-s) younger prologue A groups and the s stages issued by the loop remain; from s = PRO on, when at
         // most NS-2 whole stages remain.
-        if constexpr (!SPEC) {      // SPEC: the loader waves wait for their DMA before this barrier
-            if constexpr (XB) wait_landed<NS, A_J, LPS>(s + 1 < nst ? s + 1 : nst - 1, s, nst);
-            else wait_stage<NS, A_J, LPS>(s, nst);
-        }
+        if constexpr (!SPEC) wait_stage<NS, A_J, LPS>(s, nst);      // SPEC: the loader waves wait for their DMA before this barrier
         __builtin_amdgcn_s_barrier();     // every wave's pieces of stage s are in LDS; everyone finished stage s-1
         if (s == 0) VIDC_STAMP(2);      // first stage landed
         int fill = slot + NS - 1; if (fill >= NS) fill -= NS;     // the slot read in iteration s-1: free since the barrier
@@ -481,12 +450,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            if (!XB || s == 0) {           // (XB: the previous stage's last sub-step has read this set already)
     #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[0][i] = lds_read_b128<0>(Ab + coff[0] + i * 32 * BK * 4);
+            for (int i = 0; i < TM; ++i) fa[0][i] = lds_read_b128<0>(Ab + coff[0] + i * 32 * BK * 4);
     #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[0][j] = lds_read_b128<0>(Bb + coff[0] + j * 32 * BK * 4);
-            }
+            for (int j = 0; j < TN; ++j) fb[0][j] = lds_read_b128<0>(Bb + coff[0] + j * 32 * BK * 4);
     #pragma unroll
             for (int sub = 0; sub < BK / 8; ++sub) {
                 const int cur = sub & 1, nxt = cur ^ 1;
@@ -496,14 +463,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
     #pragma unroll
                     for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read_b128<0>(Bb + coff[sub + 1] + j * 32 * BK * 4);
                     wait_lgkmcnt<TM + TN>();      // the reads of `cur` are complete (LDS returns in order)
-                } else if (XB && s + 1 < nst) {   // first set of the NEXT stage (its DMA is covered by this stage's barrier), into fa[0] / fb[0]
-                    int ns_ = slot + 1; if (ns_ == NS) ns_ = 0;
-                    const unsigned An = a_base + (unsigned)(ns_ * STAGE * 4), Bn = b_base + (unsigned)(ns_ * STAGE * 4);
-    #pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[nxt][i] = lds_read_b128<0>(An + coff[0] + i * 32 * BK * 4);
-    #pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read_b128<0>(Bn + coff[0] + j * 32 * BK * 4);
-                    wait_lgkmcnt<TM + TN>();
                 } else {
                     wait_lgkmcnt<0>();
                 }
@@ -585,7 +544,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
     }
 
     VIDC_STAMP(3);      // main loop done
-    dep.mark(3);
     if (WKW > 1) {
         __syncthreads();
         float* red = smem;
@@ -625,7 +583,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
     //      counter (head of the workspace; device-scope atomic), and the LAST one to arrive sums the splitk partials in slice
     //      order 0..splitk-1 (its own included, re-read from the workspace) and runs the normal epilogue below.  The sum does not
     //      depend on the arrival order, so the result is bit-reproducible; the counter is left at zero for the next launch.
-    if (!CHAIN && a.splitk > 1) {
+    if (a.splitk > 1) {
         float* part = a.ws + VIDC_SPLITK_COUNTERS;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -711,7 +669,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
             // `full_tag` = true_type: all 32 rows of the tile exist (every tile but the last m-tile): no per-row predicate
             auto finish = [&](auto full_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;
-                if constexpr (PREC == 2 && !CHAIN) {
+                if constexpr (PREC == 2) {
                     // VIDC_STATS_OUT (training, plain-bf16 mode): per-channel sum and sum of squares of this 32-row block of the OUTPUT
                     // (the fp32 values stored below), as the fp64 partials the train-mode BatchNorm behind this conv reduces
                     // (csrc/train.hip chan_final_kernel): saves that BatchNorm's partial-sum launch and its pass over the tensor.
@@ -737,8 +695,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int dm = (r & 3) + 8 * (r >> 2);
-                        if constexpr (CHAIN) old[r] = (FULL || mrow + dm < a.M) ? __hip_atomic_load(yg + o0 + (unsigned)(dm * a.ldy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-                        else old[r] = (FULL || mrow + dm < a.M) ? yg[o0 + (unsigned)(dm * a.ldy)] : 0.f;
+                        old[r] = (FULL || mrow + dm < a.M) ? yg[o0 + (unsigned)(dm * a.ldy)] : 0.f;
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v[r] += old[r];
@@ -791,141 +748,7 @@ conv_igemm_f32(const ConvArgs a) {
         g = (int)fast_div(v2, a.dv_tiles_n);
         tile_n = (int)(v2 - g * a.tiles_n);
     }
-    conv_tile<BM, BN, WMW, WNW, WKW, NS, PREC, SPEC, false>(a, g, tile_m, tile_n, kz, smem, NoDep{});
-}
-
-// ---- persistent chain kernel ------------------------------------------------------------------------------------------------------
-// A run of consecutive small convs (the 22 identical bottlenecks of ResNet-101 layer3 at M = B*300..320: 66 launches of ~15 us whose
-// time is launch/drain, prologue and HBM-cold weight latency, not arithmetic) executed by ONE launch.
-//
-// * Group g (one of the <= 8 pyramids of the grouped launch) runs ENTIRELY on XCD g: a workgroup reads the XCD it was placed on
-//   (HW_REG_XCC_ID) and serves that group.  All hand-offs of a group therefore stay inside one XCD's L2: producers store plainly
-//   (write-through L1 -> the shared L2) and drain (s_waitcnt vmcnt(0)); consumers read activations with sc1 loads (L2-served: a CU's
-//   L1 is never refreshed by another CU's stores); the counters are device atomics.  No grid-wide barrier, no cross-XCD fence.
-// * Work = the (layer, n-tile, m-tile) items of the group in layer order, CLAIMED dynamically from a per-XCD counter, so nothing
-//   depends on how many workgroups the dispatcher put on an XCD or on all of them being resident (a lone workgroup would walk the
-//   whole chain by itself).  An item of layer l may start when the XCD's `done` counter has reached the first item index of layer l
-//   (all earlier layers complete).  Claims are in order and every claimed item completes, so the wait always ends.
-// * The weight tiles of the claimed item are requested (LDS-DMA prologue) BEFORE that wait: the HBM-cold latency of layer l+1's
-//   weights hides under the tail of layer l, which separate launches cannot do.
-// * Every spin is bounded: on time-out the workgroup records an error code and leaves; the host reads it (vidc_chain_status).
-struct ChainLayer {
-    ConvArgs a;
-    int item_begin;      // index of this layer's first item in the group's item list
-    int pad_[3];
-};
-struct ChainArgs {
-    const ChainLayer* layers;
-    unsigned* state;     // [0..7] next item per XCD, [8..15] items done per XCD, [16] error code (sticky), [17] workgroups that have left
-    long long* trace;    // NULL, or [workgroup][VIDC_CHAIN_TRACE_ITEMS][8] time stamps (debug: tools/chain_trace.py)
-    int n_layers, total_items, groups, spin_limit;
-};
-constexpr int kChainTraceItems = 160;
-
-struct ChainDep {
-    unsigned* done;
-    unsigned* err;
-    unsigned need;
-    int spin_limit;
-    long long* tr;        // this item's 8 stamps, or NULL
-    bool* failed;
-    const float* wtile;   // this item's 64 weight rows (group base + n0 * K), K floats each
-    int wrows, K;
-    // The item's whole weight tile is pulled into the XCD's L2 while the workgroup waits for its dependency (the ring prologue only
-    // covers the first NS-1 stages): one 4-byte load per 128-byte line, every lane its own line -- the point is the number of lines
-    // in flight, which the LDS ring cannot provide (96 KB per workgroup against ~2.4 us of HBM-cold latency = 0.8 us per stage
-    // measured; L2 hits afterwards).  The loaded words are xor-ed into a value that is never stored.
-    __device__ __forceinline__ unsigned prefetch() const {
-        unsigned acc = 0;
-        const int lines_per_row = K >> 5;                         // 128-byte lines per row
-        const int total = wrows * lines_per_row;
-        for (int i = threadIdx.x; i < total; i += 512) {
-            const int r = i / lines_per_row, c = i - r * lines_per_row;
-            acc ^= __float_as_uint(__builtin_nontemporal_load(wtile + (size_t)r * K + c * 32));
-        }
-        return acc;
-    }
-    __device__ __forceinline__ void mark(int k) const {
-        if (tr && threadIdx.x == 0) tr[k] = (long long)__builtin_amdgcn_s_memrealtime();
-    }
-    __device__ __forceinline__ void operator()() const {
-        const unsigned junk = prefetch();
-        if (junk == 0x9E3779B9u && need == 0xFFFFFFFFu) *err = junk;      // never true: keeps the loads alive
-        if (threadIdx.x < 64) {                              // one wave polls one word, relaxed, L2-served; bounded
-            int spins = 0;
-            while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > spin_limit || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                    *failed = true;                          // timed out, or another workgroup did: give up (the host reads state[16])
-                    break;
-                }
-            }
-        }
-        __syncthreads();
-    }
-};
-
-template <int NS, int PREC>
-__global__ void __launch_bounds__(512) conv_chain_kernel(const ChainArgs c) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ unsigned s_q;
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;      // HW_REG_XCC_ID[3:0]
-    const int tid = threadIdx.x;
-    if ((int)xcc < c.groups) {                      // (the other XCDs serve no group of this launch)
-        const int g = (int)xcc;
-        unsigned* next = c.state + xcc;
-        unsigned* done = c.state + 8 + xcc;
-        int l = 0, n_done = 0;
-        if (tid == 0) s_q = atomicAdd(next, 1u);
-        __syncthreads();
-        unsigned q = s_q;
-        while (q < (unsigned)c.total_items) {
-            while (l + 1 < c.n_layers && q >= (unsigned)c.layers[l + 1].item_begin) ++l;     // uniform
-            const ChainLayer* Lp = c.layers + l;
-            const ConvArgs a = Lp->a;                         // one batch of scalar loads per item instead of one per field use
-            const int item_begin = Lp->item_begin;
-            const int item = (int)q - item_begin;
-            const int tiles_m = a.tiles_m;
-            const int tile_n = item / tiles_m, tile_m = item - tile_n * tiles_m;
-            long long* tr = (c.trace && n_done < kChainTraceItems) ? c.trace + ((size_t)blockIdx.x * kChainTraceItems + n_done) * 8 : nullptr;
-            unsigned q_next = 0;
-            if (tid == 0) q_next = atomicAdd(next, 1u);          // the next claim travels while this item runs
-            bool failed = false;
-            const int n0w = tile_n * 64;
-            ChainDep dep{done, c.state + 16, (unsigned)item_begin, c.spin_limit, tr, &failed,
-                         a.w + g * a.w_gs + (size_t)n0w * a.K, min(64, a.Cout - n0w), a.K};
-            if (tr && tid == 0) tr[6] = ((long long)l << 32) | q;
-            dep.mark(0);
-            conv_tile<64, 64, 2, 2, 2, NS, PREC, 0, true>(a, g, tile_m, tile_n, 0, smem, dep);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its outputs have reached the XCD's L2
-            __syncthreads();                                      // ... and every wave is done with the LDS ring
-            dep.mark(4);
-            if (tid == 0) {
-                if (failed) atomicMax(c.state + 16, 1u + (unsigned)l);
-                atomicAdd(done, 1u);
-                s_q = failed ? 0xFFFFFFFFu : q_next;             // after a time-out this workgroup leaves
-            }
-            dep.mark(5);
-            __syncthreads();
-            q = s_q;
-            ++n_done;
-        }
-    }
-    // The claim / done counters are left at zero for the next launch by the LAST workgroup to leave (every workgroup is past its last
-    // access to them by then) -- no memset node: under hipGraph replay the launch must not depend on one.
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned t = atomicAdd(c.state + 17, 1u);
-        if (t == gridDim.x - 1) {
-            // every group's item list must have been walked to its end: a group whose XCD received no workgroup of this launch (CPX
-            // partition, CU mask, fewer than `groups` XCDs) is never claimed and nobody waits on it -- the outputs would be stale with
-            // no time-out anywhere.  Code 0x7FFFFFFF in the sticky error word (vidc_chain_status reports layer 0x7FFFFFFE).
-            for (int gi = 0; gi < c.groups; ++gi)
-                if (__hip_atomic_load(c.state + 8 + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)c.total_items) atomicCAS(c.state + 16, 0u, 0x7FFFFFFFu);      // (a time-out code set earlier stays)
-            for (int i = 0; i < 16; ++i) atomicExch(c.state + i, 0u);
-            atomicExch(c.state + 17, 0u);
-        }
-    }
+    conv_tile<BM, BN, WMW, WNW, WKW, NS, PREC, SPEC>(a, g, tile_m, tile_n, kz, smem);
 }
 
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
@@ -1215,123 +1038,6 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
     return rc;
-}
-
-// ---- persistent chain: host side ----------------------------------------------------------------------------------------------------
-struct vidc_chain {
-    ChainLayer* d_layers = nullptr;
-    unsigned* d_state = nullptr;
-    long long* d_trace = nullptr;
-    int n_layers = 0, total_items = 0, groups = 0, precision = 0, n_cu = 256;
-};
-
-namespace {
-constexpr int kChainNS = 4;
-constexpr int kChainTile = VIDC_TILE_64x64_K2_D4;
-constexpr size_t kChainLds = (size_t)kChainNS * (64 + 64) * BK * 2 * sizeof(float);
-constexpr int kChainStateWords = 32;
-
-template <int PREC>
-int chain_launch(const vidc_chain* ch, hipStream_t st) {
-    static bool attr_set[64] = {};
-    int dev = 0;
-    VIDC_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        VIDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_chain_kernel<kChainNS, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)kChainLds));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
-    ChainArgs c;
-    c.layers = ch->d_layers; c.state = ch->d_state; c.trace = ch->d_trace; c.n_layers = ch->n_layers; c.total_items = ch->total_items; c.groups = ch->groups;
-    c.spin_limit = 1000000;
-    // one workgroup per CU (128 KB of LDS each); the groups' XCDs use theirs, the others leave at once
-    hipLaunchKernelGGL((conv_chain_kernel<kChainNS, PREC>), dim3(ch->n_cu), dim3(512), kChainLds, st, c);
-    VIDC_CHECK_LAUNCH("conv_chain_kernel");
-    return VIDC_OK;
-}
-}  // namespace
-
-extern "C" int vidc_chain_create(const vidc_conv_desc* descs, int n, vidc_chain** out) {
-    VIDC_REQUIRE(descs && out, VIDC_ERR_NULL, "vidc_chain_create: null pointer");
-    VIDC_REQUIRE(n >= 2, VIDC_ERR_SHAPE, "vidc_chain_create: a chain has at least two convs");
-    std::vector<ChainLayer> layers((size_t)n);
-    int items = 0;
-    for (int i = 0; i < n; ++i) {
-        int rc = validate(descs + i);
-        if (rc != VIDC_OK) return rc;
-        vidc_conv_desc dd = descs[i];
-        VIDC_REQUIRE(dd.groups == descs[0].groups && dd.groups <= 8, VIDC_ERR_SHAPE, "vidc_chain_create: every conv needs the same <= 8 groups (one XCD each)");
-        VIDC_REQUIRE(dd.precision == descs[0].precision, VIDC_ERR_SHAPE, "vidc_chain_create: one arithmetic mode per chain");
-        VIDC_REQUIRE(dd.precision == VIDC_PREC_FP32 || dd.precision == VIDC_PREC_BF16X3, VIDC_ERR_SHAPE,
-                     "vidc_chain_create: the chain kernel is instantiated for fp32 and bf16x3 operands only (plain bf16 would run the fp32 kernel on packed bf16 data)");
-        dd.tile = kChainTile;
-        dd.splitk = 1;
-        rc = make_args(dd, layers[i].a);
-        if (rc != VIDC_OK) return rc;
-        layers[i].item_begin = items;
-        items += layers[i].a.tiles_m * layers[i].a.tiles_n;
-    }
-    vidc_chain* ch = new vidc_chain();
-    ch->n_layers = n; ch->total_items = items; ch->groups = descs[0].groups; ch->precision = descs[0].precision;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ch->n_cu = prop.multiProcessorCount;
-    hipError_t e = hipMalloc(&ch->d_layers, sizeof(ChainLayer) * (size_t)n);
-    if (e == hipSuccess) e = hipMalloc(&ch->d_state, sizeof(unsigned) * kChainStateWords);
-    if (e == hipSuccess) e = hipMemcpy(ch->d_layers, layers.data(), sizeof(ChainLayer) * (size_t)n, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(ch->d_state, 0, sizeof(unsigned) * kChainStateWords);
-    if (e != hipSuccess) {
-        vidc::set_error("vidc_chain_create: %s", hipGetErrorString(e));
-        vidc_chain_destroy(ch);
-        return VIDC_ERR_HIP;
-    }
-    *out = ch;
-    return VIDC_OK;
-}
-
-extern "C" int vidc_chain_run(vidc_chain* ch, vidc_stream_t stream) {
-    VIDC_REQUIRE(ch, VIDC_ERR_STATE, "vidc_chain_run: null chain");
-    hipStream_t st = vidc::as_stream(stream);      // (the kernel leaves its claim / done counters at zero; the error word [16] is sticky)
-    return ch->precision == VIDC_PREC_BF16X3 ? chain_launch<1>(ch, st) : chain_launch<0>(ch, st);
-}
-
-extern "C" int vidc_chain_status(vidc_chain* ch, int* failed_layer) {
-    VIDC_REQUIRE(ch && failed_layer, VIDC_ERR_NULL, "vidc_chain_status: null pointer");
-    unsigned st[kChainStateWords];
-    VIDC_HIP(hipMemcpy(st, ch->d_state, sizeof(st), hipMemcpyDeviceToHost));      // synchronises
-    *failed_layer = (int)st[16] - 1;                                             // -1: no wait ever timed out
-    return VIDC_OK;
-}
-
-extern "C" int vidc_chain_trace(vidc_chain* ch, int enable, long long* host_out, int max_words) {
-    VIDC_REQUIRE(ch, VIDC_ERR_STATE, "vidc_chain_trace: null chain");
-    const size_t words = (size_t)ch->n_cu * kChainTraceItems * 8;
-    if (enable && !ch->d_trace) {
-        VIDC_HIP(hipMalloc(&ch->d_trace, words * sizeof(long long)));
-        VIDC_HIP(hipMemset(ch->d_trace, 0, words * sizeof(long long)));
-    }
-    if (host_out) {
-        VIDC_REQUIRE(ch->d_trace && (size_t)max_words >= words, VIDC_ERR_SHAPE, "vidc_chain_trace: needs %zu words", words);
-        VIDC_HIP(hipMemcpy(host_out, ch->d_trace, words * sizeof(long long), hipMemcpyDeviceToHost));
-    }
-    if (!enable && ch->d_trace) { hipFree(ch->d_trace); ch->d_trace = nullptr; }
-    return (int)words;
-}
-
-extern "C" int vidc_chain_info(const vidc_chain* ch, int* n_layers, int* total_items) {
-    VIDC_REQUIRE(ch, VIDC_ERR_STATE, "vidc_chain_info: null chain");
-    if (n_layers) *n_layers = ch->n_layers;
-    if (total_items) *total_items = ch->total_items;
-    return VIDC_OK;
-}
-
-extern "C" int vidc_chain_destroy(vidc_chain* ch) {
-    if (!ch) return VIDC_OK;
-    if (ch->d_layers) hipFree(ch->d_layers);
-    if (ch->d_state) hipFree(ch->d_state);
-    if (ch->d_trace) hipFree(ch->d_trace);
-    delete ch;
-    return VIDC_OK;
 }
 
 extern "C" int vidc_split_bf16x3(const float* x, void* y, long long rows, int C, int ldx, vidc_stream_t stream) {

@@ -61,8 +61,13 @@ int launch_op(const vidc_op& op, hipStream_t st) {
             return vidc_upsample_nearest2x((const float*)g.p[0], (float*)g.p[1], g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.i[5], s);
         case VIDC_OP_MASK:
             return vidc_mask_scale((const float*)g.p[0], (const float*)g.p[1], (float*)g.p[2], g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.i[5], g.i[6], g.i[7], s);
-        case VIDC_OP_CHAIN:
-            return vidc_chain_run(reinterpret_cast<vidc_chain*>(const_cast<void*>(g.p[0])), s);
+        case VIDC_OP_WINO_IN:
+            return vidc_winograd_input_transform((const float*)g.p[0], const_cast<void*>(g.p[1]), g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.i[5], g.i[6],
+                                                 g.i[7], g.i[8], s);
+        case VIDC_OP_WINO_OUT:
+            return vidc_winograd_output_transform((const float*)g.p[0], (float*)g.p[1], const_cast<void*>(g.p[2]), (const float*)g.p[3],
+                                                  (const float*)g.p[4], (const float*)g.p[5], (const float*)g.p[6], g.i[0], g.i[1], g.i[2], g.i[3],
+                                                  g.i[4], g.i[5], g.i[6], g.i[7], g.i[8], s);
         case VIDC_OP_COPY: {   // p[0] -> p[1], i[0..1] = byte count (lo, hi)
             size_t bytes = (size_t)(uint32_t)g.i[0] | ((size_t)(uint32_t)g.i[1] << 32);
             VIDC_HIP(hipMemcpyAsync(const_cast<void*>(g.p[1]), g.p[0], bytes, hipMemcpyDeviceToDevice, st));

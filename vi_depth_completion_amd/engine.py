@@ -92,6 +92,34 @@ class WeightStore:
             self._cache[ck] = out
         return self._cache[ck]
 
+    def packed_winograd(self, keys, m, dry_run=False, precision=0):
+        """U = G g G^T of the 3x3 filters `keys` for F(m x m, 3x3): [G][(m+2)^2][Cout][Cin] fp32 (csrc/winograd.hip, fp64 inside), or the
+        split-bf16 image of the same bytes (precision 1) -- the weights of the (m+2)^2 * G group 1x1 GEMM launch."""
+        ck = ("wino", m, precision) + tuple(keys)
+        if ck not in self._cache:
+            ws = [self.sd()[k + ".weight"].contiguous() for k in keys]
+            co, ci, kh, kw = ws[0].shape
+            assert (kh, kw) == (3, 3)
+            a2 = (m + 2) * (m + 2)
+            out = torch.empty((len(ws) * a2, co, ci), dtype=torch.float32, device=ws[0].device)
+            if dry_run:
+                return out
+            for g, w in enumerate(ws):
+                assert tuple(w.shape) == (co, ci, 3, 3)
+                L.check(L.lib().vidc_winograd_weight_transform(L.ptr(w), L.ptr(out[g * a2]), co, ci, m, L.current_stream()), "winograd weights")
+            if precision == L.PREC_BF16X3:
+                img = torch.empty_like(out)
+                L.check(L.lib().vidc_pack_conv_weight_bf16x3(L.ptr(out), L.ptr(img), len(ws) * a2 * co, ci, 1, 1, L.current_stream()), "pack")
+                out = img
+            self._cache[ck] = out
+        return self._cache[ck]
+
+    def identity_affine(self, co, device):
+        ck = ("id", co, str(device))
+        if ck not in self._cache:
+            self._cache[ck] = (torch.ones(co, dtype=torch.float32, device=device), torch.zeros(co, dtype=torch.float32, device=device))
+        return self._cache[ck]
+
     def affine(self, conv_keys, bn_keys):
         """Per-output-channel (scale, shift) [G][Cout] for conv(+bias) followed by eval-mode BN, folded in fp64."""
         ck = ("a",) + tuple(conv_keys) + tuple(bn_keys or ())
@@ -134,7 +162,6 @@ class JointWeightStore(WeightStore):
 
 
 _TUNING = None
-CHAIN_TILE = 13      # VIDC_TILE_64x64_K2_D4: the tiling of the persistent chain kernel
 
 
 def tuning_table():
@@ -167,6 +194,36 @@ def _capped_tile(tile, cap_kb):
     return _TILE_SMALL.get(tile, tile) if _TILE_LDS_KB.get(tile, 0) > cap_kb else tile
 
 
+def winograd_mode():
+    """VIDC_WINOGRAD=auto : (default) 3x3 / stride 1 / pad 1 convs with >= 128 input channels run as Winograd F(m x m, 3x3) GEMMs
+                             (csrc/winograd.hip): the entry "W:<direct signature>" of the measured table picks m in {0, 2, 4}, else
+                             m = 4 on maps of at least 24 rows and columns and m = 2 below.
+       VIDC_WINOGRAD=0 / 2 / 4 : never / always that m where the layer qualifies (tests, A/B runs)."""
+    return os.environ.get("VIDC_WINOGRAD", "auto")
+
+
+def winograd_choice(B, H, W, co, ci, kh, kw, stride, padding, dilation, G):
+    if (kh, kw, stride, padding, dilation) != (3, 3, 1, 1, 1) or ci % 32 or co % 32:
+        return 0
+    mode = winograd_mode()
+    if mode in ("0", "2", "4"):
+        m = int(mode)
+    else:
+        ent = tuning_table().get("W:M%d_N%d_K%d_k3s1_G%d" % (B * H * W, co, 9 * ci, G))      # [m in the fp32 mode, m in the mixed mode]
+        if ent is not None:
+            m = int(ent[1 if precision_mode() == "mixed" else 0]) if isinstance(ent, (list, tuple)) else int(ent)
+        elif ci < 128:
+            m = 0
+        else:
+            m = 4 if min(H, W) >= 24 else 2
+    if m:
+        a2 = (m + 2) * (m + 2)
+        tiles = B * (-(-H // m)) * (-(-W // m))
+        if tiles * a2 * G * max(ci, co) * 4 >= 2 ** 31 or B * (-(-H // m)) > 65535:     # 32-bit buffer offsets in the GEMM kernel / grid.y
+            return 0
+    return m
+
+
 def conv_signature(d):
     return "M%d_N%d_K%d_k%ds%d_G%d" % (d.B * d.Ho * d.Wo, d.Cout, d.KH * d.KW * d.Cin, d.KH, d.stride, d.groups)
 
@@ -184,7 +241,8 @@ class Program:
         self.stream_id = 0
         self.wait_mask = 0
         self.handle = None
-        self.flops = 0           # executed conv FLOPs (2*M*N*K summed)
+        self.flops = 0           # executed conv FLOPs (2*M*N*K summed; Winograd layers count their transform-domain GEMMs)
+        self.direct_flops = 0    # the executed layers in direct form (what self.flops was before the Winograd layers)
         self.ref_flops = 0       # the same layers in the reference's formulation (1x1 convs AFTER their upsample: SURVEY §8d)
         self._keep = []
         self._split_cache = {}   # (buf, ch_off, channels) -> buffer id of the split-bf16 image
@@ -251,7 +309,15 @@ class Program:
         if accumulate:
             flags |= L.ACCUM
         flops = 2 * self.B * Ho * Wo * co * ci * kh * kw * G
+        wm = 0
+        if residual is None and not accumulate:
+            wm = winograd_choice(self.B, x.H, x.W, co, ci, kh, kw, stride, padding, dilation, G)
+        if wm:
+            self.ref_flops += int(round(flops * ref_flops_scale))
+            self.direct_flops += flops
+            return self._conv_winograd(x, y, keys, bn, bn2, flags, wm, (co, ci, Ho, Wo))
         self.flops += flops
+        self.direct_flops += flops
         self.ref_flops += int(round(flops * ref_flops_scale))
         # precision: measured table entry if there is one, else by size
         sig = "M%d_N%d_K%d_k%ds%d_G%d" % (self.B * Ho * Wo, co, kh * kw * ci, kh, stride, G)
@@ -263,6 +329,29 @@ class Program:
         self._emit("conv", [xin, residual, y if accumulate else None], [y], x=xin, y=y, keys=keys, precision=prec,
                    bn=_keys(bn) if bn is not None else None, bn2=_keys(bn2) if bn2 is not None else None,
                    residual=residual, flags=flags, stride=stride, pad=padding, geom=(co, ci, kh, kw, Ho, Wo), dilation=dilation)
+        return y
+
+    def _conv_winograd(self, x, y, keys, bn, bn2, flags, m, geom):
+        """3x3 / stride 1 / pad 1 conv + BN + ReLU as Winograd F(m x m, 3x3): input transform -> ONE grouped 1x1 GEMM launch with
+        (m+2)^2 * G groups on the MFMA kernel -> output transform with the conv's epilogue (csrc/winograd.hip)."""
+        co, ci, Ho, Wo = geom
+        G = len(keys)
+        a2 = (m + 2) * (m + 2)
+        tiles = self.B * (-(-Ho // m)) * (-(-Wo // m))
+        gflops = 2 * tiles * a2 * G * co * ci
+        self.flops += gflops
+        sig = "M%d_N%d_K%d_k1s1_G%d" % (tiles, co, ci, a2 * G)
+        prec = L.PREC_FP32
+        if self.mode == "mixed":
+            ent = tuning_table().get(sig)
+            prec = ent[2] if (ent is not None and len(ent) > 2) else default_precision(gflops)
+        V = T(self._new_buf(tiles * a2 * G * ci), 1, 1, tiles, ci, a2 * G)
+        Mm = T(self._new_buf(tiles * a2 * G * co), 1, 1, tiles, co, a2 * G)
+        self._emit("wino_in", [x], [V], x=x, v=V, m=m, cin=ci, split=int(prec == L.PREC_BF16X3))
+        self._emit("conv", [V], [Mm], x=V, y=Mm, keys=keys, precision=prec, bn=None, bn2=None, residual=None, flags=0, stride=1, pad=0,
+                   geom=(co, ci, 1, 1, 1, tiles), dilation=1, wino=m)
+        self._emit("wino_out", [Mm], [y], mm=Mm, y=y, keys=keys, bn=_keys(bn) if bn is not None else None,
+                   bn2=_keys(bn2) if bn2 is not None else None, flags=flags, m=m, cout=co)
         return y
 
     def split(self, x):
@@ -412,7 +501,7 @@ class Program:
                 continue
             xs = kw["x"]
             j = next((t for t in range(i - 1, -1, -1) if xs.buf in self.ops[t][2]), None)
-            if j is None or self.ops[j][0] not in ("conv", "maxpool", "upsample", "stem"):
+            if j is None or self.ops[j][0] not in ("conv", "maxpool", "upsample", "stem", "wino_out"):
                 continue
             pkind, pk = self.ops[j][0], self.ops[j][3]
             y = pk["y"]
@@ -433,7 +522,7 @@ class Program:
             foreign = False
             for t in range(i):
                 if xs.buf in self.ops[t][2]:
-                    if self.ops[t][0] not in ("conv", "maxpool", "upsample"):
+                    if self.ops[t][0] not in ("conv", "maxpool", "upsample", "wino_out"):
                         foreign = True
                         continue
                     yt = self.ops[t][3]["y"]
@@ -456,18 +545,18 @@ class Program:
             for t in writers:
                 yt = self.ops[t][3]["y"]
                 self.ops[t][3]["split_out"] = T(simg.buf, yt.B, yt.H, yt.W, yt.C, yt.G, ld=simg.C * simg.G, ch_off=yt.ch_off - lo)
-                if self.ops[t][0] == "conv":
+                if self.ops[t][0] in ("conv", "wino_out"):
                     self.ops[t][3]["flags"] |= L.SPLIT_OUT
                 self.ops[t][2].append(simg.buf)
             drop.add(i)
         for j, (kind, _r, _w, kw) in enumerate(self.ops):
-            if kind in ("conv", "maxpool", "upsample", "stem") and kw.get("split_out") is not None and kw["y"].buf not in self.pinned:
+            if kind in ("conv", "maxpool", "upsample", "stem", "wino_out") and kw.get("split_out") is not None and kw["y"].buf not in self.pinned:
                 yb = kw["y"].buf
                 used = any(t not in drop and yb in self.ops[t][1] for t in range(j + 1, n))
                 # a later writer of the same buffer that accumulates into it needs the fp32 values too (reads cover that); a
                 # later plain writer of ANOTHER slice of the buffer (stem groups) does not
                 if not used:
-                    if kind == "conv":
+                    if kind in ("conv", "wino_out"):
                         kw["flags"] |= L.NO_F32_OUT
                     elif kind == "upsample":
                         kw["flags"] |= L.UP_NO_F32_OUT
@@ -476,14 +565,19 @@ class Program:
         self.n_fused_splits = len(drop)
         self.ops = [op for i, op in enumerate(self.ops) if i not in drop]
 
-    def _fill_conv_desc(self, d, kw, addr, dry_run, chain=False):
+    def _fill_conv_desc(self, d, kw, addr, dry_run):
         """Fills one vidc_conv_desc from a recorded conv; returns the op's display name."""
         lib = L.lib()
         x, y, keys = kw["x"], kw["y"], kw["keys"]
         co, ci, kh, kwid, Ho, Wo = kw["geom"]
         prec = kw["precision"]
-        wp = self.ws.packed([k for k in keys], dry_run, prec)
-        s1, b1 = self.ws.affine(list(keys), list(kw["bn"]) if kw["bn"] is not None else None)
+        wm = kw.get("wino", 0)
+        if wm:
+            wp = self.ws.packed_winograd([k for k in keys], wm, dry_run, prec)
+            s1, b1 = self.ws.identity_affine(co, wp.device)
+        else:
+            wp = self.ws.packed([k for k in keys], dry_run, prec)
+            s1, b1 = self.ws.affine(list(keys), list(kw["bn"]) if kw["bn"] is not None else None)
         d.x, d.w, d.y = addr(x), wp.data_ptr(), addr(y)
         d.scale1, d.shift1 = s1.data_ptr(), b1.data_ptr()
         if kw["bn2"] is not None:
@@ -501,11 +595,11 @@ class Program:
         if kw.get("split_out") is not None:
             d.y_split = addr(kw["split_out"])
         d.x_gs, d.w_gs, d.y_gs, d.p_gs = x.C, co * kh * kwid * ci, y.C, co
+        if wm:          # (m+2)^2 transform-domain GEMMs per group of the layer, identity epilogue shared by all of them
+            d.groups, d.p_gs = len(keys) * (wm + 2) * (wm + 2), 0
         d.tile, d.splitk, d.precision = 0, 1, prec
         sig = conv_signature(d)
-        if chain:
-            d.tile, d.splitk = CHAIN_TILE, 1
-        elif os.environ.get("VIDC_FORCE_TILE"):           # (tests: the stand-alone kernel on the chain's tiling, for bit-exact comparisons)
+        if os.environ.get("VIDC_FORCE_TILE"):           # (tests / A-B runs: one tiling for every conv)
             d.tile, d.splitk = int(os.environ["VIDC_FORCE_TILE"]), 1
         else:
             ent = tuning_table().get(sig)
@@ -521,53 +615,7 @@ class Program:
         if os.environ.get("VIDC_LDS_CAP_KB"):          # experiment knob (tools/dual_stream_bench.py): tilings that leave room for a second
             d.tile = _capped_tile(d.tile, int(os.environ["VIDC_LDS_CAP_KB"]))      # workgroup of another stream on the CU
         self._keep += [wp, s1, b1]
-        return "conv:%s:%s:sk%d:%s %s flags=0x%x" % (keys[0], L.TILE_NAMES[d.tile], d.splitk, "bf16x3" if prec else "fp32", sig, d.flags)
-
-    def _fuse_chains(self):
-        """Runs of consecutive small convs (M <= VIDC_CHAIN_MAX_M, same groups <= 8, same arithmetic mode, one stream) become ONE
-        `chain` op = one persistent launch (csrc/conv_mfma.hip conv_chain_kernel): the 22 identical bottlenecks of ResNet-101 layer3
-        are 66 launches whose time is launch / prologue / HBM-cold latency, not arithmetic.  Same arithmetic per conv as the
-        stand-alone kernel with tile 64x64k2d4, split-K 1."""
-        max_m = int(os.environ.get("VIDC_CHAIN_MAX_M", "704"))
-        min_len = int(os.environ.get("VIDC_CHAIN_MIN", "6"))
-        cutset = {id(mk) for mk in self._cut_markers}
-
-        def eligible(op):
-            kind, _r, _w, kw = op
-            if kind != "conv" or kw["stream_id"] != 0 or kw["wait_mask"] != 0:
-                return False
-            co, ci, kh, kwid, Ho, Wo = kw["geom"]
-            return self.B * Ho * Wo <= max_m and len(kw["keys"]) <= 8 and kw.get("dilation", 1) == 1
-
-        out, run = [], []
-
-        def flush():
-            if len(run) >= min_len:
-                reads = [b for op in run for b in op[1]]
-                writes = [b for op in run for b in op[2]]
-                out.append(("chain", reads, writes, {"convs": [op[3] for op in run], "stream_id": 0, "wait_mask": 0}))
-                if id(run[-1]) in cutset:            # a segment boundary after the run: the marker moves to the chain op
-                    self._cut_markers = [out[-1] if mk is run[-1] else mk for mk in self._cut_markers]
-            else:
-                out.extend(run)
-            run.clear()
-
-        for op in self.ops:
-            if eligible(op) and (not run or (len(op[3]["keys"]) == len(run[0][3]["keys"]) and op[3]["precision"] == run[0][3]["precision"])):
-                run.append(op)
-                if id(op) in cutset:
-                    flush()
-            else:
-                flush()
-                if eligible(op):
-                    run.append(op)
-                    if id(op) in cutset:
-                        flush()
-                else:
-                    out.append(op)
-        flush()
-        self.n_chains = sum(1 for op in out if op[0] == "chain")
-        self.ops = out
+        return "conv:%s%s:%s:sk%d:%s %s flags=0x%x" % (keys[0], "@wino%d" % wm if wm else "", L.TILE_NAMES[d.tile], d.splitk, "bf16x3" if prec else "fp32", sig, d.flags)
 
     def _plan_buffers(self):
         n = len(self.buf_elems)
@@ -612,11 +660,6 @@ class Program:
         lib = L.lib()
         if os.environ.get("VIDC_FUSE_SPLIT", "1") == "1":
             self._fuse_splits()
-        self._chains, self._chain_descs, self.n_chains = [], [], 0
-        # Opt-in (VIDC_CHAIN=1): measured on MI355X the XCD-local persistent chain is SLOWER than the per-layer launches it replaces
-        # (1.69 ms vs 1.1 ms for the 79 layer3/4 convs of a tick: half the chip, LDS-DMA-latency-bound stages; round-2 DESIGN.md, git history).
-        if os.environ.get("VIDC_CHAIN", "0") == "1":
-            self._fuse_chains()
         self.cuts = [next(i for i, op in enumerate(self.ops) if op is mk) + 1 for mk in self._cut_markers]
         assert len(self.cuts) < L.MAX_SEGMENTS and self.cuts == sorted(set(self.cuts))
         storage = self._plan_buffers()
@@ -642,19 +685,6 @@ class Program:
                     ws_need[op.stream_id] = max(ws_need.get(op.stream_id, 0), need)
                 conv_ops.append(op)
                 self.op_names.append(name)
-            elif kind == "chain":
-                descs = (L.ConvDesc * len(kw["convs"]))()
-                names = [self._fill_conv_desc(descs[j], ckw, addr, dry_run, chain=True) for j, ckw in enumerate(kw["convs"])]
-                op.kind = L.OP_CHAIN
-                self._chain_descs.append(descs)
-                if not dry_run:
-                    h = C.c_void_p()
-                    L.check(lib.vidc_chain_create(descs, len(descs), C.byref(h)), "chain_create")
-                    self._chains.append(h)
-                    g.p[0] = h.value
-                fl = sum(2.0 * d.B * d.Ho * d.Wo * d.Cout * d.KH * d.KW * d.Cin * d.groups for d in descs)
-                self.op_names.append("chain:%d:%s:%s:F%d %s .. %s" % (len(descs), kw["convs"][0]["keys"][0], "bf16x3" if descs[0].precision else "fp32",
-                                                                     int(fl), names[0].split(" ")[-1], names[-1].split(" ")[-1]))
             elif kind == "stem":
                 x, y = kw["x"], kw["y"]
                 w = self.ws.raw(kw["key"] + ".weight").contiguous()
@@ -752,6 +782,29 @@ class Program:
                 for j, v in enumerate((x.B, x.H, x.W, x.C * x.G, x.ld, y.ld, im.H, im.W)):
                     g.i[j] = v
                 self.op_names.append("mask_scale")
+            elif kind == "wino_in":
+                x, v = kw["x"], kw["v"]
+                op.kind = L.OP_WINO_IN
+                g.p[0], g.p[1] = addr(x), addr(v)
+                for j, val in enumerate((x.B, x.H, x.W, x.C * x.G, x.ld, kw["cin"], kw["m"], kw["split"], v.ld)):
+                    g.i[j] = val
+                self.op_names.append("wino_in:F%d:%dx%dx%d" % (kw["m"], x.H, x.W, x.C * x.G))
+            elif kind == "wino_out":
+                mm, y = kw["mm"], kw["y"]
+                keys = kw["keys"]
+                s1, b1 = self.ws.affine(list(keys), list(kw["bn"]) if kw["bn"] is not None else None)
+                self._keep += [s1, b1]
+                op.kind = L.OP_WINO_OUT
+                g.p[0], g.p[1], g.p[3], g.p[4] = addr(mm), (0 if kw["flags"] & L.NO_F32_OUT else addr(y)), s1.data_ptr(), b1.data_ptr()
+                if kw.get("split_out") is not None:
+                    g.p[2] = addr(kw["split_out"])
+                if kw["bn2"] is not None:
+                    s2, b2 = self.ws.affine([None] * len(keys), list(kw["bn2"]))
+                    g.p[5], g.p[6] = s2.data_ptr(), b2.data_ptr()
+                    self._keep += [s2, b2]
+                for j, val in enumerate((y.B, y.H, y.W, y.C * y.G, kw["cout"], y.ld, kw["m"], kw["flags"], mm.ld)):
+                    g.i[j] = val
+                self.op_names.append("wino_out:F%d:%dx%dx%d" % (kw["m"], y.H, y.W, y.C * y.G))
             elif kind == "nearest2x":
                 x, y = kw["x"], kw["y"]
                 op.kind = L.OP_NEAREST2X
@@ -844,7 +897,7 @@ class Program:
                 if g_lo <= kw["g"] < g_hi:
                     picked.append(i)
                 continue
-            grouped = (kind == "conv" and len(kw["keys"]) == groups) or (kind == "maxpool" and kw["x"].G == groups)
+            grouped = (kind in ("conv", "wino_out") and len(kw["keys"]) == groups) or (kind in ("maxpool", "wino_in") and kw["x"].G == groups)
             if grouped or keep_ungrouped:
                 picked.append(i)
         ops = (L.Op * len(picked))()
@@ -853,12 +906,26 @@ class Program:
             kind, _r, _w, kw = self.ops[i]
             if kind == "conv" and len(kw["keys"]) == groups:
                 d = ops[j].u.conv
+                a2 = (kw["wino"] + 2) ** 2 if kw.get("wino") else 1        # Winograd GEMMs: (m+2)^2 launch groups per group of the layer
                 for field, gs in (("x", d.x_gs), ("w", d.w_gs), ("y", d.y_gs), ("scale1", d.p_gs), ("shift1", d.p_gs), ("scale2", d.p_gs),
                                   ("shift2", d.p_gs), ("residual", d.r_gs), ("y_split", d.y_gs)):     # every operand is 4 bytes per element
                     v = getattr(d, field)                                                              # (a split-bf16 unit = 32 x (hi, lo))
                     if v:
-                        setattr(d, field, v + 4 * g_lo * gs)
-                d.groups = g_hi - g_lo
+                        setattr(d, field, v + 4 * g_lo * gs * a2)
+                d.groups = (g_hi - g_lo) * a2
+            elif kind == "wino_in" and kw["x"].G == groups:        # x: group at channel g * cin; V rows: [gg][pos][cin] (row stride explicit)
+                g = ops[j].u.g
+                cin, a2 = kw["cin"], (kw["m"] + 2) ** 2
+                g.p[0], g.p[1] = g.p[0] + 4 * g_lo * cin, g.p[1] + 4 * g_lo * a2 * cin
+                g.i[3] = cin * (g_hi - g_lo)
+            elif kind == "wino_out" and len(kw["keys"]) == groups:
+                g = ops[j].u.g
+                co, a2 = kw["cout"], (kw["m"] + 2) ** 2
+                g.p[0] = g.p[0] + 4 * g_lo * a2 * co
+                for k in (1, 2, 3, 4, 5, 6):                       # y, split image, scale / shift arrays: group g at element g * cout
+                    if g.p[k]:
+                        g.p[k] = g.p[k] + 4 * g_lo * co
+                g.i[3] = co * (g_hi - g_lo)
             elif kind == "maxpool" and kw["x"].G == groups:
                 g = ops[j].u.g
                 cg = kw["x"].C
@@ -898,25 +965,10 @@ class Program:
                                           int(use_graph), ms, per), "program_time")
         return (ms[0], list(per)) if per_op else ms[0]
 
-    def check_chains(self):
-        """Synchronises and raises if a dependency wait of a persistent chain ever timed out (results would be garbage)."""
-        if self._chains:
-            torch.cuda.synchronize(self.device)
-        for h in self._chains:
-            failed = C.c_int(-1)
-            L.check(L.lib().vidc_chain_status(h, C.byref(failed)), "chain_status")
-            if failed.value == 0x7FFFFFFE:
-                raise RuntimeError("persistent conv chain: a group's items were never claimed (no workgroup of the launch ran on its XCD: "
-                                   "partitioned device or CU mask?) -- its outputs are stale")
-            if failed.value >= 0:
-                raise RuntimeError("persistent conv chain: the wait for layer %d timed out (no workgroup on the group's XCD?)" % failed.value)
-
     def __del__(self):
         try:
             if self.handle is not None:
                 L.lib().vidc_program_destroy(self.handle)
-            for h in getattr(self, "_chains", []):
-                L.lib().vidc_chain_destroy(h)
             for v in getattr(self, "_variants", {}).values():
                 L.lib().vidc_program_destroy(v["handle"])
         except Exception:

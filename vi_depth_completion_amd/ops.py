@@ -162,3 +162,89 @@ def head_conv1x1_upsample(x, w, bias, pad, size, relu):
     L.check(L.lib().vidc_head_conv1x1_upsample(L.ptr(x), L.ptr(w2), L.ptr(b), L.ptr(low), L.ptr(y), B, h, wd, cin, cin, co, pad,
                                                size[0], size[1], int(relu), L.current_stream()), "head")
     return y, low
+
+
+# ---- Winograd F(m x m, 3x3) (csrc/winograd.hip) ------------------------------------------------------------------------------
+def winograd_weight_transform(w_oihw, m):
+    """OIHW (Cout,Cin,3,3) -> U (a*a, Cout, Cin), a = m + 2."""
+    _dev(w_oihw)
+    w = w_oihw.contiguous().float()
+    co, ci, kh, kw = w.shape
+    assert (kh, kw) == (3, 3)
+    a2 = (m + 2) * (m + 2)
+    u = torch.empty((a2, co, ci), dtype=torch.float32, device=w.device)
+    L.check(L.lib().vidc_winograd_weight_transform(L.ptr(w), L.ptr(u), co, ci, m, L.current_stream()), "winograd_weight_transform")
+    return u
+
+
+def winograd_input_transform(x, cin, m, split=False):
+    """x NHWC (B,H,W,G*cin) -> V (tiles, G*a*a*cin) [tile][gg][pos][cin]; split=True: the split-bf16 image (float32-typed storage)."""
+    _dev(x)
+    x = x.contiguous()
+    B, H, W, Cc = x.shape
+    th, tw = -(-H // m), -(-W // m)
+    a2 = (m + 2) * (m + 2)
+    v = torch.empty((B * th * tw, a2 * Cc), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vidc_winograd_input_transform(L.ptr(x), L.ptr(v), B, H, W, Cc, Cc, cin, m, int(split), 0, L.current_stream()),
+            "winograd_input_transform")
+    return v
+
+
+def winograd_output_transform(mm, B, Ho, Wo, cout, m, scale1, shift1, relu1=False, scale2=None, shift2=None, relu2=False, split_out=None,
+                              no_f32_out=False):
+    """mm (tiles, G*a*a*cout) -> y NHWC (B,Ho,Wo,G*cout) = epilogue(A^T M A)."""
+    _dev(mm, scale1, shift1)
+    mm = mm.contiguous()
+    a2 = (m + 2) * (m + 2)
+    Cc = mm.shape[1] // a2
+    y = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=mm.device)
+    s1, b1 = scale1.contiguous().float().view(-1), shift1.contiguous().float().view(-1)
+    flags = (L.RELU1 if relu1 else 0)
+    s2 = b2 = None
+    if scale2 is not None:
+        s2, b2 = scale2.contiguous().float().view(-1), shift2.contiguous().float().view(-1)
+        flags |= L.AFFINE2 | (L.RELU2 if relu2 else 0)
+    if split_out is not None:
+        flags |= L.SPLIT_OUT | (L.NO_F32_OUT if no_f32_out else 0)
+    L.check(L.lib().vidc_winograd_output_transform(L.ptr(mm), L.ptr(y), L.ptr(split_out), L.ptr(s1), L.ptr(b1), L.ptr(s2), L.ptr(b2), B, Ho, Wo,
+                                                   Cc, cout, Cc, m, flags, 0, L.current_stream()), "winograd_output_transform")
+    return y
+
+
+def conv3x3_winograd(x, w_oihw_groups, scale1, shift1, m, relu1=False, scale2=None, shift2=None, relu2=False, precision=0, tile=0, splitk=1,
+                     split_out=None, no_f32_out=False):
+    """nn.Conv2d(cin, cout, 3, 1, 1) [+ per-channel affines / ReLUs] of G groups as Winograd F(m x m, 3x3): input transform, ONE
+    grouped 1x1 GEMM launch (a*a*G groups, identity epilogue) on the MFMA kernel, output transform with the epilogue.
+    x NHWC (B,H,W,G*cin); w_oihw_groups: list of G (cout,cin,3,3) tensors; scale / shift: (G, cout)."""
+    G = len(w_oihw_groups)
+    B, H, W, Cc = x.shape
+    cin = Cc // G
+    cout = w_oihw_groups[0].shape[0]
+    a2 = (m + 2) * (m + 2)
+    u = torch.cat([winograd_weight_transform(w, m) for w in w_oihw_groups], 0)              # (G*a2, cout, cin): group gg*a2 + pos
+    if precision == L.PREC_BF16X3:
+        img = torch.empty_like(u)
+        L.check(L.lib().vidc_pack_conv_weight_bf16x3(L.ptr(u), L.ptr(img), G * a2 * cout, cin, 1, 1, L.current_stream()), "pack")
+        u = img
+    v = winograd_input_transform(x, cin, m, split=precision == L.PREC_BF16X3)
+    tiles = v.shape[0]
+    d = L.ConvDesc()
+    mm = torch.empty((tiles, a2 * G * cout), dtype=torch.float32, device=x.device)
+    one, zero = torch.ones(cout, dtype=torch.float32, device=x.device), torch.zeros(cout, dtype=torch.float32, device=x.device)
+    d.x, d.w, d.y, d.scale1, d.shift1 = L.ptr(v), L.ptr(u), L.ptr(mm), L.ptr(one), L.ptr(zero)
+    d.B, d.H, d.W, d.Cin, d.ldx = 1, 1, tiles, cin, a2 * G * cin
+    d.Ho, d.Wo, d.Cout, d.ldy = 1, tiles, cout, a2 * G * cout
+    d.KH, d.KW, d.stride, d.pad, d.flags, d.groups = 1, 1, 1, 0, 0, a2 * G
+    d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, cout * cin, cout, 0
+    d.tile, d.splitk, d.precision = tile, splitk, precision
+    if tile == 0:
+        L.check(L.lib().vidc_conv2d_plan(C.byref(d)), "conv2d_plan")
+        if splitk > 1:
+            d.splitk = splitk
+    ws = None
+    nbytes = L.lib().vidc_conv2d_workspace_bytes(C.byref(d))
+    if nbytes:
+        ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=x.device)
+        d.workspace = L.ptr(ws)
+    L.check(L.lib().vidc_conv2d_bn_act(C.byref(d), L.current_stream()), "conv2d_bn_act (winograd GEMMs)")
+    return winograd_output_transform(mm, B, H, W, cout, m, scale1, shift1, relu1, scale2, shift2, relu2, split_out, no_f32_out)

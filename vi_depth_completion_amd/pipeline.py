@@ -107,7 +107,7 @@ def build_frame_program(sn, dc, B, H, W, device, dry_run=False, weights=None):
     if not dry_run:
         prog.storage[kinv.buf][:9].copy_(wp.kinv(device))
         import os
-        if os.environ.get("VIDC_TICK_VARIANTS", "1") == "1" and not prog.n_chains:
+        if os.environ.get("VIDC_TICK_VARIANTS", "1") == "1":
             # first tick of a stream: only the surface-normal side of segment 0 (pyramid group 0 + decoder + warps); drain tick: only the
             # depth-completion pyramids (groups 1..3) -- engine.Program.group_variant: same buffers, weights, tiles, bit-identical results
             prog.group_variant("head", 0, 0, 1, 4, keep_ungrouped=True)
@@ -594,7 +594,6 @@ class _GroupLane:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 prog.run()            # warm-up outside capture (sets kernel attributes)
-                prog.check_chains()
                 prog.capture_segments()
                 for vname in ("head", "tail"):
                     if prog.has_variant(vname):
