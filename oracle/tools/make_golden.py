@@ -142,6 +142,30 @@ def main():
 
     ref.extract_plane_images_from_normal_image = traced_extract
 
+    # The reference's OWN returns of the three plane functions (main.py:38-62, 68-101, 110-127), in call order: the records the HIP plane
+    # block and the oracle are pinned to (`refplaneN.*` below; the `planeN.*` records are the oracle's bookkeeping of the same run).
+    plane_events = []
+    orig_mnr, orig_por, orig_gen = ref.mean_normal_ranasc, ref.plane_offset_ransac, ref.generate_depth_from_plane
+
+    def traced_mean_normal_ranasc(all_normals, *a, **k):
+        n_bar, angles, inl = orig_mnr(all_normals, *a, **k)
+        plane_events.append(("normal", n_bar.detach().clone(), int(inl.sum()), float(torch.mean(torch.abs(angles)))))
+        return n_bar, angles, inl
+
+    def traced_plane_offset_ransac(normal, pts, *a, **k):
+        off, n_inl = orig_por(normal, pts, *a, **k)
+        plane_events.append(("offset", float(off), int(n_inl), int(pts.shape[1])))
+        return off, n_inl
+
+    def traced_generate_depth_from_plane(*a, **k):
+        ok = orig_gen(*a, **k)
+        plane_events.append(("project", bool(ok)))
+        return ok
+
+    ref.mean_normal_ranasc = traced_mean_normal_ranasc
+    ref.plane_offset_ransac = traced_plane_offset_ransac
+    ref.generate_depth_from_plane = traced_generate_depth_from_plane
+
     cases = [("demo_" + k, {kk: (v.unsqueeze(0) if torch.is_tensor(v) else [v]) for kk, v in items[k].items()},
               1000 + int(k)) for k in DEMO_FRAMES]
     cases.append(("synthetic_f0", S.synthetic_batch(1, 240, 320, SEED), 999))
@@ -165,8 +189,10 @@ def main():
             batch["sparse_depth"] = sd
         taps.clear()
         plane_calls.clear()
+        plane_events.clear()
         np.random.seed(npseed)
         depth_ref = run._call_cnn(batch)
+        ref_events = list(plane_events)          # (the oracle below does not go through the reference's functions)
         # oracle on the same inputs / same numpy stream
         np.random.seed(npseed)
         otaps = {}
@@ -210,6 +236,23 @@ def main():
             out[p + ".n_bar"] = t["n_bar"].numpy()
             out[p + ".scalars"] = np.array([t["n_inl"], t["mean_angle"], float(t["accepted"]), t["offset"],
                                             t["n_off_inl"], float(t["valid"])], dtype=np.float64)
+        # the reference's returns, one record per plane id in the loop's order (main.py:143: ascending ids, 0 skipped):
+        # [inliers of the best normal hypothesis, mean |angle| to n_bar, offset, offset inliers, points on the plane, projection accepted]
+        # with nan / -1 where the reference did not get that far for the plane
+        ids = [int(c) for c in np.unique(S.plane_id_map(240, 320)) if c != 0]
+        recs, cur = [], None
+        for ev in ref_events:
+            if ev[0] == "normal":
+                cur = {"n_bar": ev[1].numpy(), "sc": [ev[2], ev[3], np.nan, -1, -1, -1]}
+                recs.append(cur)
+            elif ev[0] == "offset":
+                cur["sc"][2:5] = [ev[1], ev[2], ev[3]]
+            else:
+                cur["sc"][5] = float(ev[1])
+        assert len(recs) == len(ids), (len(recs), ids)
+        for cls, r in zip(ids, recs):
+            out["refplane%d.n_bar" % cls] = r["n_bar"]
+            out["refplane%d.scalars" % cls] = np.array(r["sc"], dtype=np.float64)
         out["enrich.nnz"] = otaps["enrich_trace"][0]["nnz"]
         out["enrich.sub"] = otaps["enrich_trace"][0]["sub"].astype(np.int32)
         for k, v in taps.items():

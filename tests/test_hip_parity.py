@@ -543,6 +543,16 @@ def test_plane_block_vs_golden(pipeline, golden_dir, name):
         assert abs(rec[s, 5] - sc[1]) < 1e-3
         assert bool(rec[s, 6]) == bool(sc[2]) and abs(rec[s, 3] - sc[3]) < 2e-4
         assert rec[s, 9] == sc[4] and (rec[s, 10] == 1.0) == bool(sc[5])
+        # the REFERENCE's own returns for this plane (make_golden.py wraps main.py's mean_normal_ranasc / plane_offset_ransac /
+        # generate_depth_from_plane): n_bar, inlier counts and the verdicts are the reference's, not the oracle's bookkeeping
+        rs = f["ref" + p + ".scalars"]      # normal inliers, mean |angle|, offset, offset inliers, points on the plane, projection accepted
+        assert np.abs(rec[s, 0:3] - f["ref" + p + ".n_bar"]).max() < 2e-5
+        assert int(rec[s, 4]) == int(rs[0]), "RANSAC inlier count %d vs the reference's %d" % (rec[s, 4], rs[0])
+        assert abs(rec[s, 5] - rs[1]) < 1e-3 and bool(rec[s, 6]) == (not np.isnan(rs[2]))
+        if not np.isnan(rs[2]):
+            assert abs(rec[s, 3] - rs[2]) < 2e-4 and int(rec[s, 9]) == int(rs[3])
+            if rs[3] > 0:
+                assert (rec[s, 10] == 1.0) == (rs[5] == 1.0)
     assert int(nnz[0]) == int(f["plane_depth_nnz"]) == int(f["enrich.nnz"])
     pd = f["plane_depth_f16"].astype(np.float32)
     d = np.abs(di[0, 0].cpu().numpy() - pd)

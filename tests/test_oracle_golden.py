@@ -77,6 +77,16 @@ def test_full_path(golden_dir, seeded_weights, name):
         sc = f[p + ".scalars"]
         assert abs(t["n_inl"] - sc[0]) <= 2 and t["accepted"] == bool(sc[2]) and t["valid"] == bool(sc[5])
         assert abs(t["offset"] - sc[3]) < 1e-4
+        # ... and against what the REFERENCE's own mean_normal_ranasc / plane_offset_ransac / generate_depth_from_plane returned in the
+        # golden run (main.py:38-62, 68-101, 110-127; recorded by oracle/tools/make_golden.py around the reference's functions):
+        # [normal inliers, mean |angle|, offset, offset inliers, points on the plane, projection accepted]; nan / -1 = not reached
+        rs = f["ref" + p + ".scalars"]
+        assert np.abs(t["n_bar"].numpy() - f["ref" + p + ".n_bar"]).max() < 1e-5
+        assert abs(t["n_inl"] - rs[0]) <= 2 and abs(t["mean_angle"] - rs[1]) < 1e-3
+        assert t["accepted"] == (not np.isnan(rs[2]))
+        if t["accepted"]:
+            assert abs(t["offset"] - rs[2]) < 1e-4 and t["n_off_inl"] == int(rs[3])
+            assert t["valid"] == (rs[5] == 1.0) or rs[3] == 0          # (no offset inliers: the reference never projects)
     assert taps["enrich_trace"][0]["nnz"] == int(f["enrich.nnz"])
     assert np.array_equal(taps["enrich_trace"][0]["sub"], f["enrich.sub"])
     en = taps["enriched"][0, 0]

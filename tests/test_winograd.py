@@ -58,6 +58,7 @@ def test_oracle_restatement_is_a_3x3_conv(m, shape):
 def test_winograd_choice_policy(monkeypatch):
     from vi_depth_completion_amd import engine as E
     monkeypatch.delenv("VIDC_WINOGRAD", raising=False)
+    monkeypatch.setattr(E, "_TUNING", {})                   # the heuristic, not the measured per-layer verdicts
     assert E.winograd_choice(1, 60, 80, 768, 768, 3, 3, 1, 1, 1, 1) == 4          # large map
     assert E.winograd_choice(1, 15, 20, 1536, 1536, 3, 3, 1, 1, 1, 2) == 2        # small map
     assert E.winograd_choice(1, 60, 80, 64, 64, 3, 3, 1, 1, 1, 4) == 0            # K = 64 per GEMM: the transforms would dominate
@@ -164,7 +165,7 @@ def test_winograd_conv_second_affine_and_direct_kernel_agree(m):
     assert (nchw(y).cpu() - ref).abs().max().item() < 2e-4
     wp = torch.stack([ops.pack_conv_weight(wg.to(DEV)) for wg in w])
     yd = ops.conv2d_bn_act(xd, wp, s1.to(DEV), b1.to(DEV), 3, 3, 1, 1, relu1=True, scale2=s2.to(DEV), shift2=b2.to(DEV), relu2=True, groups=G)
-    assert (y - yd).abs().max().item() < 1e-4
+    assert (y - yd).abs().max().item() < 2e-4
 
 
 @pytest.mark.gpu

@@ -5,7 +5,7 @@ set -u
 B=${1:-4}; H=${2:-256}; OUT=${3:-gpurun_out/r5_tune}
 mkdir -p $OUT
 for m in 2 4; do
-  VIDC_WINOGRAD=$m python tools/autotune.py --heights $H --batches $B --only-missing --frame-only --splitk 1,2,4 > $OUT/autotune_w${m}_b${B}_h${H}.log 2>&1
+  VIDC_WINOGRAD=$m python tools/autotune.py --heights $H --batches $B --only-missing --merge --splitk 1,2,4 > $OUT/autotune_w${m}_b${B}_h${H}.log 2>&1
   tail -3 $OUT/autotune_w${m}_b${B}_h${H}.log
 done
 cp vi_depth_completion_amd/conv_tuning.json $OUT/conv_tuning_gemms.json

@@ -209,7 +209,11 @@ def winograd_choice(B, H, W, co, ci, kh, kw, stride, padding, dilation, G):
     if mode in ("0", "2", "4"):
         m = int(mode)
     else:
-        ent = tuning_table().get("W:M%d_N%d_K%d_k3s1_G%d" % (B * H * W, co, 9 * ci, G))      # [m in the fp32 mode, m in the mixed mode]
+        ent = None                                # [m in the fp32 mode, m in the mixed mode]; measured on the frame program (4 pyramid groups):
+        for gg in (G, 4, 3, 1, 2):                # the stand-alone programs run the same layers with 1 / 3 groups and take that verdict
+            ent = tuning_table().get("W:M%d_N%d_K%d_k3s1_G%d" % (B * H * W, co, 9 * ci, gg))
+            if ent is not None:
+                break
         if ent is not None:
             m = int(ent[1 if precision_mode() == "mixed" else 0]) if isinstance(ent, (list, tuple)) else int(ent)
         elif ci < 128:

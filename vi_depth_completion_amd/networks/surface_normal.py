@@ -34,6 +34,13 @@ class _HipModule(nn.Module):
             self._invalidate()
         return r
 
+    def _replicate_for_data_parallel(self):
+        # torch.nn.DataParallel (network_run.py:97-99) copies a module per GPU and re-broadcasts its parameters on every forward; a
+        # replica of this module would share the packed weights and captured graphs of GPU 0.  Refused, not emulated: frames shard one
+        # process per GPU (vi_depth_completion_amd/sharding.py, bench.py --gpus N).
+        raise RuntimeError("%s: torch.nn.DataParallel is not supported by the HIP path; run one process per GPU "
+                           "(vi_depth_completion_amd.sharding, bench.py --gpus N)" % type(self).__name__)
+
     def _check(self, *tensors):
         if self.training:
             raise RuntimeError("%s: the HIP path is inference-only (BatchNorm is folded); call .eval()" % type(self).__name__)
