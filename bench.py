@@ -86,7 +86,7 @@ def parse():
     ap.add_argument("--no-mixed-leg", action="store_true", help="only the headline leg (every conv in exact fp32 MFMA arithmetic)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short child-process runs of BASELINE configs[4] (training step, bf16) and "
                                                                  "configs[2] (640x480 stream, batch 8, plane head) that the default N=1 run appends as `extra_legs`")
-    ap.add_argument("--extra-legs-budget", type=float, default=75.0, help="seconds of wall clock since the start of this process after which no further extra leg is started")
+    ap.add_argument("--extra-legs-budget", type=float, default=100.0, help="seconds of wall clock since the start of this process after which no further extra leg is started")
     ap.add_argument("--no-sequential-leg", action="store_true", help="skip the short back-to-back _call_cnn measurement (per-frame latency and the "
                                                                        "rate of the operator the reference's harness calls, network_run.py:294-296)")
     ap.add_argument("--sequential-frames", type=int, default=20)
@@ -96,6 +96,10 @@ def parse():
                          "ModifiedFPN on --batch frames per GPU (train-mode BatchNorm, masked L1 / (H*W), Adam; fwd + dgrad + wgrad on the MFMA conv "
                          "kernel; VIDC_TRAIN_PRECISION=bf16 is the arithmetic the configuration names), gradients summed over ranks with a "
                          "bucketed RCCL all-reduce overlapped with the backward")
+    ap.add_argument("--regions", type=int, default=5, help="the K-step timed region is run this many times back to back (each bracketed by barrier + "
+                    "synchronize, max over ranks per region); `value` / `ms_per_step` are the MEDIAN region, all of them are listed in `regions` (SURVEY 8d: median of 5)")
+    ap.add_argument("--steady-frames", type=int, default=0, help="frames of the untimed long stream whose device time stamps give `steady_state_frames_per_s` "
+                    "(0 = 16 x lanes x frames per launch; negative = skip)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no GPU work: every rank only joins the process group and gathers a fake record (tests/test_bench_launcher.py runs "
                          "`bench.py --gpus 2 --launcher-selftest` under gloo on the CPU: spawn, rendezvous, gather, the n_gpus check)")
@@ -113,14 +117,35 @@ def launch_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or args.gpus) // args.gpus)))
+    # every rank's stderr is also kept in a file of its own (torchrun --log-dir / --tee 2; stdout stays untouched: rank 0's ONE JSON line):
+    # a rank that dies -- a HIP initialisation error, a signal (faulthandler is on in the ranks) -- leaves its last words there even when
+    # the launcher's own stream is cut; they are replayed below on failure
+    log_dir = os.environ.get("VIDC_RANK_LOG_DIR") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "vidc_rank_logs_%d" % os.getpid())
+    os.makedirs(log_dir, exist_ok=True)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+           "--log-dir", log_dir, "--tee", "2", os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank job exited with code %d; per-rank logs under %s\n" % (args.gpus, rc, log_dir))
+        for root, _dirs, files in sorted(os.walk(log_dir)):
+            for fn in sorted(files):
+                if fn.endswith((".log", ".json")) or fn in ("stderr", "stdout", "error.json"):
+                    try:
+                        txt = open(os.path.join(root, fn), errors="replace").read()
+                    except OSError:
+                        continue
+                    if txt.strip():
+                        sys.stderr.write("---- %s (last 1500 chars) ----\n%s\n" % (os.path.relpath(os.path.join(root, fn), log_dir), txt[-1500:]))
+    return rc
 
 
 def launcher_selftest(args, rank, world):
     """The N > 1 plumbing without the GPU: group, gather, the rank-count check, ONE line from rank 0."""
     import torch.distributed as dist
+    if os.environ.get("VIDC_SELFTEST_KILL_RANK") == str(rank):        # (tests: what the launcher does when a rank dies)
+        sys.stderr.write("selftest: rank %d told to die\n" % rank)
+        sys.stderr.flush()
+        os._exit(17)
     rec = sharding.metric_record(args.steps, 1.0 + 0.5 * rank, 0.0, 0.0)
     got = sharding.gather_records(rec)
     assert got.shape[0] == world, "gathered %d records from a world of %d" % (got.shape[0], world)
@@ -199,6 +224,25 @@ def conv_stack_times(prog, iters=5):
     return out, total, list(zip(prog.op_names, per))
 
 
+def winograd_summary(prog, ops, fpt, frames_per_s, peak_tflops, ref_flops_per_tick):
+    """How much of the conv stack runs in the Winograd domain, and the frame rate priced in DIRECT-form FLOPs: the 3x3 layers that run as
+    F(m x m, 3x3) execute 2.25x - 4x fewer multiply-adds than their direct form, so frames/s x the reference formulation's FLOPs can exceed
+    the MFMA peak; `conv_stack.*executed*` above always counts what the MFMA kernel really executes (transform-domain GEMMs)."""
+    wl = [n for n, _t in ops if n.startswith("conv:") and "@wino" in n]
+    t_in = sum(t for n, t in ops if n.startswith("wino_in"))
+    t_out = sum(t for n, t in ops if n.startswith("wino_out"))
+    t_gemm = sum(t for n, t in ops if n.startswith("conv:") and "@wino" in n)
+    out = {"layers_per_tick": len(wl), "F4_layers": sum("@wino4" in n for n in wl), "F2_layers": sum("@wino2" in n for n in wl),
+           "transform_ms_per_frame": round((t_in + t_out) / fpt, 4), "gemm_ms_per_frame": round(t_gemm / fpt, 4),
+           "reference_formulation_tflops_at_measured_frame_rate": round(ref_flops_per_tick / fpt * frames_per_s / 1e12, 2),
+           "reference_formulation_frac_of_peak": round(ref_flops_per_tick / fpt * frames_per_s / 1e12 / peak_tflops, 4),
+           "note": "direct-form (reference formulation, 2 FLOP/MAC) conv FLOPs per frame x measured frames/s over the dense MFMA peak of the leg's "
+                   "arithmetic: an ALGORITHMIC rate (can exceed 1: Winograd layers execute fewer multiplies); MFMA utilisation = conv_stack.at_measured_frame_rate"}
+    if prog is not None:
+        out["executed_over_direct_flops"] = round(prog.flops / max(1, prog.direct_flops), 4)
+    return out
+
+
 def measure(args, dev, rank, world, precision):
     """One leg: builds the pipeline in `precision` mode ("mixed" | "fp32": engine.precision_mode reads VIDC_PRECISION when a program is
     recorded), runs W untimed + K timed steps bracketed by barrier + synchronize, then (rank 0) the live roofline of what was timed."""
@@ -247,17 +291,39 @@ def measure(args, dev, rank, world, precision):
     if args.mode == "interleaved":      # set-up like the weight load above: every lane's program recorded, captured and uploaded before the first step
         pipe.prepare_interleaved(next(iter(frames(1))), lanes=lanes, frames_per_launch=args.frames_per_launch)
     run(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    region_s = []
+    for _r in range(max(1, args.regions)):      # every region: exactly K steps between barrier + synchronize on both sides
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        region_s.append(time.perf_counter() - t0)
+    elapsed = sorted(region_s)[len(region_s) // 2]      # this rank's median region (roofline bookkeeping below); the line uses max over ranks per region
+
+    # ---- steady state of the stream mode (outside the timed regions): one long stream, a device time stamp behind every item's result;
+    #      rate between two group boundaries well inside it, i.e. without the fill and the drain a K-step region contains ------------------
+    steady = None
+    if rank == 0 and args.mode == "interleaved" and args.steady_frames >= 0:
+        grp = lanes * args.frames_per_launch
+        n_long = args.steady_frames if args.steady_frames > 0 else 16 * grp
+        n_long = max(6 * grp, n_long // grp * grp)
+        evs = []
+        for _out in pipe.run_interleaved(frames(n_long), copy_outputs=False, lanes=lanes, frames_per_launch=args.frames_per_launch):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()                                  # the caller's stream has just been made to wait for this item's result
+            evs.append(e)
+        torch.cuda.synchronize()
+        i0, i1 = 2 * grp - 1, n_long - 2 * grp - 1      # last items of two groups, two groups away from either end
+        ms = evs[i0].elapsed_time(evs[i1])
+        steady = {"frames_per_s": round((i1 - i0) * B / (ms * 1e-3), 2), "frames": n_long,
+                  "what": "device time stamps (HIP events on the caller's stream behind every item's result) of one untimed stream of %d items: items "
+                          "%d..%d / elapsed device time -- the K-step regions above additionally contain the fill and the drain of the pipeline" % (n_long, i0, i1)}
 
     # ---- latency of the first item of a stream in the mode that was timed (outside the timed region): host time from the first request to
     #      the first depth map being complete on the device; with --frames-per-launch F the first F items finish together ------------------
@@ -373,6 +439,8 @@ def measure(args, dev, rank, world, precision):
                                     "tflops_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / fpt * (args.steps * B / elapsed) / 1e12, 2),
                                     "frac_of_peak_executed": round(sum(v[2] * (3 if k[1] == "bf16x3" else 1) for k, v in kernels.items()) / fpt * (args.steps * B / elapsed) / 1e12
                                                                    / (PEAK_BF16_MFMA_TFLOPS if precision == "mixed" else PEAK_F32_MFMA_TFLOPS), 4)}},
+                 "winograd": winograd_summary(fp if args.mode == "interleaved" else None, (sn_ops + dc_ops), fpt, args.steps * B / elapsed,
+                                              PEAK_BF16_MFMA_TFLOPS if precision == "mixed" else PEAK_F32_MFMA_TFLOPS, flops),
                  "reference_formulation_gflop_per_frame": round(flops / fpt / 1e9, 2),
                  "conv_stack_tflops_reference_formulation": round(flops / (conv_ms * 1e-3) / 1e12, 2),
                  "precision_mode": precision, "sequential_call_cnn": sequential,
@@ -384,7 +452,7 @@ def measure(args, dev, rank, world, precision):
                 for name, ops in ((("frame_program" if args.mode == "interleaved" else "surface_normal"), sn_ops), ("depth_completion", dc_ops)):
                     for n, t in ops:
                         f.write("%s\t%.2f\t%s\n" % (name, t * 1e3, n))
-    return {"elapsed": elapsed, "pipe": pipe, "lanes": lanes, "sn_sd": sn_sd, "dc_sd": dc_sd, "cc": cc, "det_sd": det_sd, "roofline": roofline, "extra": extra,
+    return {"elapsed": elapsed, "region_s": region_s, "steady": steady, "pipe": pipe, "lanes": lanes, "sn_sd": sn_sd, "dc_sd": dc_sd, "cc": cc, "det_sd": det_sd, "roofline": roofline, "extra": extra,
             "frames": frames, "pre": pre}
 
 
@@ -449,6 +517,9 @@ def main():
         sys.exit(launch_ranks(args))              # nothing below runs in the launching process
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import faulthandler
+        faulthandler.enable()                     # a rank killed by SIGSEGV / SIGBUS / SIGABRT writes its Python stack to stderr (the per-rank log)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     backend = os.environ.get("VIDC_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" to try the N > 1 path on a box with fewer GPUs
@@ -467,6 +538,10 @@ def main():
     if world > n_dev and backend == "nccl":
         raise SystemExit("bench.py: %d ranks on %d GPU(s): one rank per GPU (set VIDC_DIST_BACKEND=gloo to share GPUs on purpose)" % (world, n_dev))
     local = int(os.environ.get("LOCAL_RANK", "0")) % n_dev     # (the modulo only matters for the gloo try-out on a smaller box)
+    if world > 1:
+        # the ranks of a node open the GPU driver one after the other (0.25 s apart, outside every timed region): round 4 saw one rank of a
+        # two-rank job die within seconds of starting as the first GPU processes of a fresh box, before any launch of this package
+        time.sleep(0.25 * int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.set_grad_enabled(False)
@@ -524,6 +599,7 @@ def main():
     recs = {m: torch.zeros(4, dtype=torch.float64, device=dev) for m in legs}   # frames, seconds, sum sq err, n px
     for m in legs:
         recs[m][0], recs[m][1] = args.steps * B, res[m]["elapsed"]
+    n_reg = len(lead["region_s"])
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import vidc_oracle as O
@@ -581,17 +657,32 @@ def main():
     for m in legs:
         assert gathered[m].shape[0] == world, "gathered %d records from a world of %d ranks" % (gathered[m].shape[0], world)
     jobs = {m: sharding.combine(gathered[m]) for m in legs}
+    # per region: frames of all ranks / max over ranks of that region's time (one more 4-double gather per region and leg, outside every timed region)
+    region_fps = {}
+    for m in legs:
+        fps = []
+        for r_ in range(n_reg):
+            rr = torch.zeros(4, dtype=torch.float64, device=dev)
+            rr[0], rr[1] = args.steps * B, res[m]["region_s"][r_]
+            jr = sharding.combine(sharding.gather_records(rr))
+            fps.append((jr["frames"] / jr["seconds"], jr["seconds"]))
+        region_fps[m] = fps
     extra_legs = None
     if rank == 0 and world == 1 and not args.no_extra_legs and not args.source and not args.plane_head and B == 1 and args.mode == "interleaved":
         torch.cuda.synchronize()
         extra_legs = run_extra_legs(args)
     if rank == 0:
         job = jobs[main_mode]
-        frames, t_max = job["frames"], job["seconds"]
+        med = sorted(region_fps[main_mode])[n_reg // 2]          # the median region: (frames/s over all ranks, max-over-ranks seconds)
         F = args.frames_per_launch if args.mode == "interleaved" else 1
+        spread = (max(v[0] for v in region_fps[main_mode]) - min(v[0] for v in region_fps[main_mode])) / med[0]
         line = {
-            "metric": "frames/sec", "value": round(frames / t_max, 3), "unit": "frames/s", "n_gpus": int(gathered[main_mode].shape[0]), "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True,
+            "metric": "frames/sec", "value": round(med[0], 3), "unit": "frames/s", "n_gpus": int(gathered[main_mode].shape[0]), "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * med[1] / args.steps, 4), "higher_is_better": True,
+            "regions": [round(v[0], 3) for v in region_fps[main_mode]], "regions_spread": round(spread, 4),
+            "regions_note": "%d back-to-back timed regions of exactly %d steps each (barrier + synchronize on both sides, max over ranks per region); "
+                            "value / ms_per_step = the median region" % (n_reg, args.steps),
+            "steady_state_frames_per_s": (lead["steady"] or {}).get("frames_per_s"), "steady_state": lead["steady"],
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if main_mode == "fp32" else "f32+bf16x3"), "data": "synthetic",
             "config": {"workload": (("BASELINE configs[1]: synthetic %dx%d RGB + 200-pt sparse depth, batch %d per GPU, plane mask "
@@ -606,6 +697,9 @@ def main():
                                                   "the stream share every launch of a tick (program recorded for batch %d), an item's result does not depend on "
                                                   "its partner" % (B, F, F * B)) if F > 1 else None,
                        "frames_in_flight": (2 * lead["lanes"] * F if args.mode == "interleaved" else args.in_flight if args.mode == "streams" else 1),
+                       "latency_note": ("`value` is a stream rate: %d batch-%d items share every launch on %d lanes (%d frames in flight; first depth map of a stream "
+                                        "after first_item_latency_ms).  The reference's operator called one frame at a time is `sequential_call_cnn`; the "
+                                        "one- and two-items-per-launch stream rates are in `extra_legs`." % (F, B, lead["lanes"], 2 * lead["lanes"] * F)) if F > 1 else None,
                        "sharding": "frames round-robin over %d rank(s), no data-path collective" % world},
             "rmse_vs_oracle": (round(job["rmse"], 8) if job["rmse"] is not None else None),
             "roofline": lead["roofline"], "cpu_baseline": cpu_baseline,
@@ -614,7 +708,8 @@ def main():
         for m in legs[1:]:
             jm, rm = jobs[m], res[m]
             line.update({
-                "value_" + m: round(jm["frames"] / jm["seconds"], 3), "ms_per_step_" + m: round(1e3 * jm["seconds"] / args.steps, 4),
+                "value_" + m: round(sorted(region_fps[m])[n_reg // 2][0], 3), "ms_per_step_" + m: round(1e3 * sorted(region_fps[m])[n_reg // 2][1] / args.steps, 4),
+                "regions_" + m: [round(v[0], 3) for v in region_fps[m]], "steady_state_frames_per_s_" + m: (rm["steady"] or {}).get("frames_per_s"),
                 "dtype_" + m: ("f32" if m == "fp32" else "f32+bf16x3"), "rmse_vs_oracle_" + m: (round(jm["rmse"], 8) if jm["rmse"] is not None else None),
                 "roofline_" + m: rm["roofline"],
                 m + "_leg": {"what": ("the same %d steps in the mixed mode: the compute-bound convs on 3 x v_mfma_f32_32x32x16_bf16 per fp32-equivalent product "
@@ -648,23 +743,31 @@ def run_extra_legs(args):
              # the headline runs four items per launch (first depth map of a stream after ~26 ms); this is the same workload at the
              # lower-latency setting of the knob (two items per launch, ~15 ms), in the headline's arithmetic
              ("configs[1] with two items per launch (lower first-item latency), fp32", {},
-              ["--steps", "20", "--warmup", "5", "--frames-per-launch", "2", "--no-mixed-leg", "--no-cpu-baseline", "--no-sequential-leg", "--no-extra-legs"])]
+              ["--steps", "20", "--warmup", "5", "--frames-per-launch", "2", "--no-mixed-leg", "--no-cpu-baseline", "--no-sequential-leg", "--no-extra-legs"]),
+             ("configs[1] with one item per launch (every launch is one batch-1 frame), fp32", {},
+              ["--steps", "20", "--warmup", "5", "--frames-per-launch", "1", "--no-mixed-leg", "--no-cpu-baseline", "--no-sequential-leg", "--no-extra-legs"])]
     for name, env_add, flags in specs:
         if time.perf_counter() - t_start > args.extra_legs_budget:
             out[name] = {"skipped": "wall-clock budget of the run (%.0f s) used up" % args.extra_legs_budget}
             continue
-        env = {k: v for k, v in os.environ.items() if k not in ("VIDC_PRECISION", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        # the child is a fresh one-rank job: nothing of this process's launcher / process-group environment may reach it (a parent run with
+        # VIDC_DIST_WORLD1=1 still holds its TCPStore on MASTER_PORT: a child that inherited it would fail with address-in-use)
+        drop = ("VIDC_PRECISION", "RANK", "WORLD_SIZE", "LOCAL_RANK", "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "VIDC_DIST_WORLD1",
+                "MASTER_PORT", "MASTER_ADDR")
+        env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_")}
         env.update(env_add)
         t1 = time.perf_counter()
+        remaining = args.extra_legs_budget - (t1 - t_start)
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1"] + flags, env=env, capture_output=True, text=True, timeout=80)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1"] + flags, env=env, capture_output=True, text=True,
+                               timeout=max(20.0, min(80.0, remaining + 30.0)))      # a leg started inside the budget gets at most 30 s past it
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not lines:
                 out[name] = {"error": "exit code %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
                 continue
             d = json.loads(lines[-1])
             out[name] = {k: d.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "rmse_vs_oracle", "value_mixed", "ms_per_step_mixed",
-                                                       "dtype_mixed", "losses", "first_item_latency_ms", "config")
+                                                       "dtype_mixed", "losses", "first_item_latency_ms", "regions", "steady_state_frames_per_s", "config")
                          if d.get(k) is not None}
             out[name]["roofline"] = {k: (d.get("roofline") or {}).get(k) for k in ("bound", "achieved", "peak", "unit", "frac")}
             out[name]["command"] = "bench.py --gpus 1 " + " ".join(flags) + ("  [" + " ".join("%s=%s" % kv for kv in env_add.items()) + "]" if env_add else "")

@@ -14,7 +14,7 @@ VIDC_TRAIN_PRECISION=bf16 python tools/pack_bench.py 2>&1 | grep -v amdgpu > $O/
 for f in $O/bench_line*.json; do python - "$f" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(sys.argv[1].split('/')[-1], d['value'], d['dtype'], (d.get('conv_stack') or {}).get('at_measured_frame_rate',{}).get('frac_of_peak_executed'), d.get('value_mixed'), d.get('first_item_latency_ms'), [ (e.get('leg'), e.get('value'), e.get('ms_per_step'), e.get('error')) for e in (d.get('extra_legs') or [])])
+print(sys.argv[1].split('/')[-1], d['value'], d['dtype'], (d.get('conv_stack') or {}).get('at_measured_frame_rate',{}).get('frac_of_peak_executed'), d.get('value_mixed'), d.get('first_item_latency_ms'), [(name, e.get('value'), e.get('ms_per_step'), e.get('error')) for name, e in (d.get('extra_legs') or {}).items()])
 PY
 done
 for f in $O/train_line*.json; do python - "$f" <<'PY'

@@ -6,6 +6,7 @@ same input-batch dictionary (dataset.py:515-520), same output (B,1,H,W) depth te
 (network_run.py:319-323, main.py:256-259).  See INTEGRATION.md for how the unchanged main.py/network_run.py bind to it.
 """
 import argparse
+import weakref
 
 import numpy as np
 import torch
@@ -107,6 +108,7 @@ def build_frame_program(sn, dc, B, H, W, device, dry_run=False, weights=None):
     if not dry_run:
         prog.storage[kinv.buf][:9].copy_(wp.kinv(device))
         import os
+import weakref
         if os.environ.get("VIDC_TICK_VARIANTS", "1") == "1":
             # first tick of a stream: only the surface-normal side of segment 0 (pyramid group 0 + decoder + warps); drain tick: only the
             # depth-completion pyramids (groups 1..3) -- engine.Program.group_variant: same buffers, weights, tiles, bit-identical results
@@ -374,6 +376,11 @@ class DepthCompletionPipeline:
                 out, ev, n, lane = ready.pop(nxt)
                 nxt += 1
                 torch.cuda.current_stream().wait_event(ev)        # device-side: readers on the caller's stream find the items complete
+                if copy_outputs:
+                    # the clone was allocated on the LANE's stream and is read on the caller's: without this the caching allocator hands the
+                    # block back to the lane's pool when the caller drops the tensor and a later visit of the lane (hypothesis temporaries,
+                    # the next clone) may overwrite it under a read the caller enqueued asynchronously
+                    out.record_stream(torch.cuda.current_stream())
                 B = out.shape[0] // F
                 for j in range(n):
                     yield out[j * B:(j + 1) * B]
@@ -435,6 +442,8 @@ class DepthCompletionPipeline:
                 out = self.cnn.enqueue(st["rgb"], st["normals"], depth_in, 0)
                 out = out.clone() if copy_outputs else out
             main.wait_stream(sb)
+            if copy_outputs:
+                out.record_stream(main)          # allocated on stream B, consumed on the caller's (see _run_grouped's flush)
             return out
 
         for batch in batches:
@@ -615,16 +624,21 @@ class _GroupLane:
 
     def _homo(self, j, batch):
         """The item's homogeneous coordinates on the device, safe to read after the caller got control back: a host tensor goes through
-        the slot's staging ring; a device tensor of the caller is copied once and again only when it was written to since (its
-        data pointer / version counter: a camera's grid does not change between frames)."""
+        the slot's staging ring; a device tensor of the caller is copied into the slot's own buffer on EVERY put (0.9 MB device to
+        device on the lane's stream, overlapped).  Round 4 cached the copy keyed on (data_ptr, _version): writes through raw pointers
+        -- this package's own kernels, dlpack / numpy views -- do not bump `_version` and a refilled grid was served stale, `_version`
+        raises on inference-mode tensors, and the cache pinned the caller's tensor.  `pipe.static_grid = True` opts back into copying
+        only when the tensor OBJECT changes (a camera whose grid is never rewritten in place)."""
         t = batch["homogeneous_coordinates"]
         if not t.is_cuda:
             return self.stagers[j]("homogeneous_coordinates", t, self.pipe.device)
         ent = self.cache["homo"][j]
-        key = (t.data_ptr(), t._version, tuple(t.shape))
-        if ent is None or ent[0] != key:
-            ent = (key, t.clone(), t)             # (the source stays referenced: its address cannot be handed to another tensor meanwhile)
+        if ent is None or ent[1].shape != t.shape or ent[1].dtype != t.dtype:
+            ent = [None, torch.empty_like(t)]
             self.cache["homo"][j] = ent
+        if not (getattr(self.pipe, "static_grid", False) and ent[0] is not None and ent[0]() is t):
+            ent[1].copy_(t, non_blocking=True)
+            ent[0] = weakref.ref(t)
         return ent[1]
 
     # ---- launch sequence -------------------------------------------------------------------------------------------------------------
