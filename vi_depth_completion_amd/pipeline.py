@@ -108,7 +108,6 @@ def build_frame_program(sn, dc, B, H, W, device, dry_run=False, weights=None):
     if not dry_run:
         prog.storage[kinv.buf][:9].copy_(wp.kinv(device))
         import os
-import weakref
         if os.environ.get("VIDC_TICK_VARIANTS", "1") == "1":
             # first tick of a stream: only the surface-normal side of segment 0 (pyramid group 0 + decoder + warps); drain tick: only the
             # depth-completion pyramids (groups 1..3) -- engine.Program.group_variant: same buffers, weights, tiles, bit-identical results
@@ -376,7 +375,7 @@ class DepthCompletionPipeline:
                 out, ev, n, lane = ready.pop(nxt)
                 nxt += 1
                 torch.cuda.current_stream().wait_event(ev)        # device-side: readers on the caller's stream find the items complete
-                if copy_outputs:
+                if copy_outputs and out.is_cuda:
                     # the clone was allocated on the LANE's stream and is read on the caller's: without this the caching allocator hands the
                     # block back to the lane's pool when the caller drops the tensor and a later visit of the lane (hypothesis temporaries,
                     # the next clone) may overwrite it under a read the caller enqueued asynchronously
@@ -442,7 +441,7 @@ class DepthCompletionPipeline:
                 out = self.cnn.enqueue(st["rgb"], st["normals"], depth_in, 0)
                 out = out.clone() if copy_outputs else out
             main.wait_stream(sb)
-            if copy_outputs:
+            if copy_outputs and out.is_cuda:
                 out.record_stream(main)          # allocated on stream B, consumed on the caller's (see _run_grouped's flush)
             return out
 
