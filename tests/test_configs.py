@@ -109,39 +109,27 @@ def test_config2_640x480_batch8_with_plane_head(pipe, detector, detector_weights
             flipped.append(int((ids_dev[i] != ids_or[i]).sum()))
         print("configs[2]: per image -- detections (device / oracle lists agree) %s, unmatched detections %s, differing id pixels %s, planes %s"
               % ([int(a) for a in agree], unmatched, flipped, [int(m.max()) for m in ids_dev]))
-        # Integer work, asserted exactly: wherever the two detection lists agree (every box and score; the decisions that follow --
-        # score > 0.9, mask > 0.5 per pixel, biggest component, >= 5 % of the image, ids by size -- are then taken on the same numbers)
-        # the id maps must be identical pixel for pixel.  Where a detection decision upstream flipped (random-noise frames put NMS IoUs
-        # within 1e-2 of their thresholds: round 3 found one box pair at IoU 0.4987 / 0.4951 against the 0.5 bar on frame 40) the maps may
-        # differ, but only on ONE image of the eight, by at most two detections, and on at most 3 % of its pixels.
-        for i in range(B):
-            if agree[i]:
-                assert flipped[i] == 0, "image %d: same detections as the oracle but %d id pixels differ" % (i, flipped[i])
-        assert sum(agree) >= B - 1, (agree, unmatched)
-        assert all(u <= 4 for u in unmatched) and all(f <= 0.03 * 240 * 320 for f in flipped), (unmatched, flipped)
+        # Integer work, asserted exactly: the detector's programs run every conv in exact fp32, direct form, whatever mode the depth path is in
+        # (networks/plane_mask_rcnn.detector_arithmetic), so EVERY image must take the oracle's detection decisions -- same boxes, same
+        # scores -- and the decisions that follow (score > 0.9, mask > 0.5 per pixel, biggest component, >= 5 % of the image, ids by size)
+        # must give the oracle's id map pixel for pixel.  (Round 4 ran the detector in the mixed mode and had to allow one flipped NMS
+        # decision on one of these eight noise frames: box pair at IoU 0.4987 / 0.4951 against the 0.5 bar.)
+        assert all(agree), (agree, unmatched)
+        assert all(f == 0 for f in flipped), flipped
         assert max(int(m.max()) for m in ids_dev) >= 2, "the seeded detector finds planes on these frames"
-        # ... and such a flip is ARITHMETIC, not logic: the detector recorded with every conv in exact fp32 (VIDC_PRECISION=fp32; the mixed
-        # mode's bf16x3 products move box regressions by ~1e-3 px, enough for an IoU 5e-3 off its threshold on noise frames) takes the
-        # oracle's decisions on every image -- same detections, same id maps, pixel for pixel
-        if not all(agree):
-            from vi_depth_completion_amd.plane_mask import PlaneMaskDetector
-            monkeypatch.setenv("VIDC_PRECISION", "fp32")
-            det32 = PlaneMaskDetector(device=DEV)
-            det32.load_state_dict({k: v.to(DEV) for k, v in detector_weights.items()})
-            ids32 = det32.run_on_batch(dev_batch["image"]).cpu().numpy()
-            bf32, _ = det32._ctx(B, 240, 320)
-            n32, s32, b32 = bf32.n_det.cpu().numpy(), bf32.det_scores.cpu().numpy(), bf32.det_boxes.cpu().numpy()
-            monkeypatch.delenv("VIDC_PRECISION")
-            for i in range(B):
-                so, bo = or_dets[i]
-                sd, bd = s32[i][:n32[i]], b32[i][:n32[i]]
-                miss = sum(1 for k in range(len(so)) if not len(sd) or not _has_match(bo[k], so[k], bd, sd)) + \
-                    sum(1 for k in range(len(sd)) if not len(so) or not _has_match(bd[k], sd[k], bo, so))
-                assert miss == 0 and len(so) == len(sd), "image %d: the fp32 detector still disagrees with the oracle (%d unmatched)" % (i, miss)
-                assert int((ids32[i] != ids_or[i]).sum()) == 0, "image %d: fp32 detector, same detections, %d id pixels differ" % (i, int((ids32[i] != ids_or[i]).sum()))
-            print("configs[2]: with the detector in fp32 all %d images take the oracle's detection decisions and id maps (the mixed-mode flip on image(s) %s is arithmetic)"
-                  % (B, [i for i in range(B) if not agree[i]]))
-            del det32
+        # the opt-in mixed-mode detector (VIDC_DETECTOR_PRECISION=mixed): close, not exact -- at most one image with a flipped decision
+        from vi_depth_completion_amd.plane_mask import PlaneMaskDetector
+        monkeypatch.setenv("VIDC_DETECTOR_PRECISION", "mixed")
+        monkeypatch.setenv("VIDC_PRECISION", "mixed")
+        detm = PlaneMaskDetector(device=DEV)
+        detm.load_state_dict({k: v.to(DEV) for k, v in detector_weights.items()})
+        idsm = detm.run_on_batch(dev_batch["image"]).cpu().numpy()
+        monkeypatch.delenv("VIDC_DETECTOR_PRECISION")
+        monkeypatch.delenv("VIDC_PRECISION")
+        differing = [int((idsm[i] != ids_or[i]).sum()) for i in range(B)]
+        print("configs[2]: opt-in mixed-mode detector, differing id pixels per image %s" % differing)
+        assert sum(1 for d in differing if d) <= 1 and all(d <= 0.03 * 240 * 320 for d in differing), differing
+        del detm
         ref = O.call_cnn(seeded_weights["sn"], seeded_weights["dc"], ref_batch, ids_dev, INTR, 200, rng=np.random.RandomState(21))
         rmse = float((got - ref).pow(2).mean().sqrt())
         per_img = (got - ref).pow(2).mean(dim=(1, 2, 3)).sqrt()

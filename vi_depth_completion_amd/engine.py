@@ -202,10 +202,11 @@ def winograd_mode():
     return os.environ.get("VIDC_WINOGRAD", "auto")
 
 
-def winograd_choice(B, H, W, co, ci, kh, kw, stride, padding, dilation, G):
+def winograd_choice(B, H, W, co, ci, kh, kw, stride, padding, dilation, G, mode=None, precision=None):
     if (kh, kw, stride, padding, dilation) != (3, 3, 1, 1, 1) or ci % 32 or co % 32:
         return 0
-    mode = winograd_mode()
+    mode = mode if mode is not None else winograd_mode()
+    precision = precision if precision is not None else precision_mode()
     if mode in ("0", "2", "4"):
         m = int(mode)
     else:
@@ -215,7 +216,7 @@ def winograd_choice(B, H, W, co, ci, kh, kw, stride, padding, dilation, G):
             if ent is not None:
                 break
         if ent is not None:
-            m = int(ent[1 if precision_mode() == "mixed" else 0]) if isinstance(ent, (list, tuple)) else int(ent)
+            m = int(ent[1 if precision == "mixed" else 0]) if isinstance(ent, (list, tuple)) else int(ent)
         elif ci < 128:
             m = 0
         else:
@@ -235,7 +236,10 @@ def conv_signature(d):
 class Program:
     """Records ops symbolically (buffers are integers), then `finalize()` plans memory and builds the C program."""
 
-    def __init__(self, weights, device, batch, reuse_buffers=True):
+    def __init__(self, weights, device, batch, reuse_buffers=True, mode=None, winograd=None):
+        """mode: "fp32" | "mixed" (default: precision_mode()); winograd: "0" | "2" | "4" | "auto" (default: winograd_mode()) -- a program whose
+        results feed DECISIONS (the plane-mask detector: score / IoU / mask thresholds) is recorded with mode="fp32", winograd="0": exact
+        fp32 direct-form sums, the arithmetic its oracle pins."""
         self.ws, self.device, self.B = weights, device, batch
         self.ops = []            # (kind, dict)
         self.buf_elems = []      # elements per buffer id
@@ -252,7 +256,8 @@ class Program:
         self._split_cache = {}   # (buf, ch_off, channels) -> buffer id of the split-bf16 image
         self.cuts = []           # op indices where a new segment starts (see cut()); filled by finalize()
         self._cut_markers = []
-        self.mode = precision_mode()
+        self.mode = mode if mode is not None else precision_mode()
+        self.winograd = winograd
 
     # ---- buffers ----------------------------------------------------------------------------------------
     def _new_buf(self, elems, pinned=False):
@@ -315,7 +320,7 @@ class Program:
         flops = 2 * self.B * Ho * Wo * co * ci * kh * kw * G
         wm = 0
         if residual is None and not accumulate:
-            wm = winograd_choice(self.B, x.H, x.W, co, ci, kh, kw, stride, padding, dilation, G)
+            wm = winograd_choice(self.B, x.H, x.W, co, ci, kh, kw, stride, padding, dilation, G, mode=self.winograd, precision=self.mode)
         if wm:
             self.ref_flops += int(round(flops * ref_flops_scale))
             self.direct_flops += flops

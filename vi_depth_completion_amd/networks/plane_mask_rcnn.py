@@ -98,6 +98,16 @@ def cell_anchors(stride, size):
     return torch.from_numpy(np.vstack(out)).float()
 
 
+def detector_arithmetic():
+    """Arithmetic of the detector's three programs.  What they compute feeds DECISIONS -- score > 0.9, NMS IoU > 0.5 / 0.7, mask > 0.5 per
+    pixel (demo/predictor.py:143-190, 253-323) -- which are index work and must come out as the oracle's: every conv in exact fp32, direct
+    form (round 4 ran them in the mixed mode: bf16x3 products moved a box regression by ~1e-3 px and flipped one NMS decision on one of eight
+    noise frames; the cost of fp32 here is ~1.3 ms per batch of 8 next to ~26 ms).  VIDC_DETECTOR_PRECISION=mixed restores the old behaviour."""
+    import os
+    mode = os.environ.get("VIDC_DETECTOR_PRECISION", "fp32")
+    return {"mode": mode, "winograd": "0" if mode == "fp32" else None}
+
+
 class GeneralizedRCNN(_HipModule):
     def __init__(self):
         super().__init__()
@@ -178,7 +188,7 @@ class GeneralizedRCNN(_HipModule):
 
     def build_dense(self, B, H, W, device, dry_run=False):
         Hp, Wp = self.padded(H, W)
-        prog = engine.Program(self._weights, device, B)
+        prog = engine.Program(self._weights, device, B, **detector_arithmetic())
         img = prog.input_nchw("image", 3, H, W)
         cols = prog.det_im2col(img, Hp, Wp, PIXEL_MEAN_BGR)
         t = prog.conv(cols, "backbone.body.stem.conv1@im2col", bn="backbone.body.stem.bn1", relu=True)
@@ -211,7 +221,7 @@ class GeneralizedRCNN(_HipModule):
         return prog
 
     def build_box(self, B, device, dry_run=False):
-        prog = engine.Program(self._weights, device, B * ROI_SLOTS)
+        prog = engine.Program(self._weights, device, B * ROI_SLOTS, **detector_arithmetic())
         x = prog.nhwc(7, 7, 256)
         prog.pinned.add(x.buf)
         prog.inputs["pooled"] = x
@@ -222,7 +232,7 @@ class GeneralizedRCNN(_HipModule):
         return prog
 
     def build_mask(self, B, device, dry_run=False):
-        prog = engine.Program(self._weights, device, B * ROI_SLOTS)
+        prog = engine.Program(self._weights, device, B * ROI_SLOTS, **detector_arithmetic())
         x = prog.nhwc(14, 14, 256)
         prog.pinned.add(x.buf)
         prog.inputs["pooled"] = x
