@@ -33,6 +33,13 @@ SHAPES = {  # name: (H, W, cin, cout, k, G, tile, precision)
     "b2_l3_1x1_256to1024_G4_fp32": (32, 20, 256, 1024, 1, 4, 29, 0),
     "b2_l3_1x1_1024to256_G4_fp32": (32, 20, 1024, 256, 1, 4, 32, 0),
     "b2_l3_3x3_G4_fp32": (32, 20, 256, 256, 3, 4, 28, 0),
+    # round 5: four stream items per launch (M = 1280), fp32 leg
+    "b4_l3_1x1_1024to256_G4_fp32": (64, 20, 1024, 256, 1, 4, 32, 0),
+    "b4_l3_1x1_1024to256_G4_fp32_32x32k4d2": (64, 20, 1024, 256, 1, 4, 30, 0),
+    "b4_l3_1x1_1024to256_G4_fp32_64x64k2": (64, 20, 1024, 256, 1, 4, 5, 0),
+    "b4_l3_1x1_256to1024_G4_fp32": (64, 20, 256, 1024, 1, 4, 35, 0),
+    "b4_l3_1x1_256to1024_G4_fp32_64x64d2": (64, 20, 256, 1024, 1, 4, 29, 0),
+    "b4_l3_wino4_gemm_fp32": (4, 20, 256, 256, 1, 144, 8, 0),
 }
 
 
@@ -71,6 +78,12 @@ def main():
             t = t[:nb]
             start = (t[:, 6] - t[:, 6].min()) / 100.0          # us, 100 MHz clock
             end = (t[:, 7] - t[:, 6].min()) / 100.0
+            dur = end - start
+            order = np.argsort(start)
+            late = int((start > 0.5 * np.median(dur)).sum())       # workgroups that started after others had run for a while (a later round)
+            print("    per-workgroup: duration median %.2f us (min %.2f, max %.2f); %d of %d started late (> half a median duration after the first); "
+                  "sum of durations / (256 CUs x last end) = %.2f workgroups resident per CU on average" % (
+                      np.median(dur), dur.min(), dur.max(), late, nb, dur.sum() / (256.0 * end.max())))
             print("%-22s tile %-8s wgs %4d  event %.1f us | start skew max %.2f us, last end %.2f us | cycles: setup %.0f  issued %.0f  "
                   "first-data %.0f  loop-done %.0f  end %.0f | sub: args %.0f  B-issued %.0f  A-decoded %.0f  affine-loads %.0f" % (name, L.TILE_NAMES[tile], nb, e0.elapsed_time(e1) * 1e3, start.max(), end.max(),
                                                                   t[:, 0].mean(), t[:, 1].mean(), t[:, 2].mean(), t[:, 3].mean(), t[:, 4].mean(),

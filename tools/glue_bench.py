@@ -34,7 +34,7 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     H, W = 256, 320
     rows = []
-    for B in (1, 8, 32):
+    for B in (1, 4, 8, 32):
         wp = Warping2DOFAlignment(202.0, 202.0, 0.5 * 319.87654, 0.5 * 239.87603 * H / 240.0)
         b = S.synthetic_batch(B, H, W, 1234)
         x = b["image"].cuda()
@@ -50,6 +50,19 @@ def main():
             yo = torch.empty(B, Ho, Wo, Cc, device="cuda")
             us = timed(lambda: lib.vidc_upsample_bilinear_ac(xi.data_ptr(), yo.data_ptr(), B, h, w, Cc, Cc, Ho, Wo, Cc, 0, None, st))
             rows.append(("upsample %dx%dx%d -> %dx%d" % (h, w, Cc, Ho, Wo), B, us, (xi.numel() + yo.numel()) * 4))
+        # Winograd transforms (csrc/winograd.hip) of the layers that dominate them: dc/feature1_upsamping.0 (768 ch at 64x80, F(4x4)) and the
+        # level-2 launch of the depth decoder (3 x 768 ch at 32x40, F(4x4)); algorithmic bytes = the NHWC tensor + the transform-domain tensor
+        for (h, w, cin, G, m) in ((64, 80, 768, 1, 4), (32, 40, 768, 3, 4), (16, 20, 256, 4, 4), (16, 20, 1536, 2, 2)):
+            a2 = (m + 2) ** 2
+            tiles = B * (-(-h // m)) * (-(-w // m))
+            xi = torch.randn(B, h, w, G * cin, device="cuda")
+            v = torch.empty(tiles, a2 * G * cin, device="cuda")
+            one = torch.ones(G * cin, device="cuda")
+            us = timed(lambda: lib.vidc_winograd_input_transform(xi.data_ptr(), v.data_ptr(), B, h, w, G * cin, G * cin, cin, m, 0, 0, st))
+            rows.append(("wino_in F%d %dx%dx%d" % (m, h, w, G * cin), B, us, (xi.numel() + v.numel()) * 4))
+            us = timed(lambda: lib.vidc_winograd_output_transform(v.data_ptr(), xi.data_ptr(), None, one.data_ptr(), one.data_ptr(), None, None, B, h, w, G * cin, cin, G * cin, m,
+                                                                  L.RELU1, 0, st))
+            rows.append(("wino_out F%d %dx%dx%d" % (m, h, w, G * cin), B, us, (xi.numel() + v.numel()) * 4))
         xi = torch.randn(B, 128, 160, 512, device="cuda")
         yo = torch.empty(B, 64, 80, 512, device="cuda")
         us = timed(lambda: lib.vidc_maxpool3x3s2(xi.data_ptr(), yo.data_ptr(), B, 128, 160, 512, 512, 512, None, st))
