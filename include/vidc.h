@@ -80,7 +80,10 @@ enum vidc_conv_flags {
     VIDC_SPLIT_OUT = 64,   /* also write the split-bf16 image of the result to y_split (layout of y,
                               same channel stride) so a following bf16x3 conv needs no split pass */
     VIDC_NO_F32_OUT = 128, /* with SPLIT_OUT: skip the fp32 store (nobody reads it)              */
-    VIDC_STATS_OUT = 256   /* training, VIDC_PREC_BF16 only, groups == 1, no second affine / residual / accumulate / split output:
+    VIDC_X_PLANAR_GROUPS = 512, /* group g's input is a plane of its own (B*H*W rows of ldx values at x + g*x_gs) instead of a channel slice of
+                              rows shared by all groups: the grouped weight-gradient GEMMs of the training step (dY^T of the three pyramids) */
+    VIDC_STATS_OUT = 256   /* training, VIDC_PREC_BF16 only, no second affine / residual / accumulate / split output (with `groups` > 1 the rows of
+                              the partials hold groups * Cout doubles, group-major like the channels of y):
                               `y_split` points to ceil(M / 32) x 2 x Cout doubles and receives, per block of 32 output rows, the
                               per-channel sum and sum of squares of the fp32 result -- the partials vidc_bn_train_forward_stats
                               reduces, so the train-mode BatchNorm behind the conv needs no pass of its own over the tensor */

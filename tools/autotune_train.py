@@ -31,7 +31,7 @@ OUT = os.path.join(ROOT, "vi_depth_completion_amd", "train_tuning.json")
 def time_launches(lib, d, st, pool, junk, copies):
     """Average GPU time (us) of `copies` back-to-back launches of `d` in one captured graph; weights of small layers rotate through
     `pool` (cold per launch, as in a step where 1.2 GB of parameters are touched between two uses)."""
-    wbytes = d.Cout * d.KH * d.KW * d.Cin * 4
+    wbytes = d.groups * d.Cout * d.KH * d.KW * d.Cin * 4
     stride = (wbytes + 255) // 256 * 256
     rotate = pool is not None and 2 * stride <= pool.numel() * 4
     if rotate:
@@ -102,7 +102,7 @@ def main():
         d.flags &= ~L.ACCUM
         d.workspace = ws.data_ptr()
         M, units = d.B * d.Ho * d.Wo, d.KH * d.KW * d.Cin // 32
-        big_w = d.Cout * d.KH * d.KW * d.Cin * 4 > (32 << 20)
+        big_w = d.groups * d.Cout * d.KH * d.KW * d.Cin * 4 > (32 << 20)
         ent, line = [], []
         for prec in (0, 1):
             if prec not in precs or (prec == 1 and d0.precision == 0 and role == "gemm" and False):
@@ -120,11 +120,11 @@ def main():
             for t, (bm, bn) in TILE_DIMS.items():
                 if bn > max(64, d.Cout) or bm >= 4 * max(32, M):
                     continue
-                wgs = -(-M // bm) * -(-d.Cout // bn)
+                wgs = -(-M // bm) * -(-d.Cout // bn) * d.groups
                 for sk in (1, 2, 4, 8, 16, 32, 64):
                     if sk > 1 and (units // sk < 4 or wgs * (sk // 2) >= 2048):
                         continue
-                    if sk > 1 and L.SPLITK_COUNTERS + sk * M * d.Cout > ws.numel():
+                    if sk > 1 and L.SPLITK_COUNTERS + sk * d.groups * M * d.Cout > ws.numel():
                         continue
                     d.tile, d.splitk = t, sk
                     us = time_launches(lib, d, st, None if big_w else pool, junk, 6 if big_w else 16)
@@ -151,7 +151,7 @@ def main():
         d.flags &= ~L.ACCUM
         d.workspace = ws.data_ptr()
         M, units = d.B * d.Ho * d.Wo, d.KH * d.KW * d.Cin // 32
-        big_w = d.Cout * d.KH * d.KW * d.Cin * 4 > (32 << 20)
+        big_w = d.groups * d.Cout * d.KH * d.KW * d.Cin * 4 > (32 << 20)
         p = L.ConvDesc.from_buffer_copy(d)
         p.tile = 0
         lib.vidc_conv2d_plan(C.byref(p))
@@ -162,11 +162,11 @@ def main():
         for t, (bm, bn) in TILE_DIMS.items():
             if bn > max(64, d.Cout) or bm >= 4 * max(32, M):
                 continue
-            wgs = -(-M // bm) * -(-d.Cout // bn)
+            wgs = -(-M // bm) * -(-d.Cout // bn) * d.groups
             for sk in (1, 2, 4, 8, 16, 32, 64):
                 if sk > 1 and (units // sk < 4 or wgs * (sk // 2) >= 2048):
                     continue
-                if sk > 1 and L.SPLITK_COUNTERS + sk * M * d.Cout > ws.numel():
+                if sk > 1 and L.SPLITK_COUNTERS + sk * d.groups * M * d.Cout > ws.numel():
                     continue
                 d.tile, d.splitk = t, sk
                 us = time_launches(lib, d, st, None if big_w else pool, junk, 6 if big_w else 16)

@@ -18,7 +18,7 @@ MAX_STREAMS = 4
 MAX_SEGMENTS = 4
 
 # vidc_conv_flags / vidc_up_flags / vidc_op_kind / vidc_conv_tile
-RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM, SPLIT_OUT, NO_F32_OUT, STATS_OUT = 1, 2, 4, 8, 16, 32, 64, 128, 256
+RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM, SPLIT_OUT, NO_F32_OUT, STATS_OUT, X_PLANAR_GROUPS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 UP_RELU, UP_ACCUM, UP_NO_F32_OUT = 1, 2, 4
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPSAMPLE, OP_HEAD, OP_WARP_PARAMS, OP_WARP_FWD, OP_WARP_INV, OP_COPY, OP_SPLIT, OP_AVGPOOL, OP_NORMALIZE, OP_DET_IM2COL, OP_NEAREST2X, _OP_RETIRED_15, OP_MASK, OP_WINO_IN, OP_WINO_OUT = range(1, 19)
 TILE_AUTO = 0

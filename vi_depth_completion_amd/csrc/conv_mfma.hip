@@ -193,7 +193,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
     };
-    const int x_bytes = __builtin_amdgcn_readfirstlane((int)(((long long)a.B * a.H * a.W * a.ldx - g * a.x_gs) * 4));
+    // (VIDC_X_PLANAR_GROUPS: every group's input is a plane of its own with B*H*W rows of ldx values, x_gs apart -- the training step's grouped
+    //  weight-gradient GEMMs; else the groups are channel slices of shared rows and a later group sees fewer bytes behind its base)
+    const int x_bytes = __builtin_amdgcn_readfirstlane((int)(((long long)a.B * a.H * a.W * a.ldx - ((a.flags & VIDC_X_PLANAR_GROUPS) ? 0 : g * a.x_gs)) * 4));
     const int w_bytes = __builtin_amdgcn_readfirstlane((int)((long long)a.Cout * a.K * 4));
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.x + g * a.x_gs), 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.w + g * a.w_gs), 0, w_bytes, 0x00020000);
@@ -577,7 +579,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
     const bool aff2 = a.flags & VIDC_AFFINE2, has_res = a.flags & VIDC_RESIDUAL, accum = a.flags & VIDC_ACCUM;
     const bool st_f32 = !(a.flags & VIDC_NO_F32_OUT), st_split = a.flags & VIDC_SPLIT_OUT;
     unsigned short* ysp = st_split ? a.y_split + (size_t)g * a.y_gs * 2 : nullptr;
-    double* stats_out = (PREC == 2 && (a.flags & VIDC_STATS_OUT)) ? reinterpret_cast<double*>(a.y_split) : nullptr;   // (groups == 1, host-checked)
+    double* stats_out = (PREC == 2 && (a.flags & VIDC_STATS_OUT)) ? reinterpret_cast<double*>(a.y_split) : nullptr;
 #ifndef VIDC_CONV_TIMING
     // ---- split-K without a second launch: every k-slice workgroup stores its fp32 partial tile, takes a ticket on the tile's
     //      counter (head of the workspace; device-scope atomic), and the LAST one to arrive sums the splitk partials in slice
@@ -684,9 +686,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int g, const 
                         }
                         const double o0s = __shfl_xor(s0, 32), o1s = __shfl_xor(s1, 32);
                         if (lh == 0 && n < a.Cout && mb < a.M) {
-                            double* sp = stats_out + ((size_t)(mb >> 5) * 2) * (size_t)a.Cout + n;
+                            // rows of groups * Cout doubles: a grouped launch writes the partials of ONE BatchNorm over all groups' channels
+                            const size_t ctot = (size_t)a.groups * (size_t)a.Cout;
+                            double* sp = stats_out + ((size_t)(mb >> 5) * 2) * ctot + (size_t)g * a.Cout + n;
                             sp[0] = s0 + o0s;
-                            sp[a.Cout] = s1 + o1s;
+                            sp[ctot] = s1 + o1s;
                         }
                     }
                 }
@@ -905,9 +909,11 @@ int validate(const vidc_conv_desc* d) {
     VIDC_REQUIRE(!(d->flags & VIDC_SPLIT_OUT) || (d->y_split && d->Cout % 32 == 0 && d->ldy % 32 == 0), VIDC_ERR_NULL,
                  "conv: SPLIT_OUT needs y_split and Cout, ldy multiples of 32");
     VIDC_REQUIRE(!(d->flags & VIDC_NO_F32_OUT) || (d->flags & VIDC_SPLIT_OUT), VIDC_ERR_SHAPE, "conv: NO_F32_OUT without SPLIT_OUT writes nothing");
-    VIDC_REQUIRE(!(d->flags & VIDC_STATS_OUT) || (d->precision == VIDC_PREC_BF16 && d->y_split && d->groups == 1 &&
+    VIDC_REQUIRE(!(d->flags & VIDC_STATS_OUT) || (d->precision == VIDC_PREC_BF16 && d->y_split &&
                                                   !(d->flags & (VIDC_AFFINE2 | VIDC_RESIDUAL | VIDC_ACCUM | VIDC_SPLIT_OUT | VIDC_NO_F32_OUT))),
-                 VIDC_ERR_SHAPE, "conv: STATS_OUT needs VIDC_PREC_BF16, one group, y_split = the partials buffer and a plain epilogue");
+                 VIDC_ERR_SHAPE, "conv: STATS_OUT needs VIDC_PREC_BF16, y_split = the partials buffer and a plain epilogue");
+    VIDC_REQUIRE(!(d->flags & VIDC_X_PLANAR_GROUPS) || (long long)d->groups * d->x_gs * 4 < (1ll << 31), VIDC_ERR_SHAPE,
+                 "conv: X_PLANAR_GROUPS: the planes of all groups must stay below 2 GiB");
     VIDC_REQUIRE((long long)d->B * d->Ho * d->Wo < (1ll << 31), VIDC_ERR_SHAPE, "conv: M overflows int32");
     VIDC_REQUIRE((long long)d->Cout * d->KH * d->KW * d->Cin * 4 < (1ll << 31), VIDC_ERR_SHAPE,
                  "conv: one group's weights must stay below 2 GiB (32-bit buffer offsets)");

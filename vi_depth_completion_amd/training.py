@@ -33,6 +33,16 @@ from . import engine
 from .networks.fpn_decoder import _BRANCH_PLAN
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+PYRAMIDS = ("resnet_rgb", "resnet_normal", "resnet_depth")      # the three ResNet-101 pyramids of ModifiedFPN (depth_completion.py:75-77)
+
+
+def _keys(key):
+    """A parameter-name prefix, or one per group of a grouped launch (the same layer of the three pyramids)."""
+    return (key,) if isinstance(key, str) else tuple(key)
+
+
+def _cat(p, suffix):
+    return tuple(q + suffix for q in _keys(p)) if not isinstance(p, str) else p + suffix
 
 
 class Act:
@@ -152,6 +162,34 @@ class DepthCompletionTrainer:
         self.cnn = cnn
         self.lr, self.betas, self.eps = float(learning_rate), betas, float(eps)
         self.named = [(k, p) for k, p in cnn.named_parameters()]
+        # Grouped pyramids (round 5, VIDC_TRAIN_GROUPED=0 switches back to one launch chain per pyramid): the same layer of the three
+        # pyramids runs as ONE launch with three groups -- forward conv, data gradient, weight-gradient GEMM -- and ONE BatchNorm launch over
+        # the 3 x C channels of the grouped tensor, as the inference frame program has always done.  A group selects base pointers only, so
+        # the three layers' parameters (and gradients, Adam moments, BatchNorm running statistics) are laid out next to each other in the
+        # flat buffers: [rgb | normal | depth] per parameter name.  Values, gradients and the all-reduced sums are what they were.
+        # (the grouped weight-gradient GEMM writes the three .grad tensors in place; the A/B switch VIDC_TRAIN_WGRAD_INPLACE=0 -- staging
+        #  buffer + permute, tap-major operand rows -- therefore runs the per-pyramid chains)
+        # Default ("auto"): grouped + ONE stream when the step runs across ranks, three per-pyramid stream lanes on a single rank.  Measured
+        # (MI355X, batch 8, bf16, profiles/r5_train_grouped_ab.txt): grouped = 1252 launches / 27.8 ms of kernel time per step instead of
+        # 3258 / 42.0 ms, but as ONE dependency chain (27.3-27.5 ms per step) against 25.9 ms for the three lanes, whose launch latencies
+        # hide under each other -- on this runtime kernels of different streams fill each other's gaps, they do not add throughput.
+        # Across ranks the step is cut into two graphs around the decoder's all-reduce, and there the three-lane form falls into the
+        # runtime's slow regime above 4 hardware queues (50.4 against 27.4 ms at GPU_MAX_HW_QUEUES=8) while the single-stream grouped chain
+        # does not care (27.8 / 28.4 ms at 4 / 8 queues): the multi-rank default must not depend on a queue count nobody controls.
+        mode = os.environ.get("VIDC_TRAIN_GROUPED", "auto")
+        want = self._distributed() if mode == "auto" else mode == "1"
+        self.grouped = (want and os.environ.get("VIDC_TRAIN_WGRAD_INPLACE", "1") == "1" and all(hasattr(cnn, pn) for pn in PYRAMIDS))
+        if self.grouped:
+            by_name = dict(self.named)
+            first = PYRAMIDS[0] + "."
+            inter = []
+            for k, _p in self.named:
+                if k.startswith(first):
+                    for pn in PYRAMIDS:
+                        kk = pn + "." + k[len(first):]
+                        inter.append((kk, by_name[kk]))
+            seen = {k for k, _ in inter}
+            self.named = inter + [(k, q) for k, q in self.named if k not in seen]
         dev = self.named[0][1].device
         if dev.type != "cuda":
             raise RuntimeError("move the network to the GPU before building the trainer")
@@ -171,6 +209,19 @@ class DepthCompletionTrainer:
             self.param[k], self.grad[k] = p.data, p.grad
             o += k_n
         self.buf = {k: b for k, b in cnn.named_buffers()}
+        if self.grouped:      # BatchNorm running statistics of the three pyramids: the same interleaved order, in a flat buffer of their own
+            first = PYRAMIDS[0] + "."
+            fl = [k for k in self.buf if k.startswith(first) and self.buf[k].dtype == torch.float32]
+            tot = sum(self.buf[k].numel() for k in fl) * len(PYRAMIDS)
+            self.flat_b = torch.empty(tot, dtype=torch.float32, device=dev)
+            o = 0
+            for k in fl:
+                for pn in PYRAMIDS:
+                    b = self.buf[pn + "." + k[len(first):]]
+                    self.flat_b[o:o + b.numel()].copy_(b.detach().reshape(-1))
+                    b.data = self.flat_b[o:o + b.numel()].view(b.shape)
+                    o += b.numel()
+        self._adjacent = {}
         self.buckets = GradientBuckets(n, compress=("bf16" if os.environ.get("VIDC_TRAIN_GRAD_BF16", "0") == "1" else None))
         # the decoder's parameters (feature*_upsamping, feature_concat) form the tail of the flat buffers (named_parameters order): their
         # gradients are complete when the decoder's backward is, long before the pyramids' -- they are all-reduced while those still run
@@ -182,7 +233,7 @@ class DepthCompletionTrainer:
         self._gemm_ws = {}          # split-K workspace per stream lane (lane 0 = the caller's stream)
         self._cur = 0               # stream lane the ops being recorded / replayed run on (0 = main, 1..3 = the three pyramids, 1..4 = the decoder branches)
         self._lanes = None
-        self.n_lanes = int(os.environ.get("VIDC_TRAIN_STREAMS", "3"))
+        self.n_lanes = int(os.environ.get("VIDC_TRAIN_STREAMS", "1" if self.grouped else "3"))      # (grouped: the decoder's four branches stay on the caller's stream too)
         self._pack_items, self._pack_table, self._packed_fresh = [], None, False
         self.use_graph = os.environ.get("VIDC_TRAIN_GRAPH", "1") != "0"
         self._graphs, self._graph_seen = {}, {}
@@ -244,7 +295,7 @@ class DepthCompletionTrainer:
     def _beside(self, fn):
         """Runs `fn` (launches that nothing on the current lane waits for before the end of the backward) on the lane's side stream, with
         its own scratch / split-K workspace key; `_join_wgrad` makes the main stream wait for all of them."""
-        if not (self.wgrad_side and self.n_lanes > 1):
+        if not self.wgrad_side:
             fn()
             return
         lane = self._cur
@@ -280,19 +331,21 @@ class DepthCompletionTrainer:
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
     # ---- conv: forward, dgrad, wgrad --------------------------------------------------------------------------------------------
-    def _conv_call(self, x_t, w_packed, shift, y_t, kh, kw, stride, pad, relu, accumulate, x_bf=None, stats=None):
+    def _conv_call(self, x_t, w_packed, shift, y_t, kh, kw, stride, pad, relu, accumulate, x_bf=None, stats=None, groups=1):
         """One launch of the inference conv kernel.  In bf16x3 mode the activations are split here (one extra pass over x); `w_packed`
-        must already be in the matching format (`_pack`)."""
+        must already be in the matching format (`_pack`).  groups = G > 1: x_t / y_t hold G groups as channel slices ([.., G*cin] /
+        [.., G*cout]), w_packed the G packed weights back to back; `shift` ([cout]) is shared by the groups."""
         B, H, W, cin = x_t.shape
         _, Ho, Wo, cout = y_t.shape
+        G = groups
         ldx = _ld(x_t)
         if self.precision == L.PREC_BF16X3:
             xs = self._empty(B, H, W, cin)
             L.check(L.lib().vidc_split_bf16x3(L.ptr(x_t), L.ptr(xs), B * H * W, cin, ldx, L.current_stream()), "split")
             x_t, ldx = xs, cin
         elif self.precision == L.PREC_BF16:      # plain bf16 rows; the descriptor counts two channels per element (include/vidc.h)
-            if cin % 64:
-                raise RuntimeError("bf16 training needs conv input channels in multiples of 64 (got %d)" % cin)
+            if (cin // G) % 64:
+                raise RuntimeError("bf16 training needs conv input channels in multiples of 64 (got %d)" % (cin // G))
             xs = x_bf                             # the producer wrote the bf16 copy already (bn / bn backward)
             if xs is not None and tuple(xs.shape) != (B, H, W, cin // 2):
                 raise RuntimeError("bf16 operand copy of shape %s for an activation of shape %s" % (tuple(xs.shape), (B, H, W, cin)))
@@ -301,6 +354,7 @@ class DepthCompletionTrainer:
                 L.check(L.lib().vidc_cast_bf16(L.ptr(x_t), L.ptr(xs), B * H * W, cin, ldx, L.current_stream()), "cast")
             x_t, cin = xs, cin // 2
             ldx = cin
+        cin, cout = cin // G, cout // G           # per group (cin in the descriptor's units: two bf16 channels per element in the bf16 mode)
         d = L.ConvDesc()
         d.x, d.w, d.y = L.ptr(x_t), L.ptr(w_packed), L.ptr(y_t)
         d.scale1, d.shift1 = L.ptr(self._const(self._ones, cout, 1.0)), L.ptr(shift)
@@ -311,8 +365,8 @@ class DepthCompletionTrainer:
         if stats is not None:                 # (the descriptor's y_split field carries the partials buffer: include/vidc.h VIDC_STATS_OUT)
             d.flags |= L.STATS_OUT
             d.y_split = L.ptr(stats)
-        d.groups, d.splitk, d.precision, d.tile = 1, 1, self.precision, 0
-        d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, cout * kh * kw * cin, cout, cout
+        d.groups, d.splitk, d.precision, d.tile = G, 1, self.precision, 0
+        d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, cout * kh * kw * cin, cout, (cout if G == 1 else 0)
         self._plan(d, "conv")
         L.check(L.lib().vidc_conv2d_bn_act(C.byref(d), L.current_stream()), "conv")
 
@@ -321,10 +375,11 @@ class DepthCompletionTrainer:
         [tile, splitk] per arithmetic mode), else the planner's cost model.  Split-K partial sums go through one persistent workspace
         (ticket counters at its head, zeroed once; the last workgroup of a tile resets its ticket)."""
         lib = L.lib()
-        if self.tune_hook is not None:
-            self.tune_hook(d, role)
+        fixed = self.tune_hook(d, role) if self.tune_hook is not None else None      # (a hook that returns True has set tile / splitk itself)
         ent = training_table().get(engine.conv_signature(d))
-        if ent is not None and len(ent) > 2 * d.precision + 1 and ent[2 * d.precision]:
+        if fixed:
+            pass
+        elif ent is not None and len(ent) > 2 * d.precision + 1 and ent[2 * d.precision]:
             d.tile, d.splitk = ent[2 * d.precision], ent[2 * d.precision + 1]
         else:
             L.check(lib.vidc_conv2d_plan(C.byref(d)), "conv plan")
@@ -342,16 +397,24 @@ class DepthCompletionTrainer:
         """Packed weights of conv `key` for the forward ('f') or the dgrad ('d': kernel flipped, channels transposed) launch, in the
         trainer's arithmetic mode.  The parameters move every step: `repack()` rebuilds every packed copy with one launch at the start of
         a forward; a conv met for the first time is packed here and joins the table."""
-        ent = self._packed.get((key, kind))
+        keys = _keys(key)                      # (a tuple: the G packed copies back to back, what a grouped launch reads as w + g * w_gs)
+        ent = self._packed.get((keys, kind))
         if ent is not None and self._packed_fresh:
-            return ent
+            return ent[0]
         co, ci, kh, kw = w.shape
         if ent is None:
-            ent = self._packed[(key, kind)] = self._empty(co * ci * kh * kw // (2 if self.precision == L.PREC_BF16 else 1))
-            self._pack_items.append((w, ent, co, ci, kh, kw, (1 if kind == "d" else 0) | {L.PREC_FP32: 0, L.PREC_BF16X3: 2, L.PREC_BF16: 4}[self.precision]))
+            n1 = co * ci * kh * kw // (2 if self.precision == L.PREC_BF16 else 1)
+            buf = self._empty(n1 * len(keys))
+            mine = []
+            for g, k in enumerate(keys):
+                wk = self.param[k + ".weight"] if len(keys) > 1 else w
+                assert tuple(wk.shape) == (co, ci, kh, kw), k
+                mine.append((wk, buf[g * n1:(g + 1) * n1], co, ci, kh, kw, (1 if kind == "d" else 0) | {L.PREC_FP32: 0, L.PREC_BF16X3: 2, L.PREC_BF16: 4}[self.precision]))
+            self._pack_items += mine
+            ent = self._packed[(keys, kind)] = (buf, mine)
             self._pack_table = None
-        self._launch_pack([it for it in self._pack_items if it[1] is ent])
-        return ent
+        self._launch_pack(ent[1])
+        return ent[0]
 
     def _launch_pack(self, items):
         table = (L.PackItem * len(items))()
@@ -377,7 +440,21 @@ class DepthCompletionTrainer:
                 L.check(L.lib().vidc_pack_conv_weights_batched(L.ptr(dev), n, blocks, L.current_stream()), "pack")
         self._packed_fresh = True
 
-    def _wgrad_fits(self, geom):
+    def _adjacent_base(self, store, keys, suffix):
+        """The G tensors `store[k + suffix]` of a grouped layer as ONE contiguous run (group g at base + g * numel): the first one's
+        tensor after a check, once per layer, that the flat layout really put them next to each other."""
+        t0 = store[keys[0] + suffix]
+        if len(keys) > 1:
+            ck = (id(store), keys, suffix)
+            if ck not in self._adjacent:
+                for g, k in enumerate(keys):
+                    t = store[k + suffix]
+                    if t.shape != t0.shape or t.data_ptr() != t0.data_ptr() + 4 * g * t0.numel():
+                        raise RuntimeError("grouped training: %s%s of the pyramids are not adjacent in the flat buffers" % (k, suffix))
+                self._adjacent[ck] = True
+        return t0
+
+    def _wgrad_fits(self, geom, G=1):
         """Whether `_wgrad_gemm` takes this shape (else the direct pixel-reduction kernel runs, which reads the fp32 dY)."""
         B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad = geom
         if os.environ.get("VIDC_WGRAD", "gemm") != "gemm":
@@ -386,7 +463,7 @@ class DepthCompletionTrainer:
         bf16 = self.precision == L.PREC_BF16
         Mp = (M + 63) // 64 * 64 if bf16 else (M + 31) // 32 * 32
         e = 2 if bf16 else 1
-        return not (taps * ci * Mp * 4 // e >= (1 << 31) or co * Mp // e >= (1 << 29) or ci % 32 or co % 4)
+        return not (taps * ci * Mp * 4 // e >= (1 << 31) or G * co * Mp // e >= (1 << 29) or ci % 32 or co % 4)
 
     def _wgrad_gemm(self, g, x, key, geom, g_t=None):
         """dW through the conv kernel: dW[co][ci][tap] = sum over pixels of dY^T[co][m] * Xt[ci*taps + tap][m] is the 1x1 case of
@@ -394,46 +471,49 @@ class DepthCompletionTrainer:
         -- LDS-tiled, split-K, at several times the rate of the direct pixel-reduction kernel (vidc_conv_wgrad, kept for shapes beyond the
         32-bit limits of the conv kernel) -- and its output is the parameter's .grad in place.  g_t: dY^T if the BatchNorm backward has
         written it already.  Returns False when the shape does not fit."""
-        B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad = geom
-        if not self._wgrad_fits(geom):
+        B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad = geom          # ci, co: per group
+        keys = _keys(key)
+        G = len(keys)
+        if not self._wgrad_fits(geom, G) or (G > 1 and not self.wgrad_inplace):
             return False
         lib, st = L.lib(), L.current_stream()
         taps, M = kh * kw, B * Ho * Wo
         bf16 = self.precision == L.PREC_BF16
         Mp = (M + 63) // 64 * 64 if bf16 else (M + 31) // 32 * 32
         e = 2 if bf16 else 1                     # pixels per 4-byte element of an operand row
-        xt = self._empty(taps * ci, Mp // e)
+        # grouped: the rows of both operands are channel-major over ALL groups' channels, i.e. group g's rows are a contiguous run
+        xt = self._empty(G * taps * ci, Mp // e)
         split = {L.PREC_FP32: 0, L.PREC_BF16X3: 1, L.PREC_BF16: 2}[self.precision]      # operands written in the GEMM's format directly
-        if g_t is not None and bf16 and g_t[1] == Mp and g_t[0].numel() == co * Mp // e:
+        if g_t is not None and bf16 and g_t[1] == Mp and g_t[0].numel() == G * co * Mp // e:
             gt = g_t[0]                           # written by the BatchNorm backward that produced g (vidc_bn_train_backward_t)
         else:
             if g is None:
-                raise RuntimeError("wgrad %s: neither dY nor a matching dY^T" % key)
-            gt = self._empty(co, Mp // e)
-            L.check(lib.vidc_im2col_transposed(L.ptr(g), L.ptr(gt), B, Ho, Wo, co, _ld(g), Ho, Wo, 1, 1, 1, 0, Mp, split, st), "transpose dY")
+                raise RuntimeError("wgrad %s: neither dY nor a matching dY^T" % (key,))
+            gt = self._empty(G * co, Mp // e)
+            L.check(lib.vidc_im2col_transposed(L.ptr(g), L.ptr(gt), B, Ho, Wo, G * co, _ld(g), Ho, Wo, 1, 1, 1, 0, Mp, split, st), "transpose dY")
         # rows of Xt in channel-major order (split + 4): the GEMM's output [co][ci*taps + tap] IS the OIHW weight gradient, written in place
         # (no staging buffer, no permute / copy launch)
         inplace = self.wgrad_inplace            # False: tap-major rows, staging buffer, permute / copy (A/B, tests)
         if bf16 and taps == 1 and stride == 1 and pad == 0 and x.bf is not None and self.xt_from_bf16:
             # 1x1 / stride 1: Xt is the plain transpose of x, taken from the bf16 operand copy the forward conv read (half the bytes, same bits)
-            L.check(lib.vidc_transpose_bf16(L.ptr(x.bf), L.ptr(xt), M, ci, Mp, st), "transpose x (bf16)")
-        elif bf16 and inplace and x.bf is not None and self.xt_from_bf16 and B * H * W * ci < (1 << 31):
+            L.check(lib.vidc_transpose_bf16(L.ptr(x.bf), L.ptr(xt), M, G * ci, Mp, st), "transpose x (bf16)")
+        elif bf16 and inplace and x.bf is not None and self.xt_from_bf16 and B * H * W * G * ci < (1 << 31):
             # any other geometry: the transposed im2col gathered from the bf16 copy as well (half the input bytes of the fp32 source)
-            L.check(lib.vidc_im2col_transposed_bf16(L.ptr(x.bf), L.ptr(xt), B, H, W, ci, Ho, Wo, kh, kw, stride, pad, Mp, st), "im2col^T (bf16)")
+            L.check(lib.vidc_im2col_transposed_bf16(L.ptr(x.bf), L.ptr(xt), B, H, W, G * ci, Ho, Wo, kh, kw, stride, pad, Mp, st), "im2col^T (bf16)")
         else:
-            L.check(lib.vidc_im2col_transposed(L.ptr(x.t), L.ptr(xt), B, H, W, ci, x.ld, Ho, Wo, kh, kw, stride, pad, Mp, split | (4 if inplace else 0), st), "im2col^T")
+            L.check(lib.vidc_im2col_transposed(L.ptr(x.t), L.ptr(xt), B, H, W, G * ci, x.ld, Ho, Wo, kh, kw, stride, pad, Mp, split | (4 if inplace else 0), st), "im2col^T")
         Mp //= e
         n_out = taps * ci
-        gw = self.grad[key + ".weight"]
+        gw = self._adjacent_base(self.grad, keys, ".weight")      # grouped: the G gradients are one contiguous run, group g at + g * co * n_out
         tmp = gw if inplace else self._empty(co, n_out)
         d = L.ConvDesc()
         d.x, d.w, d.y = L.ptr(gt), L.ptr(xt), L.ptr(tmp)
         d.scale1, d.shift1 = L.ptr(self._const(self._ones, n_out, 1.0)), L.ptr(self._const(self._zeros, n_out, 0.0))
         d.B, d.H, d.W, d.Cin, d.ldx = 1, 1, co, Mp, Mp
         d.Ho, d.Wo, d.Cout, d.ldy = 1, co, n_out, n_out
-        d.KH, d.KW, d.stride, d.pad, d.flags = 1, 1, 1, 0, 0
-        d.groups, d.splitk, d.precision, d.tile = 1, 1, self.precision, 0
-        d.x_gs, d.w_gs, d.y_gs, d.p_gs = Mp, n_out * Mp, n_out, n_out
+        d.KH, d.KW, d.stride, d.pad, d.flags = 1, 1, 1, 0, (L.X_PLANAR_GROUPS if G > 1 else 0)
+        d.groups, d.splitk, d.precision, d.tile = G, 1, self.precision, 0
+        d.x_gs, d.w_gs, d.y_gs, d.p_gs = (co * Mp if G > 1 else Mp), n_out * Mp, (co * n_out if G > 1 else n_out), (0 if G > 1 else n_out)
         self._plan(d, "gemm")
         L.check(lib.vidc_conv2d_bn_act(C.byref(d), st), "wgrad gemm")
         if not inplace:
@@ -445,25 +525,32 @@ class DepthCompletionTrainer:
 
     def conv(self, x, key, stride=1, pad=0, relu=False, out=None):
         """nn.Conv2d (+ReLU when no BatchNorm sits in between, depth_completion.py:141-142).  Records its backward."""
-        w = self.param[key + ".weight"]
-        bias = self.param.get(key + ".bias")
+        keys = _keys(key)                        # G > 1: the same layer of the three pyramids as one grouped launch (x, y: G channel slices)
+        G = len(keys)
+        w = self.param[keys[0] + ".weight"]
+        bias = self.param.get(keys[0] + ".bias")
+        if G > 1 and bias is not None:
+            raise RuntimeError("grouped conv %s: a bias per group is not supported (the pyramids' convs have none)" % (keys,))
         co, ci, kh, kw = w.shape
-        B, H, W, _ = x.t.shape
+        B, H, W, cx = x.t.shape
+        if cx != G * ci:
+            raise RuntimeError("conv %s: input has %d channels, expected %d x %d" % (keys[0], cx, G, ci))
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
         wp = self._pack(key, "f", w)
         if self.precision == L.PREC_BF16 and x.bf is None and ci % 64 == 0:      # the bf16 operand copy, made once per activation: every conv that
-            x.bf = self._empty(B, H, W, ci // 2)                                   # reads x uses it, and so does the weight-gradient transpose
-            L.check(L.lib().vidc_cast_bf16(L.ptr(x.t), L.ptr(x.bf), B * H * W, ci, x.ld, L.current_stream()), "cast")
-        y = Act(out if out is not None else self._empty(B, Ho, Wo, co))
+            x.bf = self._empty(B, H, W, G * ci // 2)                               # reads x uses it, and so does the weight-gradient transpose
+            L.check(L.lib().vidc_cast_bf16(L.ptr(x.t), L.ptr(x.bf), B * H * W, G * ci, x.ld, L.current_stream()), "cast")
+        y = Act(out if out is not None else self._empty(B, Ho, Wo, G * co))
         y.conv_out = not relu and self.dyt_fused
         # stride 1, no bias, bf16 operands, GEMM weight gradient: this conv's backward reads dY only as bf16 rows (dgrad) and as dY^T (wgrad)
         y.no_f32_grad = (y.conv_out and self.skip_f32_dy and self.precision == L.PREC_BF16 and stride == 1 and bias is None and co % 64 == 0 and
-                         B * Ho * Wo < (1 << 31) and self._wgrad_fits((B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad)))
+                         B * Ho * Wo < (1 << 31) and self._wgrad_fits((B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad), G) and (G == 1 or self.wgrad_inplace))
         # (VIDC_TRAIN_CONV_STATS_MAX_M bounds the output rows it is used for: one partial per 32 rows makes the final reduction of a large
         #  map long -- 4800 partials at M = 153 600 -- but limiting it to 16 384 or 3 000 rows measured the same step time within 0.2 ms)
         if self.conv_stats and self.precision == L.PREC_BF16 and not relu and out is None and co % 32 == 0 and B * Ho * Wo <= self.conv_stats_max_m:
-            y.stats = torch.empty(((B * Ho * Wo + 31) // 32) * 2 * co, dtype=torch.float64, device=self.device)
-        self._conv_call(x.t, wp, bias if bias is not None else self._const(self._zeros, co, 0.0), y.t, kh, kw, stride, pad, relu, False, x_bf=x.bf, stats=y.stats)
+            y.stats = torch.empty(((B * Ho * Wo + 31) // 32) * 2 * G * co, dtype=torch.float64, device=self.device)
+        self._conv_call(x.t, wp, bias if bias is not None else self._const(self._zeros, co, 0.0), y.t, kh, kw, stride, pad, relu, False, x_bf=x.bf, stats=y.stats,
+                        groups=G)
 
         def backward():
             g, g_bf, g_t = y.grad, y.grad_bf, y.grad_t
@@ -473,21 +560,24 @@ class DepthCompletionTrainer:
                 # read a stand-in tensor as if it were the gradient
                 Mp_ = (B * Ho * Wo + 63) // 64 * 64
                 if not (y.no_f32_grad and not relu and g_bf is not None and g_t is not None and self.precision == L.PREC_BF16 and
-                        g_t[1] == Mp_ and g_t[0].numel() == co * Mp_ // 2):
-                    raise RuntimeError("conv %s: no fp32 gradient and no matching bf16 forms of it (no_f32_grad invariant broken)" % key)
+                        g_t[1] == Mp_ and g_t[0].numel() == G * co * Mp_ // 2):
+                    raise RuntimeError("conv %s: no fp32 gradient and no matching bf16 forms of it (no_f32_grad invariant broken)" % (key,))
             if relu:                                         # y = relu(conv): mask first
-                gm = self._empty(B, Ho, Wo, co)
-                L.check(L.lib().vidc_relu_backward(L.ptr(g), L.ptr(y.t), L.ptr(gm), y.rows, co, _ld(g), y.ld, co, 0, L.current_stream()), "relu_bwd")
+                gm = self._empty(B, Ho, Wo, G * co)
+                L.check(L.lib().vidc_relu_backward(L.ptr(g), L.ptr(y.t), L.ptr(gm), y.rows, G * co, _ld(g), y.ld, G * co, 0, L.current_stream()), "relu_bwd")
                 g, g_bf, g_t = gm, None, None
             lib = L.lib()
 
             def weight_and_bias_gradient(g=g, g_t=g_t):     # (column sums for the bias); on the lane's side stream: see __init__
                 if not self._wgrad_gemm(g, x, key, (B, H, W, ci, Ho, Wo, co, kh, kw, stride, pad), g_t=g_t):
-                    sc = self._scratch_bytes(lib.vidc_conv_wgrad_scratch_bytes(B, Ho, Wo, co, ci, kh, kw))
-                    L.check(lib.vidc_conv_wgrad(L.ptr(g), L.ptr(x.t), L.ptr(self.grad[key + ".weight"]), B, H, W, ci, x.ld, Ho, Wo, co, _ld(g), kh, kw, stride,
-                                                pad, L.ptr(sc), L.current_stream()), "wgrad")
+                    if g is None:
+                        raise RuntimeError("wgrad %s: the direct kernel needs the fp32 dY" % (key,))
+                    for gi, k in enumerate(keys):                # (shapes beyond the GEMM's 32-bit limits: the direct kernel, group by group)
+                        sc = self._scratch_bytes(lib.vidc_conv_wgrad_scratch_bytes(B, Ho, Wo, co, ci, kh, kw))
+                        L.check(lib.vidc_conv_wgrad(L.ptr(g[..., gi * co:(gi + 1) * co]), L.ptr(x.t[..., gi * ci:(gi + 1) * ci]), L.ptr(self.grad[k + ".weight"]), B, H, W,
+                                                    ci, x.ld, Ho, Wo, co, _ld(g), kh, kw, stride, pad, L.ptr(sc), L.current_stream()), "wgrad")
                 if bias is not None:
-                    L.check(lib.vidc_colsum(L.ptr(g), y.rows, co, _ld(g), L.ptr(self.grad[key + ".bias"]), L.ptr(self._train_scratch(y.rows, co)),
+                    L.check(lib.vidc_colsum(L.ptr(g), y.rows, co, _ld(g), L.ptr(self.grad[keys[0] + ".bias"]), L.ptr(self._train_scratch(y.rows, co)),
                                             L.current_stream()), "colsum")
 
             self._beside(weight_and_bias_gradient)
@@ -497,15 +587,16 @@ class DepthCompletionTrainer:
             wd = self._pack(key, "d", w)
             gz = g
             if stride > 1:
-                gz, g_bf = self._empty(B, H, W, co), None
-                L.check(lib.vidc_zero_stuff(L.ptr(g), L.ptr(gz), B, Ho, Wo, co, _ld(g), stride, H, W, L.current_stream()), "zero_stuff")
+                gz, g_bf = self._empty(B, H, W, G * co), None
+                L.check(lib.vidc_zero_stuff(L.ptr(g), L.ptr(gz), B, Ho, Wo, G * co, _ld(g), stride, H, W, L.current_stream()), "zero_stuff")
             acc = x.grad is not None
             if not acc:
-                x.grad = self._empty(B, H, W, ci)
+                x.grad = self._empty(B, H, W, G * ci)
             if acc:
                 x.grad_bf = x.grad_t = None                  # x.grad changes below
             # (gz None: the BatchNorm backward wrote dY as bf16 only -- y.t stands in for its geometry, the kernel reads g_bf)
-            self._conv_call(gz if gz is not None else y.t, wd, self._const(self._zeros, ci, 0.0), x.grad, kh, kw, 1, kh - 1 - pad, False, acc, x_bf=g_bf)
+            self._conv_call(gz if gz is not None else y.t, wd, self._const(self._zeros, ci, 0.0), x.grad, kh, kw, 1, kh - 1 - pad, False, acc, x_bf=g_bf,
+                            groups=G)
 
         self._record(backward)
         return y
@@ -515,26 +606,31 @@ class DepthCompletionTrainer:
         """BatchNorm2d in train mode (+ReLU).  residual: the Bottleneck tail in the same pass, y = relu?(bn(x) + residual) -- the value and
         the backward are those of bn(x, relu=False) followed by add(., residual, relu); the add's launch and its pass over the map go."""
         Cc = x.t.shape[-1]
-        y = Act(out if out is not None else torch.empty_like(x.t))
+        keys = _keys(key)            # G > 1: ONE BatchNorm launch over the G x C channels of a grouped tensor; the G parameter / gradient /
+        y = Act(out if out is not None else torch.empty_like(x.t))      # running-statistics vectors are contiguous runs of the flat buffers
         mean, rstd = self._empty(Cc), self._empty(Cc)
-        gamma, beta = self.param[key + ".weight"], self.param[key + ".bias"]
+        gamma, beta = self._adjacent_base(self.param, keys, ".weight"), self._adjacent_base(self.param, keys, ".bias")
+        if gamma.numel() * len(keys) != Cc:
+            raise RuntimeError("bn %s: %d channels for %d x %d parameters" % (keys[0], Cc, len(keys), gamma.numel()))
+        run_mean, run_var = self._adjacent_base(self.buf, keys, ".running_mean"), self._adjacent_base(self.buf, keys, ".running_var")
+        g_gamma, g_beta = self._adjacent_base(self.grad, keys, ".weight"), self._adjacent_base(self.grad, keys, ".bias")
         bf16 = self.precision == L.PREC_BF16 and Cc % 64 == 0
         if bf16:
             y.bf = self._empty(*x.t.shape[:-1], Cc // 2)
         if x.stats is not None and x.stats.numel() == ((x.rows + 31) // 32) * 2 * Cc and x.ld == Cc:
             # x is a conv's output and the conv's epilogue has written its channel sums: final reduction + apply pass only
-            L.check(L.lib().vidc_bn_train_forward_stats(L.ptr(x.t), L.ptr(y.t), x.rows, Cc, x.ld, y.ld, L.ptr(gamma), L.ptr(beta), L.ptr(self.buf[key + ".running_mean"]),
-                                                        L.ptr(self.buf[key + ".running_var"]), BN_EPS, BN_MOMENTUM, int(relu), L.ptr(mean), L.ptr(rstd),
+            L.check(L.lib().vidc_bn_train_forward_stats(L.ptr(x.t), L.ptr(y.t), x.rows, Cc, x.ld, y.ld, L.ptr(gamma), L.ptr(beta), L.ptr(run_mean),
+                                                        L.ptr(run_var), BN_EPS, BN_MOMENTUM, int(relu), L.ptr(mean), L.ptr(rstd),
                                                         L.ptr(y.bf) if y.bf is not None else None, L.ptr(residual.t) if residual is not None else None,
                                                         residual.ld if residual is not None else 0, L.ptr(x.stats), L.ptr(self._train_scratch(x.rows, Cc)),
                                                         L.current_stream()), "bn_forward (conv stats)")
             x.stats = None                    # (consumed; the buffer goes back to the allocator with the activation's other temporaries)
         else:
-            L.check(L.lib().vidc_bn_train_forward_add(L.ptr(x.t), L.ptr(y.t), x.rows, Cc, x.ld, y.ld, L.ptr(gamma), L.ptr(beta), L.ptr(self.buf[key + ".running_mean"]),
-                                                      L.ptr(self.buf[key + ".running_var"]), BN_EPS, BN_MOMENTUM, int(relu), L.ptr(mean), L.ptr(rstd),
+            L.check(L.lib().vidc_bn_train_forward_add(L.ptr(x.t), L.ptr(y.t), x.rows, Cc, x.ld, y.ld, L.ptr(gamma), L.ptr(beta), L.ptr(run_mean),
+                                                      L.ptr(run_var), BN_EPS, BN_MOMENTUM, int(relu), L.ptr(mean), L.ptr(rstd),
                                                       L.ptr(y.bf) if y.bf is not None else None, L.ptr(residual.t) if residual is not None else None,
                                                       residual.ld if residual is not None else 0, L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_forward")
-        self._nbt.append(self.buf[key + ".num_batches_tracked"])
+        self._nbt += [self.buf[k + ".num_batches_tracked"] for k in keys]
         y_in = y               # what the BatchNorm part of the backward takes dy from
         if residual is not None:
             y_in = Act(y.t)    # (geometry only: its .grad is the masked gradient handed on by the add part)
@@ -564,7 +660,7 @@ class DepthCompletionTrainer:
             tbt = self._empty(Cc, Mp // 2) if (tbf is not None and x.conv_out and x.rows < (1 << 31)) else None
             L.check(L.lib().vidc_bn_train_backward_t(L.ptr(y_in.grad), L.ptr(x.t), L.ptr(y.t) if mask_relu else None, L.ptr(target) if target is not None else None,
                                                      x.rows, Cc, _ld(y_in.grad), x.ld, y.ld,
-                                                     Cc, L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(self.grad[key + ".weight"]), L.ptr(self.grad[key + ".bias"]),
+                                                     Cc, L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(g_gamma), L.ptr(g_beta),
                                                      L.ptr(tbf) if tbf is not None else None, L.ptr(tbt) if tbt is not None else None, Mp,
                                                      L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_backward")
             if acc:
@@ -658,30 +754,55 @@ class DepthCompletionTrainer:
         return y
 
     def _bottleneck(self, x, p, stride, project, out=None):
-        t = self.bn(self.conv(x, p + "conv1"), p + "bn1", True)
-        t = self.bn(self.conv(t, p + "conv2", stride, 1), p + "bn2", True)
+        """p: the block's parameter prefix, or one prefix per pyramid (grouped: x and the result hold the pyramids as channel slices)."""
+        t = self.bn(self.conv(x, _cat(p, "conv1")), _cat(p, "bn1"), True)
+        t = self.bn(self.conv(t, _cat(p, "conv2"), stride, 1), _cat(p, "bn2"), True)
         if not self.bn_add_fused:
-            t = self.bn(self.conv(t, p + "conv3"), p + "bn3", False)
-            idn = self.bn(self.conv(x, p + "downsample.0", stride, 0), p + "downsample.1", False) if project else x
+            t = self.bn(self.conv(t, _cat(p, "conv3")), _cat(p, "bn3"), False)
+            idn = self.bn(self.conv(x, _cat(p, "downsample.0"), stride, 0), _cat(p, "downsample.1"), False) if project else x
             return self.add(t, idn, True, out=out)
-        t = self.conv(t, p + "conv3")
-        idn = self.bn(self.conv(x, p + "downsample.0", stride, 0), p + "downsample.1", False) if project else x
-        return self.bn(t, p + "bn3", True, out=out, residual=idn)      # relu(bn3(.) + identity) in the BatchNorm's apply pass
+        t = self.conv(t, _cat(p, "conv3"))
+        idn = self.bn(self.conv(x, _cat(p, "downsample.0"), stride, 0), _cat(p, "downsample.1"), False) if project else x
+        return self.bn(t, _cat(p, "bn3"), True, out=out, residual=idn)      # relu(bn3(.) + identity) in the BatchNorm's apply pass
+
+    def _stem_grouped(self, xs, ps, out_channels=64):
+        """The three pyramids' stem convs (Cin 3, 3, 1: three small launches) into the channel slices of ONE [B, Ho, Wo, 3 x 64] tensor."""
+        B, _c, H, W = xs[0].shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        G = len(ps)
+        Ct = G * out_channels
+        y = Act(self._empty(B, Ho, Wo, Ct))
+        for g, (x_nchw, pp) in enumerate(zip(xs, ps)):
+            L.check(L.lib().vidc_stem_conv3x3s2(L.ptr(x_nchw), L.ptr(self.param[pp + "conv1.conv1_1.weight"]), L.ptr(y.t[..., g * out_channels:]), B, x_nchw.shape[1],
+                                                H, W, out_channels, Ct, 1, None, 0, L.current_stream()), "stem")
+
+        def backward():
+            g_ = self._empty(B, Ho, Wo, Ct)
+            L.check(L.lib().vidc_relu_backward(L.ptr(y.grad), L.ptr(y.t), L.ptr(g_), y.rows, Ct, _ld(y.grad), Ct, Ct, 0, L.current_stream()), "relu_bwd")
+            for g, (x_nchw, pp) in enumerate(zip(xs, ps)):
+                cin = x_nchw.shape[1]
+                sc = self._scratch_bytes(L.lib().vidc_stem_wgrad_scratch_bytes(B, cin, H, W, out_channels))
+                L.check(L.lib().vidc_stem_wgrad(L.ptr(g_[..., g * out_channels:]), L.ptr(x_nchw), L.ptr(self.grad[pp + "conv1.conv1_1.weight"]), B, cin, H, W, out_channels,
+                                                Ct, L.ptr(sc), L.current_stream()), "stem_wgrad")
+
+        self._record(backward)
+        return y
 
     def _pyramid(self, x_nchw, p, module, level_out):
         """ResNetPyramids.forward (depth_completion.py:55-65) in train mode; level l's output goes to `level_out[l]` (a channel slice of
         the concat buffer, depth_completion.py:151-152)."""
-        t = self._stem(x_nchw, p)
-        t = self.bn(self.conv(t, p + "conv1.conv1_2", 1, 1), p + "conv1.bn_2", True)
-        t = self.bn(self.conv(t, p + "conv1.conv1_3", 1, 1), p + "conv1.bn1_3", True)
-        t = self.bn(t, p + "bn1", True)
+        grouped = not isinstance(p, str)      # p: one prefix per pyramid, x_nchw: their inputs; level_out[l]: the whole concat buffer of level l
+        t = self._stem_grouped(x_nchw, p) if grouped else self._stem(x_nchw, p)
+        t = self.bn(self.conv(t, _cat(p, "conv1.conv1_2"), 1, 1), _cat(p, "conv1.bn_2"), True)
+        t = self.bn(self.conv(t, _cat(p, "conv1.conv1_3"), 1, 1), _cat(p, "conv1.bn1_3"), True)
+        t = self.bn(t, _cat(p, "bn1"), True)
         t = self.maxpool(t)
         outs = []
         for li in range(1, 5):
             stage = getattr(module, "layer%d" % li)
             for bi, blk in enumerate(stage):
                 last = bi == len(stage) - 1
-                t = self._bottleneck(t, "%slayer%d.%d." % (p, li, bi), blk.stride, blk.downsample is not None, out=level_out[li - 1] if last else None)
+                t = self._bottleneck(t, _cat(p, "layer%d.%d." % (li, bi)), blk.stride, blk.downsample is not None, out=level_out[li - 1] if last else None)
             outs.append(t)
         return outs
 
@@ -703,7 +824,13 @@ class DepthCompletionTrainer:
         # they are three parallel branches.  Scratch and split-K workspaces are per lane.  VIDC_TRAIN_STREAMS=1: one stream.
         main = torch.cuda.current_stream()
         multi = self.n_lanes > 1
-        for pi, (name, x) in enumerate((("resnet_rgb", image), ("resnet_normal", normal), ("resnet_depth", depth_in))):
+        if self.grouped:
+            # ONE chain of grouped launches for the three pyramids on the caller's stream: a third of the launches, each three times the
+            # work; level l's last block writes the concat buffer directly and the decoder reads the very same activation object, so the
+            # decoder's d(concat) IS the pyramids' level gradient (no slicing step)
+            xs = [t.contiguous().float() for t in (image, normal, depth_in)]
+            levels = self._pyramid(xs, tuple(n + "." for n in PYRAMIDS), getattr(self.cnn, PYRAMIDS[0]), cat)
+        for pi, (name, x) in enumerate(() if self.grouped else (("resnet_rgb", image), ("resnet_normal", normal), ("resnet_depth", depth_in))):
             outs = [cat[l][..., pi * chans[l]:(pi + 1) * chans[l]] for l in range(4)]
             x = x.contiguous().float()
             if not multi:
@@ -715,12 +842,12 @@ class DepthCompletionTrainer:
             with torch.cuda.stream(side):
                 subs.append(self._pyramid(x, name + ".", getattr(self.cnn, name), outs))
             self._cur = 0
-        if multi:
+        if multi and not self.grouped:
             for side in self._lane_streams():
                 main.wait_stream(side)
 
         def split_level_grads():                     # runs (in the backward) once the decoder has produced d(concat): slices become the
-            for l in range(4):                       # gradients of the three pyramids' level outputs
+            for l in range(4 if not self.grouped else 0):      # gradients of the three pyramids' level outputs (grouped: the same objects)
                 for pi in range(3):
                     g = levels[l].grad[..., pi * chans[l]:(pi + 1) * chans[l]]
                     subs[pi][l].grad = g if subs[pi][l].grad is None else subs[pi][l].grad
