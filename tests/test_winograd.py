@@ -110,7 +110,8 @@ WINO_SHAPES = [
     (1, 8, 10, 512, 256, 1),
     (1, 9, 11, 32, 64, 1),         # odd sizes, partial tiles on both edges
     (1, 64, 80, 64, 32, 4),
-]
+    (4, 64, 80, 256, 32, 2),       # large enough for the four-channels-per-thread form of the transforms with m = 2 and m = 4 (the shapes above
+]                                  # run one channel per thread: csrc/winograd.hip vecn)
 
 
 @pytest.mark.gpu

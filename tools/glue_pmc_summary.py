@@ -12,14 +12,14 @@ import csv
 import statistics
 import sys
 
-KEEP = ("warp_fwd_kernel", "warp_inv_rot_norm_kernel", "upsample_kernel", "maxpool_kernel", "wino_in_kernel<2>", "wino_in_kernel<4>", "wino_out_kernel<2>", "wino_out_kernel<4>")
+KEEP = ("warp_fwd_kernel", "warp_inv_rot_norm_kernel", "upsample_kernel", "maxpool_kernel", "wino_in_kernel", "wino_out_kernel")
 
 
 def load(path, counter):
     per = {}
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-        if name not in KEEP or r["Counter_Name"] != counter:
+        if not name.startswith(KEEP) or r["Counter_Name"] != counter:
             continue
         key = (name, int(r["Grid_Size"]), int(r["Workgroup_Size"]))
         per.setdefault(key, []).append((float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))

@@ -16,37 +16,88 @@
 //            (b * th + ty) * tw + tx with th = ceil(H / m), tw = ceil(W / m): GEMM group gg * a^2 + pos reads channel slice
 //            [(gg * a^2 + pos) * Cin, +Cin) of every row, so a restriction to a contiguous range of gg is a pointer offset.
 //     U    : [gg][pos][Cout][Cin]
-// One thread = one tile x 4 consecutive channels (16-byte accesses, lanes along channels).
+// One thread = one tile x 4 consecutive channels (16-byte accesses, lanes along channels), x 1 channel on the small maps (vecn below).
 #include "common.h"
 
 namespace {
 
-typedef float4 f4;
-__device__ __forceinline__ f4 operator+(f4 a, f4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ f4 operator-(f4 a, f4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ f4 operator*(float s, f4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+// N consecutive channels per thread: 4 (16-byte accesses) on maps large enough to fill the chip that way, 1 on the small maps (a 16x20
+// map of 1024 channels is 80 tiles x 256 float4 columns = 80 workgroups for 256 CUs, each thread a serial chain of 36 loads + 36 stores:
+// launch / latency-bound at ~10 us; one channel per thread is four times the threads with a quarter of the chain, lanes still along channels)
+template <int N> struct vecn {
+    float v[N];
+};
+template <int N> __device__ __forceinline__ vecn<N> operator+(const vecn<N>& a, const vecn<N>& b) {
+    vecn<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+template <int N> __device__ __forceinline__ vecn<N> operator-(const vecn<N>& a, const vecn<N>& b) {
+    vecn<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = a.v[i] - b.v[i];
+    return r;
+}
+template <int N> __device__ __forceinline__ vecn<N> operator*(float s, const vecn<N>& a) {
+    vecn<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = s * a.v[i];
+    return r;
+}
+template <int N> __device__ __forceinline__ vecn<N> vzero() {
+    vecn<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = 0.f;
+    return r;
+}
+template <int N> __device__ __forceinline__ vecn<N> vload(const float* p) {
+    vecn<N> r;
+    if constexpr (N == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = p[i];
+    }
+    return r;
+}
+template <int N> __device__ __forceinline__ void vstore(float* p, const vecn<N>& a) {
+    if constexpr (N == 4) *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) p[i] = a.v[i];
+    }
+}
+template <int N> __device__ __forceinline__ void vstore_split(unsigned short* img, size_t row, int ld, int c, const vecn<N>& a) {
+    if constexpr (N == 4) vidc::store_split4(img, row, ld, c, make_float4(a.v[0], a.v[1], a.v[2], a.v[3]));
+    else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) vidc::store_split(img, row, ld, c + i, a.v[i]);
+    }
+}
 
 // B^T d for one column (input transform) and A^T m for one column (output transform); the standard matrices of Lavin & Gray
 // ("Fast Algorithms for Convolutional Neural Networks", 2015) with interpolation points 0, +-1 (m = 2) and 0, +-1, +-2 (m = 4).
 template <int M_> struct Wino;
 template <> struct Wino<2> {
     static constexpr int A = 4;
-    __device__ static __forceinline__ void bt(const f4 (&d)[4], f4 (&t)[4]) {
+    template <typename V> __device__ static __forceinline__ void bt(const V (&d)[4], V (&t)[4]) {
         t[0] = d[0] - d[2];
         t[1] = d[1] + d[2];
         t[2] = d[2] - d[1];
         t[3] = d[1] - d[3];
     }
-    __device__ static __forceinline__ void at(const f4 (&m)[4], f4 (&o)[2]) {
+    template <typename V> __device__ static __forceinline__ void at(const V (&m)[4], V (&o)[2]) {
         o[0] = (m[0] + m[1]) + m[2];
         o[1] = (m[1] - m[2]) - m[3];
     }
 };
 template <> struct Wino<4> {
     static constexpr int A = 6;
-    __device__ static __forceinline__ void bt(const f4 (&d)[6], f4 (&t)[6]) {
-        const f4 p = d[4] - 4.f * d[2], q = d[3] - 4.f * d[1];
-        const f4 r = d[4] - d[2], s = 2.f * (d[3] - d[1]);
+    template <typename V> __device__ static __forceinline__ void bt(const V (&d)[6], V (&t)[6]) {
+        const V p = d[4] - 4.f * d[2], q = d[3] - 4.f * d[1];
+        const V r = d[4] - d[2], s = 2.f * (d[3] - d[1]);
         t[0] = (4.f * d[0] - 5.f * d[2]) + d[4];
         t[1] = p + q;
         t[2] = p - q;
@@ -54,8 +105,8 @@ template <> struct Wino<4> {
         t[4] = r - s;
         t[5] = (4.f * d[1] - 5.f * d[3]) + d[5];
     }
-    __device__ static __forceinline__ void at(const f4 (&m)[6], f4 (&o)[4]) {
-        const f4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    template <typename V> __device__ static __forceinline__ void at(const V (&m)[6], V (&o)[4]) {
+        const V s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
         o[0] = (m[0] + s12) + s34;
         o[1] = d12 + 2.f * d34;
         o[2] = s12 + 4.f * s34;
@@ -72,21 +123,22 @@ __device__ __forceinline__ void band_block(unsigned& bx, unsigned& by) {
     bx = idx - by * gx;
 }
 
-template <int M_>
+template <int M_, int N>
 __global__ void __launch_bounds__(256)
 wino_in_kernel(const float* __restrict__ x, float* __restrict__ v, unsigned short* __restrict__ vsp, int H, int W, int C, int ldx, int Cin,
                int th, int tw, int ldv) {
     constexpr int A = Wino<M_>::A;
-    const unsigned q = (unsigned)C / 4u;
+    typedef vecn<N> V;
+    const unsigned q = (unsigned)C / (unsigned)N;
     unsigned bx, by;                       // by = tile row (b, ty): wave-uniform
     band_block(bx, by);
     const unsigned i = bx * blockDim.x + threadIdx.x;
     if (i >= (unsigned)tw * q) return;
     const int tx = (int)(i / q);
-    const int c = (int)(i - (unsigned)tx * q) * 4;
+    const int c = (int)(i - (unsigned)tx * q) * N;
     const int b = (int)(by / (unsigned)th), ty = (int)(by - (unsigned)b * (unsigned)th);
     const int iy0 = ty * M_ - 1, ix0 = tx * M_ - 1;
-    f4 d[A][A];
+    V d[A][A];
 #pragma unroll
     for (int r = 0; r < A; ++r) {
         const int iy = iy0 + r;
@@ -94,15 +146,14 @@ wino_in_kernel(const float* __restrict__ x, float* __restrict__ v, unsigned shor
 #pragma unroll
         for (int s = 0; s < A; ++s) {
             const int ix = ix0 + s;
-            d[r][s] = (rok && (unsigned)ix < (unsigned)W) ? *reinterpret_cast<const f4*>(&x[((size_t)(b * H + iy) * W + ix) * ldx + c])
-                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            d[r][s] = (rok && (unsigned)ix < (unsigned)W) ? vload<N>(&x[((size_t)(b * H + iy) * W + ix) * ldx + c]) : vzero<N>();
         }
     }
     // B^T d (columns), then (.) B (rows)
-    f4 t[A][A];
+    V t[A][A];
 #pragma unroll
     for (int s = 0; s < A; ++s) {
-        f4 col[A], out[A];
+        V col[A], out[A];
 #pragma unroll
         for (int r = 0; r < A; ++r) col[r] = d[r][s];
         Wino<M_>::bt(col, out);
@@ -114,44 +165,45 @@ wino_in_kernel(const float* __restrict__ x, float* __restrict__ v, unsigned shor
     const int ch0 = gg * (A * A) * Cin + cc;
 #pragma unroll
     for (int r = 0; r < A; ++r) {
-        f4 out[A];
+        V out[A];
         Wino<M_>::bt(t[r], out);
 #pragma unroll
         for (int s = 0; s < A; ++s) {
             const int ch = ch0 + (r * A + s) * Cin;
-            if (vsp) vidc::store_split4(vsp, tile, ldv, ch, out[s]);
-            else *reinterpret_cast<f4*>(&v[tile * ldv + ch]) = out[s];
+            if (vsp) vstore_split<N>(vsp, tile, ldv, ch, out[s]);
+            else vstore<N>(&v[tile * ldv + ch], out[s]);
         }
     }
 }
 
-template <int M_>
+template <int M_, int N>
 __global__ void __launch_bounds__(256)
 wino_out_kernel(const float* __restrict__ mm, float* __restrict__ y, unsigned short* __restrict__ ysp, const float* __restrict__ scale1,
                 const float* __restrict__ shift1, const float* __restrict__ scale2, const float* __restrict__ shift2, int Ho, int Wo, int C,
                 int Cout, int ldy, int th, int tw, int flags, int ldm) {
     constexpr int A = Wino<M_>::A;
-    const unsigned q = (unsigned)C / 4u;
+    typedef vecn<N> V;
+    const unsigned q = (unsigned)C / (unsigned)N;
     unsigned bx, by;
     band_block(bx, by);
     const unsigned i = bx * blockDim.x + threadIdx.x;
     if (i >= (unsigned)tw * q) return;
     const int tx = (int)(i / q);
-    const int c = (int)(i - (unsigned)tx * q) * 4;
+    const int c = (int)(i - (unsigned)tx * q) * N;
     const int b = (int)(by / (unsigned)th), ty = (int)(by - (unsigned)b * (unsigned)th);
     const int gg = c / Cout, cc = c - gg * Cout;
     const size_t tile = ((size_t)by) * tw + tx;
     const float* src = mm + tile * ldm + gg * (A * A) * Cout + cc;
-    f4 m[A][A];
+    V m[A][A];
 #pragma unroll
     for (int r = 0; r < A; ++r)
 #pragma unroll
-        for (int s = 0; s < A; ++s) m[r][s] = *reinterpret_cast<const f4*>(&src[(r * A + s) * Cout]);
+        for (int s = 0; s < A; ++s) m[r][s] = vload<N>(&src[(r * A + s) * Cout]);
     // A^T m (columns), then (.) A (rows)
-    f4 t[M_][A];
+    V t[M_][A];
 #pragma unroll
     for (int s = 0; s < A; ++s) {
-        f4 col[A], out[M_];
+        V col[A], out[M_];
 #pragma unroll
         for (int r = 0; r < A; ++r) col[r] = m[r][s];
         Wino<M_>::at(col, out);
@@ -159,15 +211,15 @@ wino_out_kernel(const float* __restrict__ mm, float* __restrict__ y, unsigned sh
         for (int r = 0; r < M_; ++r) t[r][s] = out[r];
     }
     // the epilogue of conv_mfma.hip: acc * s1 + b1 -> relu -> [* s2 + b2 -> relu]; ReLU off = max with -inf
-    const f4 s1 = *reinterpret_cast<const f4*>(&scale1[c]), b1 = *reinterpret_cast<const f4*>(&shift1[c]);
+    const V s1 = vload<N>(&scale1[c]), b1 = vload<N>(&shift1[c]);
     const float lo1 = (flags & VIDC_RELU1) ? 0.f : -INFINITY, lo2 = (flags & VIDC_RELU2) ? 0.f : -INFINITY;
     const bool aff2 = flags & VIDC_AFFINE2;
-    f4 s2 = make_float4(1.f, 1.f, 1.f, 1.f), b2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (aff2) { s2 = *reinterpret_cast<const f4*>(&scale2[c]); b2 = *reinterpret_cast<const f4*>(&shift2[c]); }
+    V s2 = vzero<N>(), b2 = vzero<N>();
+    if (aff2) { s2 = vload<N>(&scale2[c]); b2 = vload<N>(&shift2[c]); }
     const bool st_f32 = !(flags & VIDC_NO_F32_OUT);
 #pragma unroll
     for (int r = 0; r < M_; ++r) {
-        f4 out[M_];
+        V out[M_];
         Wino<M_>::at(t[r], out);
         const int oy = ty * M_ + r;
         if (oy >= Ho) continue;
@@ -175,16 +227,16 @@ wino_out_kernel(const float* __restrict__ mm, float* __restrict__ y, unsigned sh
         for (int s = 0; s < M_; ++s) {
             const int ox = tx * M_ + s;
             if (ox >= Wo) continue;
-            f4 o = out[s];
-            o.x = fmaxf(o.x * s1.x + b1.x, lo1); o.y = fmaxf(o.y * s1.y + b1.y, lo1);
-            o.z = fmaxf(o.z * s1.z + b1.z, lo1); o.w = fmaxf(o.w * s1.w + b1.w, lo1);
+            V o = out[s];
+#pragma unroll
+            for (int k = 0; k < N; ++k) o.v[k] = fmaxf(o.v[k] * s1.v[k] + b1.v[k], lo1);
             if (aff2) {
-                o.x = fmaxf(o.x * s2.x + b2.x, lo2); o.y = fmaxf(o.y * s2.y + b2.y, lo2);
-                o.z = fmaxf(o.z * s2.z + b2.z, lo2); o.w = fmaxf(o.w * s2.w + b2.w, lo2);
+#pragma unroll
+                for (int k = 0; k < N; ++k) o.v[k] = fmaxf(o.v[k] * s2.v[k] + b2.v[k], lo2);
             }
             const size_t row = (size_t)(b * Ho + oy) * Wo + ox;
-            if (st_f32) *reinterpret_cast<f4*>(&y[row * ldy + c]) = o;
-            if (ysp) vidc::store_split4(ysp, row, ldy, c, o);
+            if (st_f32) vstore<N>(&y[row * ldy + c], o);
+            if (ysp) vstore_split<N>(ysp, row, ldy, c, o);
         }
     }
 }
@@ -247,11 +299,17 @@ extern "C" int vidc_winograd_input_transform(const float* x, void* v, int B, int
     if (ldv == 0) ldv = (m + 2) * (m + 2) * C;
     VIDC_REQUIRE(ldv >= (m + 2) * (m + 2) * C && ldv % 4 == 0 && (!split || ldv % 32 == 0), VIDC_ERR_SHAPE, "vidc_winograd_input_transform: bad row stride ldv = %d", ldv);
     VIDC_REQUIRE((long long)B * th <= 65535, VIDC_ERR_SHAPE, "vidc_winograd_input_transform: B * tile rows = %lld exceed the grid", (long long)B * th);
-    const dim3 grid((unsigned)(vidc::cdiv(tw * (C / 4), 256) + 7) / 8 * 8, (unsigned)(B * th));
+    // four channels per thread where that still fills the chip, one on the small maps (see vecn)
+    const bool wide = (long long)B * th * tw * (C / 4) >= 131072;
+    const int per = wide ? 4 : 1;
+    const dim3 grid((unsigned)(vidc::cdiv(tw * (C / per), 256) + 7) / 8 * 8, (unsigned)(B * th));
     float* vf = split ? nullptr : reinterpret_cast<float*>(v);
     unsigned short* vs = split ? reinterpret_cast<unsigned short*>(v) : nullptr;
-    if (m == 2) hipLaunchKernelGGL(wino_in_kernel<2>, grid, dim3(256), 0, vidc::as_stream(stream), x, vf, vs, H, W, C, ldx, Cin, th, tw, ldv);
-    else hipLaunchKernelGGL(wino_in_kernel<4>, grid, dim3(256), 0, vidc::as_stream(stream), x, vf, vs, H, W, C, ldx, Cin, th, tw, ldv);
+    hipStream_t st = vidc::as_stream(stream);
+    if (m == 2 && wide) hipLaunchKernelGGL((wino_in_kernel<2, 4>), grid, dim3(256), 0, st, x, vf, vs, H, W, C, ldx, Cin, th, tw, ldv);
+    else if (m == 2) hipLaunchKernelGGL((wino_in_kernel<2, 1>), grid, dim3(256), 0, st, x, vf, vs, H, W, C, ldx, Cin, th, tw, ldv);
+    else if (wide) hipLaunchKernelGGL((wino_in_kernel<4, 4>), grid, dim3(256), 0, st, x, vf, vs, H, W, C, ldx, Cin, th, tw, ldv);
+    else hipLaunchKernelGGL((wino_in_kernel<4, 1>), grid, dim3(256), 0, st, x, vf, vs, H, W, C, ldx, Cin, th, tw, ldv);
     VIDC_CHECK_LAUNCH("wino_in_kernel");
     return VIDC_OK;
 }
@@ -274,10 +332,15 @@ extern "C" int vidc_winograd_output_transform(const float* mm, float* y, void* y
     if (ldm == 0) ldm = (m + 2) * (m + 2) * C;
     VIDC_REQUIRE(ldm >= (m + 2) * (m + 2) * C && ldm % 4 == 0, VIDC_ERR_SHAPE, "vidc_winograd_output_transform: bad row stride ldm = %d", ldm);
     VIDC_REQUIRE((long long)B * th <= 65535, VIDC_ERR_SHAPE, "vidc_winograd_output_transform: B * tile rows = %lld exceed the grid", (long long)B * th);
-    const dim3 grid((unsigned)(vidc::cdiv(tw * (C / 4), 256) + 7) / 8 * 8, (unsigned)(B * th));
+    const bool wide = (long long)B * th * tw * (C / 4) >= 131072;
+    const int per = wide ? 4 : 1;
+    const dim3 grid((unsigned)(vidc::cdiv(tw * (C / per), 256) + 7) / 8 * 8, (unsigned)(B * th));
     unsigned short* ys = reinterpret_cast<unsigned short*>(y_split);
-    if (m == 2) hipLaunchKernelGGL(wino_out_kernel<2>, grid, dim3(256), 0, vidc::as_stream(stream), mm, y, ys, scale1, shift1, scale2, shift2, Ho, Wo, C, Cout, ldy, th, tw, flags, ldm);
-    else hipLaunchKernelGGL(wino_out_kernel<4>, grid, dim3(256), 0, vidc::as_stream(stream), mm, y, ys, scale1, shift1, scale2, shift2, Ho, Wo, C, Cout, ldy, th, tw, flags, ldm);
+    hipStream_t st = vidc::as_stream(stream);
+    if (m == 2 && wide) hipLaunchKernelGGL((wino_out_kernel<2, 4>), grid, dim3(256), 0, st, mm, y, ys, scale1, shift1, scale2, shift2, Ho, Wo, C, Cout, ldy, th, tw, flags, ldm);
+    else if (m == 2) hipLaunchKernelGGL((wino_out_kernel<2, 1>), grid, dim3(256), 0, st, mm, y, ys, scale1, shift1, scale2, shift2, Ho, Wo, C, Cout, ldy, th, tw, flags, ldm);
+    else if (wide) hipLaunchKernelGGL((wino_out_kernel<4, 4>), grid, dim3(256), 0, st, mm, y, ys, scale1, shift1, scale2, shift2, Ho, Wo, C, Cout, ldy, th, tw, flags, ldm);
+    else hipLaunchKernelGGL((wino_out_kernel<4, 1>), grid, dim3(256), 0, st, mm, y, ys, scale1, shift1, scale2, shift2, Ho, Wo, C, Cout, ldy, th, tw, flags, ldm);
     VIDC_CHECK_LAUNCH("wino_out_kernel");
     return VIDC_OK;
 }
