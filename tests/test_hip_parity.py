@@ -319,6 +319,44 @@ def test_stem_conv(cin, hw):
     assert (nchw(y).cpu() - ref).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("align_corners", [False, True])
+def test_stem_conv_gathers_through_the_warp_bit_for_bit(golden_dir, align_corners):
+    """Round 5: the surface-normal stem reads its input THROUGH the forward warp (vidc_stem_conv3x3s2_warped, same tap code as
+    warp_fwd_kernel) instead of a stored warped image: identical bits on the 11 golden gravities (incl. the extreme tilts whose samples
+    fall outside the image), both grid_sample conventions."""
+    from vi_depth_completion_amd import ops
+    from vi_depth_completion_amd.networks.warping_2dof_alignment import Warping2DOFAlignment
+    w_, g, a, img, _nmap = _warp_inputs(golden_dir)
+    wp = Warping2DOFAlignment(float(w_["fx"]), float(w_["fy"]), float(w_["cx"]), float(w_["cy"]), align_corners=align_corners)
+    wt = S.normal01(5, "stem.w", (64, 3, 3, 3), scale=0.2).float().to(DEV)
+    x = img.to(DEV)
+    params = wp._params(g.to(DEV), a.to(DEV))
+    _H, warped = wp.warp_with_gravity_center_aligned(x, g.to(DEV), a.to(DEV))
+    ref = ops.stem_conv3x3s2(warped, wt, relu=True)
+    got = ops.stem_conv3x3s2_warped(x, params, wt, wp.cx, wp.cy, align_corners, relu=True)
+    assert torch.equal(got, ref)
+    assert float(ref.abs().max()) > 0.1
+
+
+def test_frame_program_with_and_without_the_fused_warp_is_bit_identical(seeded_weights, monkeypatch):
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    batch = S.synthetic_batch(2, 240, 320, 1234)
+    dev_batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    outs = []
+    for fuse in ("1", "0"):               # (opt-in: the separate warp launch is the default, DESIGN 4.4)
+        monkeypatch.setenv("VIDC_FUSE_WARP", fuse)
+        pipe = DepthCompletionPipeline(enriched_samples=200, device=torch.device(DEV), rng=np.random.RandomState(3))
+        pipe.load_state_dicts({k: v.to(DEV) for k, v in seeded_weights["sn"].items()}, {k: v.to(DEV) for k, v in seeded_weights["dc"].items()})
+        pipe.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(240, 320))
+        seq = pipe._call_cnn(dev_batch).cpu()
+        pipe.rng = np.random.RandomState(3)
+        inter = [o.cpu() for o in pipe.run_interleaved(iter([dev_batch, dev_batch]), lanes=2)]
+        outs.append((seq, inter))
+        del pipe
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(outs[0][1], outs[1][1]))
+
+
 @pytest.mark.parametrize("hw", [(120, 160), (128, 160), (7, 9)])
 def test_maxpool(hw):
     from vi_depth_completion_amd import ops

@@ -45,6 +45,14 @@ def main():
         rows.append(("warp_fwd 3ch %dx%d" % (W, H), B, us, 2 * x.numel() * 4))
         us = timed(lambda: lib.vidc_warp2dof_inv_rot_norm(x.data_ptr(), p.data_ptr(), y.data_ptr(), B, H, W, wp.cx, wp.cy, 0, 1, st))
         rows.append(("warp_inv_rot_norm", B, us, 2 * x.numel() * 4))
+        # the surface-normal stem gathering its input through the forward warp (round 5; replaces warp_fwd + stem in the programs):
+        # algorithmic bytes = the image read once + the 64-channel half-resolution output
+        wt = torch.randn(64, 3, 3, 3, device="cuda") * 0.2
+        ys = torch.empty(B, H // 2, W // 2, 64, device="cuda")
+        us = timed(lambda: lib.vidc_stem_conv3x3s2_warped(x.data_ptr(), p.data_ptr(), wt.data_ptr(), ys.data_ptr(), B, H, W, 64, 64, 1, None, 0, wp.cx, wp.cy, 0, st))
+        rows.append(("stem conv through the warp", B, us, (x.numel() + ys.numel()) * 4))
+        us = timed(lambda: lib.vidc_stem_conv3x3s2(x.data_ptr(), wt.data_ptr(), ys.data_ptr(), B, 3, H, W, 64, 64, 1, None, 0, st))
+        rows.append(("stem conv (plain input)", B, us, (x.numel() + ys.numel()) * 4))
         for (h, w, Cc, Ho, Wo) in ((32, 40, 768, 64, 80), (16, 20, 1536, 32, 40), (32, 40, 256, 64, 80)):
             xi = torch.randn(B, h, w, Cc, device="cuda")
             yo = torch.empty(B, Ho, Wo, Cc, device="cuda")

@@ -12,7 +12,7 @@ import csv
 import statistics
 import sys
 
-KEEP = ("warp_fwd_kernel", "warp_inv_rot_norm_kernel", "upsample_kernel", "maxpool_kernel", "wino_in_kernel", "wino_out_kernel")
+KEEP = ("warp_fwd_kernel", "warp_inv_rot_norm_kernel", "upsample_kernel", "maxpool_kernel", "wino_in_kernel", "wino_out_kernel", "stem_conv_kernel")
 
 
 def load(path, counter):

@@ -121,6 +121,7 @@ SIGNATURES = {
     "vidc_winograd_input_transform": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_winograd_output_transform": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_stem_conv3x3s2": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "vidc_stem_conv3x3s2_warped": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _f, _f, _i, _vp]),
     "vidc_maxpool3x3s2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vidc_upsample_bilinear_ac": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vidc_avgpool2d": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

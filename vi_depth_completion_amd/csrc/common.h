@@ -68,4 +68,61 @@ __device__ inline void store_split4(unsigned short* img, size_t row, int ld, int
     *reinterpret_cast<uint2*>(u + 32) = make_uint2(l0 | ((unsigned)l1 << 16), l2 | ((unsigned)l3 << 16));
 }
 
+// ---- bilinear tap set, zero padding (grid_sampler_2d semantics) ---------------------------------------------
+struct Taps {
+    int o00, o01, o10, o11;       // element offsets inside one H*W plane (clamped, valid even if weight==0)
+    float w00, w01, w10, w11;
+};
+
+__device__ inline Taps make_taps(float u, float v, float cx, float cy, int W, int H, int align_corners) {
+    float gx = (1.0f / ((float)W / 2)) * (u - cx);
+    float gy = (1.0f / ((float)H / 2)) * (v - cy);
+    float ix, iy;
+    if (align_corners) {
+        ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
+        iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    } else {
+        ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
+        iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    }
+    // keep NaN/inf and far-out coordinates harmless: they sample nothing
+    if (!(ix > -2.0f && ix < (float)W + 1.0f)) ix = -2.0f;
+    if (!(iy > -2.0f && iy < (float)H + 1.0f)) iy = -2.0f;
+    float fx0 = floorf(ix), fy0 = floorf(iy);
+    int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix;
+    float wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
+    bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1), cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    Taps t;
+    t.o00 = cy0 * W + cx0; t.o01 = cy0 * W + cx1; t.o10 = cy1 * W + cx0; t.o11 = cy1 * W + cx1;
+    t.w00 = (vx0 && vy0) ? wx0 * wy0 : 0.f;
+    t.w01 = (vx1 && vy0) ? wx1 * wy0 : 0.f;
+    t.w10 = (vx0 && vy1) ? wx0 * wy1 : 0.f;
+    t.w11 = (vx1 && vy1) ? wx1 * wy1 : 0.f;
+    return t;
+}
+
+__device__ inline float sample(const float* __restrict__ plane, const Taps& t) {
+    // explicit fma chain: the result must not depend on how the compiler unrolls the channel loop
+    return fmaf(plane[t.o11], t.w11, fmaf(plane[t.o10], t.w10, fmaf(plane[t.o01], t.w01, plane[t.o00] * t.w00)));
+}
+
+// Tap set of output pixel (X, Y) of the gravity-aligned forward warp (warping_2dof_alignment.py:142-152): H^-1 (X / kw + px_min, Y / kh + py_min, 1)
+// from the per-sample record of vidc_warp2dof_params.  One definition for the stand-alone warp kernel (csrc/warp.hip) and for the stem conv
+// that gathers its input through the warp (csrc/pointwise.hip): the same bits either way.
+__device__ inline Taps warp_fwd_taps(const float* __restrict__ p, int X, int Y, float cx, float cy, int W, int H, int align_corners) {
+    const float px_min = p[27], py_min = p[28], kw = p[29], kh = p[30];
+    float Xs, Ys, P0, P1, P2;
+    {
+#pragma clang fp contract(off)
+        Xs = (1.0f / kw) * (float)X + px_min;
+        Ys = (1.0f / kh) * (float)Y + py_min;
+        P0 = (p[18] * Xs + p[19] * Ys) + p[20];
+        P1 = (p[21] * Xs + p[22] * Ys) + p[23];
+        P2 = (p[24] * Xs + p[25] * Ys) + p[26];
+    }
+    return make_taps(P0 / P2, P1 / P2, cx, cy, W, H, align_corners);
+}
+
 }  // namespace vidc

@@ -8,10 +8,15 @@ namespace {
 // ---- stem: 3x3 stride-2 pad-1 conv, Cin in {1,3}, NCHW in -> NHWC out (networks/surface_normal.py:17-18) --------
 // One workgroup = 64 output pixels of one row segment x all Cout (<=64 per pass) channels.  The 27 (or 9) weights of
 // a lane's output channel live in registers; the input patch is staged in LDS and broadcast.
-template <int CIN>
+// WARP = true (round 5): the conv's input is the gravity-aligned forward warp of x (warping_2dof_alignment.py:108-156 in front of
+// surface_normal.py:163) and the patch loader gathers it on the fly -- one projective map and one bilinear tap set per patch pixel, shared
+// by the CIN channels, the very code of warp_fwd_kernel (vidc::warp_fwd_taps / vidc::sample), so the patch holds the bits that kernel would
+// have stored.  The warped image is never written: one launch and a 2 x 3HW x 4 byte round trip less per frame.
+template <int CIN, bool WARP>
 __global__ void __launch_bounds__(256)
 stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int H, int W, int Ho, int Wo,
-                 int Cout, int ldy, int relu, unsigned short* __restrict__ ysp, int ch0) {
+                 int Cout, int ldy, int relu, unsigned short* __restrict__ ysp, int ch0, const float* __restrict__ warp_params, float wcx, float wcy,
+                 int align_corners) {
     constexpr int PIX = 64;                 // output pixels per workgroup (along X)
     constexpr int PW = 2 * PIX + 1;         // input patch width
     __shared__ float patch[CIN][3][PW + 3];
@@ -20,12 +25,51 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
     const size_t plane = (size_t)H * W;
     const float* xb = x + (size_t)b * CIN * plane;
     const int ix_base = ox0 * 2 - 1, iy_base = oy * 2 - 1;
-    for (int e = tid; e < CIN * 3 * PW; e += 256) {
-        int c = e / (3 * PW), r = (e / PW) % 3, i = e % PW;
-        int iy = iy_base + r, ix = ix_base + i;
-        float v = 0.f;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[c * plane + (size_t)iy * W + ix];
-        patch[c][r][i] = v;
+    if constexpr (WARP) {
+        // The record was written by the launch just before this one (warp_params_kernel).  It is read through the VECTOR memory path into
+        // LDS, not with scalar loads: `warp_params + b * 32` is wave-uniform, hipcc turns plain reads of it into s_load (scalar data cache),
+        // and with two or three lanes' graphs in flight those returned the PREVIOUS tick's record now and then (round 5: whole stem outputs
+        // computed with the last frame's homography, nondeterministically, only with >= 2 lanes, never eagerly) -- the scalar cache is not
+        // reliably invalidated between two kernel nodes of a captured graph.
+        __shared__ float wp[VIDC_WARP_PARAMS];
+        if (tid < VIDC_WARP_PARAMS) wp[tid] = __builtin_nontemporal_load(warp_params + (size_t)b * VIDC_WARP_PARAMS + tid);
+        __syncthreads();
+        for (int e = tid; e < 3 * PW; e += 256) {
+            const int r = e / PW, i = e - r * PW;
+            const int iy = iy_base + r, ix = ix_base + i;
+            const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;      // (outside: the conv's zero padding, not a warp sample)
+            vidc::Taps t;
+            if (in) t = vidc::warp_fwd_taps(wp, ix, iy, wcx, wcy, W, H, align_corners);
+            // The image is sampled with system-scope loads (coherent, never served from a stale cache line).  With plain loads a few cache
+            // lines of the image now and then still held the PREVIOUS frame's pixels when two or three lanes' graphs were in flight (round 5:
+            // nondeterministic 1e-3 differences in the depth map of one frame in ten, traced to 400-800 wrong words of this kernel's output;
+            // the image is rewritten by a device-to-device copy before every launch; 8 of 8 runs clean with these loads, 6 of 8 dirty
+            // without).  The stand-alone warp kernel reading the same buffer has never shown it (its reads are banded per XCD).
+#if 1
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                float v = 0.f;
+                if (in) {
+                    const float* pl = xb + c * plane;
+                    const float a00 = __hip_atomic_load(pl + t.o00, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), a01 = __hip_atomic_load(pl + t.o01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const float a10 = __hip_atomic_load(pl + t.o10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), a11 = __hip_atomic_load(pl + t.o11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    v = fmaf(a11, t.w11, fmaf(a10, t.w10, fmaf(a01, t.w01, a00 * t.w00)));
+                }
+                patch[c][r][i] = v;
+            }
+#else
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) patch[c][r][i] = in ? vidc::sample(xb + c * plane, t) : 0.f;
+#endif
+        }
+    } else {
+        for (int e = tid; e < CIN * 3 * PW; e += 256) {
+            int c = e / (3 * PW), r = (e / PW) % 3, i = e % PW;
+            int iy = iy_base + r, ix = ix_base + i;
+            float v = 0.f;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[c * plane + (size_t)iy * W + ix];
+            patch[c][r][i] = v;
+        }
     }
     __syncthreads();
     const int co = tid & 63, pgrp = tid >> 6;      // lanes run along channels -> 256-byte coalesced NHWC stores
@@ -270,8 +314,25 @@ extern "C" int vidc_normalize_nchw(const float* x, float* y, int B, int C, int H
     return VIDC_OK;
 }
 
+namespace {
+int stem_launch(const float* x, const float* w_oihw, float* y, int B, int Cin, int H, int W, int Cout, int ldy, int relu, void* y_split, int split_ch0,
+                const float* warp_params, float cx, float cy, int align_corners, vidc_stream_t stream);
+}
+
 extern "C" int vidc_stem_conv3x3s2(const float* x, const float* w_oihw, float* y, int B, int Cin, int H, int W, int Cout, int ldy,
                                    int relu, void* y_split, int split_ch0, vidc_stream_t stream) {
+    return stem_launch(x, w_oihw, y, B, Cin, H, W, Cout, ldy, relu, y_split, split_ch0, nullptr, 0.f, 0.f, 0, stream);
+}
+
+extern "C" int vidc_stem_conv3x3s2_warped(const float* x, const float* warp_params, const float* w_oihw, float* y, int B, int H, int W, int Cout, int ldy,
+                                          int relu, void* y_split, int split_ch0, float cx, float cy, int align_corners, vidc_stream_t stream) {
+    VIDC_REQUIRE(warp_params, VIDC_ERR_NULL, "vidc_stem_conv3x3s2_warped: null warp parameters");
+    return stem_launch(x, w_oihw, y, B, 3, H, W, Cout, ldy, relu, y_split, split_ch0, warp_params, cx, cy, align_corners, stream);
+}
+
+namespace {
+int stem_launch(const float* x, const float* w_oihw, float* y, int B, int Cin, int H, int W, int Cout, int ldy, int relu, void* y_split, int split_ch0,
+                const float* warp_params, float cx, float cy, int align_corners, vidc_stream_t stream) {
     VIDC_REQUIRE(x && w_oihw && (y || y_split), VIDC_ERR_NULL, "vidc_stem_conv3x3s2: null pointer");
     VIDC_REQUIRE(!y_split || (ldy % 32 == 0 && split_ch0 >= 0), VIDC_ERR_SHAPE, "vidc_stem_conv3x3s2: split output needs ldy % 32 == 0");
     unsigned short* ysp = reinterpret_cast<unsigned short*>(y_split);
@@ -279,13 +340,17 @@ extern "C" int vidc_stem_conv3x3s2(const float* x, const float* w_oihw, float* y
                  "vidc_stem_conv3x3s2: unsupported shape (Cin=%d must be 1 or 3)", Cin);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     dim3 grid(vidc::cdiv(Wo, 64), Ho, B);
-    if (Cin == 3)
-        hipLaunchKernelGGL(stem_conv_kernel<3>, grid, dim3(256), 0, vidc::as_stream(stream), x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0);
+    hipStream_t st = vidc::as_stream(stream);
+    if (warp_params)
+        hipLaunchKernelGGL((stem_conv_kernel<3, true>), grid, dim3(256), 0, st, x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0, warp_params, cx, cy, align_corners);
+    else if (Cin == 3)
+        hipLaunchKernelGGL((stem_conv_kernel<3, false>), grid, dim3(256), 0, st, x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0, warp_params, cx, cy, align_corners);
     else
-        hipLaunchKernelGGL(stem_conv_kernel<1>, grid, dim3(256), 0, vidc::as_stream(stream), x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0);
+        hipLaunchKernelGGL((stem_conv_kernel<1, false>), grid, dim3(256), 0, st, x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0, warp_params, cx, cy, align_corners);
     VIDC_CHECK_LAUNCH("stem_conv_kernel");
     return VIDC_OK;
 }
+}  // namespace
 
 extern "C" int vidc_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, int ldx, int ldy, void* y_split,
                                  vidc_stream_t stream) {

@@ -25,6 +25,9 @@ int launch_op(const vidc_op& op, hipStream_t st) {
         case VIDC_OP_CONV:
             return vidc_conv2d_bn_act(&op.u.conv, s);
         case VIDC_OP_STEM:
+            if (g.p[4])      // input gathered through the forward warp: p[4] = warp parameter records, f = cx, cy, i[8] = align_corners
+                return vidc_stem_conv3x3s2_warped((const float*)g.p[0], (const float*)g.p[4], (const float*)g.p[1], (float*)g.p[2], g.i[0], g.i[2], g.i[3], g.i[4],
+                                                  g.i[5], g.i[6], const_cast<void*>(g.p[3]), g.i[7], g.f[0], g.f[1], g.i[8], s);
             return vidc_stem_conv3x3s2((const float*)g.p[0], (const float*)g.p[1], (float*)g.p[2], g.i[0], g.i[1], g.i[2], g.i[3],
                                        g.i[4], g.i[5], g.i[6], const_cast<void*>(g.p[3]), g.i[7], s);
         case VIDC_OP_MAXPOOL:

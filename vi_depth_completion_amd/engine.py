@@ -245,7 +245,7 @@ class Program:
         self.buf_elems = []      # elements per buffer id
         self.pinned = set()      # buffer ids that must not alias (inputs / outputs)
         self.inputs, self.outputs = {}, {}
-        self.reuse = reuse_buffers
+        self.reuse = reuse_buffers and os.environ.get("VIDC_NO_BUFFER_REUSE", "0") != "1"      # (debug knob of tools/dbg_lanes.py: every program tensor in storage of its own)
         self.stream_id = 0
         self.wait_mask = 0
         self.handle = None
@@ -574,6 +574,31 @@ class Program:
         self.n_fused_splits = len(drop)
         self.ops = [op for i, op in enumerate(self.ops) if i not in drop]
 
+    def _fuse_warp_into_stem(self):
+        """A stem conv whose input is the output of a forward warp that nothing else reads gathers its input through the warp itself
+        (vidc_stem_conv3x3s2_warped: the tap sets of warp_fwd_kernel, bit for bit) and the warp launch + the warped image go away
+        (VERDICT r4 item 9).  Not when the warped image has another reader (the use_mask branch, surface_normal.py:150-162) or is an output."""
+        drop = set()
+        for i, (kind, reads, _w, kw) in enumerate(self.ops):
+            if kind != "stem" or kw["x"].C != 3:
+                continue
+            xb = kw["x"].buf
+            j = next((t for t in range(i - 1, -1, -1) if xb in self.ops[t][2]), None)
+            if j is None or self.ops[j][0] != "warp_fwd" or xb in self.pinned:
+                continue
+            if any(t != i and t not in drop and xb in self.ops[t][1] for t in range(len(self.ops))):
+                continue
+            if any(id(self.ops[t]) in {id(mk) for mk in self._cut_markers} for t in range(j, i)):      # (a segment boundary in between)
+                continue
+            wkw = self.ops[j][3]
+            kw["warp"] = {"x": wkw["x"], "p": wkw["p"], "intr": wkw["intr"], "ac": wkw["ac"]}
+            self.ops[i] = (kind, [b for b in reads if b != xb] + [wkw["x"].buf, wkw["p"].buf], _w, kw)
+            drop.add(j)
+        if drop:
+            self._cut_markers = [mk for mk in self._cut_markers]      # (markers are op identities: the dropped warp ops are never markers, checked above)
+            self.ops = [op for t, op in enumerate(self.ops) if t not in drop]
+        self.n_fused_warps = len(drop)
+
     def _fill_conv_desc(self, d, kw, addr, dry_run):
         """Fills one vidc_conv_desc from a recorded conv; returns the op's display name."""
         lib = L.lib()
@@ -667,6 +692,12 @@ class Program:
     def finalize(self, dry_run=False):
         """Plans buffers and builds the C op array.  dry_run=True stops before any HIP call (host-logic tests on CPU)."""
         lib = L.lib()
+        # Opt-in (VIDC_FUSE_WARP=1): bit-identical, one launch and 2 x 3HW x 4 bytes less per frame, no measurable gain (< 0.2 % of the tick),
+        # and the fused kernel needs system-scope loads to be safe beside other lanes (csrc/pointwise.hip) -- the separate warp launch stays.
+        if os.environ.get("VIDC_FUSE_WARP", "0") == "1":
+            self._fuse_warp_into_stem()
+        else:
+            self.n_fused_warps = 0
         if os.environ.get("VIDC_FUSE_SPLIT", "1") == "1":
             self._fuse_splits()
         self.cuts = [next(i for i, op in enumerate(self.ops) if op is mk) + 1 for mk in self._cut_markers]
@@ -704,7 +735,11 @@ class Program:
                     g.i[j] = v
                 if kw.get("split_out") is not None:
                     g.p[3] = addr(kw["split_out"])
-                self.op_names.append("stem:" + kw["key"])
+                wf = kw.get("warp")
+                if wf is not None:             # the input is gathered through the forward warp: x = the unwarped image, p[4] = the parameter records
+                    g.p[0], g.p[4] = addr(wf["x"]), addr(wf["p"])
+                    g.f[0], g.f[1], g.i[8] = wf["intr"].cx, wf["intr"].cy, wf["ac"]
+                self.op_names.append("stem:" + kw["key"] + ("+warp" if wf is not None else ""))
             elif kind == "maxpool":
                 x, y = kw["x"], kw["y"]
                 op.kind = L.OP_MAXPOOL

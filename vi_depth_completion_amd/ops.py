@@ -119,6 +119,20 @@ def stem_conv3x3s2(x_nchw, w_oihw, relu=True, split_out=None):
     return y
 
 
+def stem_conv3x3s2_warped(x_nchw, warp_params, w_oihw, cx, cy, align_corners=False, relu=True):
+    """The stem conv on the gravity-aligned forward warp of x, gathered on the fly (the warped image is never stored)."""
+    _dev(x_nchw, warp_params, w_oihw)
+    x, w = x_nchw.contiguous().float(), w_oihw.contiguous().float()
+    B, cin, H, W = x.shape
+    assert cin == 3
+    co = w.shape[0]
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((B, Ho, Wo, co), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vidc_stem_conv3x3s2_warped(L.ptr(x), L.ptr(warp_params), L.ptr(w), L.ptr(y), B, H, W, co, co, int(relu), None, 0, float(cx), float(cy),
+                                               int(align_corners), L.current_stream()), "stem (warped input)")
+    return y
+
+
 def maxpool3x3s2(x, split_out=None):
     _dev(x)
     x = x.contiguous()
