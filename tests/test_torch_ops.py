@@ -35,6 +35,7 @@ def test_shape_functions():
         w = torch.empty(128, 64, 3, 3)
         s = torch.empty(128)
         assert torch.ops.vidc.conv2d_bn_act(x, w, s, s, 2, 1, True, 1).shape == (2, 30, 40, 128)
+        assert torch.ops.vidc.conv3x3_winograd(x, w, s, s, 4, True, 0).shape == (2, 60, 80, 128)
         assert torch.ops.vidc.maxpool3x3s2(x).shape == (2, 30, 40, 64)
         assert torch.ops.vidc.upsample_bilinear_ac(x, 120, 160, False).shape == (2, 120, 160, 64)
         assert torch.ops.vidc.stem_conv3x3s2(torch.empty(2, 3, 240, 320), torch.empty(64, 3, 3, 3), True).shape == (2, 120, 160, 64)
@@ -119,6 +120,20 @@ def test_conv_op_matches_torch(precision, tol):
     ref = F.relu(F.conv2d(x, w, stride=2, padding=1) * scale[None, :, None, None] + shift[None, :, None, None])
     y = torch.ops.vidc.conv2d_bn_act(x.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda(), scale.cuda(), shift.cuda(), 2, 1, True, precision)
     assert y.shape == (2, 15, 20, 96)
+    assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max() < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [2, 4])
+@pytest.mark.parametrize("precision,tol", [(0, 2e-4), (1, 2e-3)])
+def test_winograd_conv_op_matches_torch(m, precision, tol):
+    x = S.normal01(8, "ops.x", (2, 64, 30, 41)).float()
+    w = S.normal01(8, "ops.w", (96, 64, 3, 3)).float() * (2.0 / (64 * 9)) ** 0.5
+    scale = 0.5 + S.uniform01(8, "ops.s", (96,)).float()
+    shift = 0.1 * S.normal01(8, "ops.b", (96,)).float()
+    ref = F.relu(F.conv2d(x, w, stride=1, padding=1) * scale[None, :, None, None] + shift[None, :, None, None])
+    y = torch.ops.vidc.conv3x3_winograd(x.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda(), scale.cuda(), shift.cuda(), m, True, precision)
+    assert y.shape == (2, 30, 41, 96)
     assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max() < tol
 
 

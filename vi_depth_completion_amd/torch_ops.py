@@ -11,6 +11,7 @@ the operators are the per-op surface for callers that compose the kernels with o
     torch.ops.vidc.warp2dof_fwd(x, g, a, fx, fy, cx, cy, align_corners)      warping_2dof_alignment.py:108-156
     torch.ops.vidc.warp2dof_inv_rot_norm(x, g, a, fx, fy, cx, cy, align_corners, normalize)   :216-255 (+ surface_normal.py:170)
     torch.ops.vidc.conv2d_bn_act(x_nhwc, w_oihw, scale, shift, stride, pad, relu, precision)  Conv2d+BatchNorm2d(eval)+ReLU
+    torch.ops.vidc.conv3x3_winograd(x_nhwc, w_oihw, scale, shift, m, relu, precision)         the 3x3 / stride-1 layers as Winograd F(m x m, 3x3)
     torch.ops.vidc.stem_conv3x3s2(x_nchw, w_oihw, relu)                       surface_normal.py:36 (conv1_1, no BN)
     torch.ops.vidc.maxpool3x3s2(x_nhwc)                                       torchvision ResNet.maxpool
     torch.ops.vidc.upsample_bilinear_ac(x_nhwc, Ho, Wo, relu)                 nn.UpsamplingBilinear2d (align_corners=True)
@@ -79,6 +80,21 @@ def _(x_nhwc, w_oihw, scale, shift, stride, pad, relu, precision):
     B, H, W, _c = x_nhwc.shape
     co, _ci, kh, kw = w_oihw.shape
     return x_nhwc.new_empty((B, (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1, co))
+
+
+@torch.library.custom_op("vidc::conv3x3_winograd", mutates_args=(), device_types=_DEV)
+def conv3x3_winograd(x_nhwc: torch.Tensor, w_oihw: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, m: int, relu: bool,
+                     precision: int) -> torch.Tensor:
+    """relu?(conv3x3(x, w, stride 1, pad 1) * scale + shift) as Winograd F(m x m, 3x3), m = 2 or 4: input transform, the a*a
+    transform-domain GEMMs as one grouped launch of the MFMA conv kernel, output transform with the epilogue (csrc/winograd.hip);
+    the form the networks' 3x3 layers run in where the measured table says so.  precision as in conv2d_bn_act."""
+    return _ops.conv3x3_winograd(x_nhwc, [w_oihw], scale.reshape(1, -1), shift.reshape(1, -1), m, relu1=relu, precision=precision)
+
+
+@conv3x3_winograd.register_fake
+def _(x_nhwc, w_oihw, scale, shift, m, relu, precision):
+    B, H, W, _c = x_nhwc.shape
+    return x_nhwc.new_empty((B, H, W, w_oihw.shape[0]))
 
 
 @torch.library.custom_op("vidc::stem_conv3x3s2", mutates_args=(), device_types=_DEV)
