@@ -138,6 +138,26 @@ def test_transforms_vs_restatement(m, shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("m", [2, 4])
+def test_transform_bits_do_not_depend_on_the_groups_sharing_the_launch(m):
+    """A frame program's first / drain ticks run the transforms restricted to one resp. three of the four pyramids
+    (engine.Program.group_variant): fewer channels per launch, hence the one-channel-per-thread instantiation where the full launch takes
+    four.  Both must round alike (csrc/winograd.hip compiles without mul + add contraction for that reason): group 0 alone == group 0 of 4."""
+    from vi_depth_completion_amd import ops
+    B, H, W, cin, cout, G = (1 if m == 2 else 4), 64, 80, 256, 256, 4      # one group: B*th*tw*(C/4) = 81920 < 131072 <= 327680: four groups
+    x = nhwc(S.normal01(31, "x", (B, G * cin, H, W)).float()).to(DEV)
+    a2 = (m + 2) ** 2
+    v4 = ops.winograd_input_transform(x, cin, m).view(-1, G, a2 * cin)
+    v1 = ops.winograd_input_transform(x[..., :cin].contiguous(), cin, m).view(-1, 1, a2 * cin)
+    assert torch.equal(v4[:, :1], v1)
+    mm = S.normal01(32, "mm", (v4.shape[0], G, a2 * cout)).float().to(DEV)
+    s1, b1 = S.uniform01(33, "s", (G, cout)).float().to(DEV) + 0.5, S.normal01(34, "b", (G, cout)).float().to(DEV)
+    y4 = ops.winograd_output_transform(mm.view(mm.shape[0], -1), B, H, W, cout, m, s1, b1, relu1=True)
+    y1 = ops.winograd_output_transform(mm[:, 0].contiguous(), B, H, W, cout, m, s1[:1], b1[:1], relu1=True)
+    assert torch.equal(y4[..., :cout], y1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [2, 4])
 @pytest.mark.parametrize("shape", WINO_SHAPES)
 def test_winograd_conv_vs_torch(m, shape):
     from vi_depth_completion_amd import ops

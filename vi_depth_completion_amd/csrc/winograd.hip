@@ -19,6 +19,12 @@
 // One thread = one tile x 4 consecutive channels (16-byte accesses, lanes along channels), x 1 channel on the small maps (vecn below).
 #include "common.h"
 
+// No mul + add contraction anywhere in this file: the transforms are instantiated per tile size and per channels-per-thread, the
+// restricted-group variants of a frame program (engine.Program.group_variant) pick another instantiation than the full launch for the
+// same layer, and hipcc contracts `a - 4 * b` into an fma in one instantiation and not in the other -- a frame's bits then depended on
+// which tick of a lane computed it (tests/test_frames_per_launch.py).  Every product and sum below rounds once, like the numpy oracle.
+#pragma clang fp contract(off)
+
 namespace {
 
 // N consecutive channels per thread: 4 (16-byte accesses) on maps large enough to fill the chip that way, 1 on the small maps (a 16x20
