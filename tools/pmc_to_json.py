@@ -66,7 +66,7 @@ def main():
         if kern not in alg:
             continue
         wkb = float(wk) if wk.lower() != "nan" else 0.0
-        table[kern] = {"round": 4, "program_batch": int(os.environ.get("VIDC_REPLAY_BATCH", "4")), "launches_per_tick": calls, "avg_us_under_counter_collection": us,
+        table[kern] = {"round": int(os.environ.get("VIDC_ROUND", "5")), "program_batch": int(os.environ.get("VIDC_REPLAY_BATCH", "4")), "launches_per_tick": calls, "avg_us_under_counter_collection": us,
                        "fetch_bytes": int(fk * 1024), "write_bytes": int(wkb * 1024), "traffic_bytes": int((fk + wkb) * 1024),
                        "algorithmic_bytes": int(alg[kern] / cnt[kern]), "traffic_over_algorithmic": round((fk + wkb) * 1024 / (alg[kern] / cnt[kern]), 3),
                        "mfma_busy_fraction": (round(float(busy) / 100.0, 4) if busy.lower() != "nan" else None),
