@@ -15,15 +15,61 @@ namespace {
 
 constexpr int TT = 256;
 
+// What the per-channel sums become, applied by the thread that finishes a channel in chan_final_kernel (no extra launch).
+// batch mean, biased variance and invstd from the two per-channel sums (shared by chan_final_kernel's FinalStats and the kernels that
+// fold that reduction into their prologue, so that both forms round identically)
+struct BnMoments { double mu, var; float mean, rstd; };
+__device__ inline BnMoments bn_moments(double s0, double s1, long long M, float eps) {
+    BnMoments r;
+    r.mu = s0 / (double)M;
+    r.var = s1 / (double)M - r.mu * r.mu;
+    if (r.var < 0.0) r.var = 0.0;
+    r.mean = (float)r.mu;
+    r.rstd = (float)(1.0 / sqrt(r.var + (double)eps));
+    return r;
+}
+__device__ inline void bn_update_running(float* running_mean, float* running_var, int c, const BnMoments& m, long long M, float momentum) {
+    const double unbiased = M > 1 ? m.var * (double)M / (double)(M - 1) : m.var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m.mu);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+}
+
+struct FinalStats {      // nn.BatchNorm2d.forward in train(): batch mean, biased variance, invstd = 1/sqrt(var + eps); running_mean/var <-
+    long long M;         // (1 - momentum) * old + momentum * (mean, unbiased var)
+    float eps, momentum;
+    float *mean, *rstd, *running_mean, *running_var;
+    __device__ void operator()(int c, double s0, double s1) const {
+        const BnMoments m = bn_moments(s0, s1, M, eps);
+        mean[c] = m.mean;
+        rstd[c] = m.rstd;
+        if (running_mean) bn_update_running(running_mean, running_var, c, m, M, momentum);
+    }
+};
+struct FinalParamGrad {  // dbeta = sum dy, dgamma = sum dy * xhat
+    float *dgamma, *dbeta;
+    __device__ void operator()(int c, double s0, double s1) const { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
+};
+struct FinalColsum {     // bias gradient of a conv: column sums of dY (first sum only)
+    float* out;
+    __device__ void operator()(int c, double s0, double) const { out[c] = (float)s0; }
+};
+
 // ---- per-channel sums over rows: partial[chunk][q][C] (fp64) -------------------------------------------------------------------------
 // block = 256 threads = 64 channels x 4 row-lanes; grid = (C/64 rounded up, n_chunks).  MODE 0: sum x, sum x^2.  MODE 1 (BN backward):
 // sum dy', sum dy' * xhat with dy' = dy * (y > 0) when y != NULL (the ReLU that followed the BatchNorm).
-template <int MODE>
+// `tickets` != NULL (round 5): no chan_final launch behind this kernel.  The workgroups of a 64-channel column take a ticket on the
+// column's counter after their chunk sums are out (relaxed agent-scope stores: coherent across the XCDs' L2s without a fence, like the
+// split-K partial tiles of csrc/conv_mfma.hip); the LAST one to arrive adds all chunks of the column up exactly as chan_final_kernel
+// does -- lane l takes chunks l, l + 32, ... in order, then the fixed pairwise tree over the 32 lanes -- applies `fin` and leaves the
+// counter at zero.  Same numbers in the same order: bit-identical to the two-launch form, whichever workgroup arrives last.
+template <int MODE, typename Final>
 __global__ void __launch_bounds__(TT)
 chan_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ y, long long M, int C, int lda, int ldb,
-                    int ldy, const float* __restrict__ mean, const float* __restrict__ rstd, int rows_per_chunk, double* __restrict__ partial) {
+                    int ldy, const float* __restrict__ mean, const float* __restrict__ rstd, int rows_per_chunk, double* __restrict__ partial,
+                    double* __restrict__ sums, unsigned* __restrict__ tickets, Final fin) {
     // block = 16 channel quads (64 channels, one float4 per thread and row) x 16 row-lanes; C % 4 == 0 and the strides % 4 == 0 (host-checked)
-    __shared__ double red[2][16][64];
+    __shared__ double red[2][32][64];      // (the partial phase uses [2][16][64]; the ticket tail all of it)
+    __shared__ int last_s;
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + cq * 4;
     const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
@@ -66,49 +112,63 @@ chan_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, co
             double t = 0.0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) t += red[q][j][l];
-            partial[((size_t)blockIdx.y * 2 + q) * C + cc] = t;
+            double* dst = partial + ((size_t)blockIdx.y * 2 + q) * C + cc;
+            if (tickets) __hip_atomic_store(dst, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = t;
+        }
+    }
+    if (!tickets) return;                          // (uniform over the launch)
+    // ---- ticket: ordering by completion -- every chunk-sum store of this workgroup has been acknowledged before the barrier in front of the ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int n_chunks = (int)gridDim.y;
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(tickets + blockIdx.x, 1u);
+        const bool last = t == (unsigned)(n_chunks - 1);
+        if (last) atomicExch(tickets + blockIdx.x, 0u);
+        last_s = last ? 1 : 0;
+    }
+    __syncthreads();
+    if (!*reinterpret_cast<volatile int*>(&last_s)) return;
+    {   // thread = channel l x 8 of chan_final's 32 lanes; lane j adds chunks j, j + 32, ... in order
+        const int l = threadIdx.x & 63, j0 = (threadIdx.x >> 6) * 8, cc = blockIdx.x * 64 + l;
+        double t0[8], t1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { t0[j] = 0.0; t1[j] = 0.0; }
+        if (cc < C)
+            for (int k0 = 0; k0 < n_chunks; k0 += 32) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = k0 + j0 + j;
+                    if (k < n_chunks) {
+                        t0[j] += __hip_atomic_load(partial + ((size_t)k * 2 + 0) * C + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        t1[j] += __hip_atomic_load(partial + ((size_t)k * 2 + 1) * C + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[0][j0 + j][l] = t0[j]; red[1][j0 + j][l] = t1[j]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {            // chan_final_kernel's tree: lane j += lane j + w for j < w
+        for (int i = threadIdx.x; i < w * 64; i += TT) {
+            const int j = i >> 6, l = i & 63;
+            red[0][j][l] += red[0][j + w][l];
+            red[1][j][l] += red[1][j + w][l];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 64) {
+        const int cc = blockIdx.x * 64 + threadIdx.x;
+        if (cc < C) {
+            const double a0 = red[0][0][threadIdx.x], a1 = red[1][0][threadIdx.x];
+            sums[cc] = a0;
+            sums[C + cc] = a1;
+            fin(cc, a0, a1);
         }
     }
 }
-
-// What the per-channel sums become, applied by the thread that finishes a channel in chan_final_kernel (no extra launch).
-// batch mean, biased variance and invstd from the two per-channel sums (shared by chan_final_kernel's FinalStats and the kernels that
-// fold that reduction into their prologue, so that both forms round identically)
-struct BnMoments { double mu, var; float mean, rstd; };
-__device__ inline BnMoments bn_moments(double s0, double s1, long long M, float eps) {
-    BnMoments r;
-    r.mu = s0 / (double)M;
-    r.var = s1 / (double)M - r.mu * r.mu;
-    if (r.var < 0.0) r.var = 0.0;
-    r.mean = (float)r.mu;
-    r.rstd = (float)(1.0 / sqrt(r.var + (double)eps));
-    return r;
-}
-__device__ inline void bn_update_running(float* running_mean, float* running_var, int c, const BnMoments& m, long long M, float momentum) {
-    const double unbiased = M > 1 ? m.var * (double)M / (double)(M - 1) : m.var;
-    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m.mu);
-    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
-}
-
-struct FinalStats {      // nn.BatchNorm2d.forward in train(): batch mean, biased variance, invstd = 1/sqrt(var + eps); running_mean/var <-
-    long long M;         // (1 - momentum) * old + momentum * (mean, unbiased var)
-    float eps, momentum;
-    float *mean, *rstd, *running_mean, *running_var;
-    __device__ void operator()(int c, double s0, double s1) const {
-        const BnMoments m = bn_moments(s0, s1, M, eps);
-        mean[c] = m.mean;
-        rstd[c] = m.rstd;
-        if (running_mean) bn_update_running(running_mean, running_var, c, m, M, momentum);
-    }
-};
-struct FinalParamGrad {  // dbeta = sum dy, dgamma = sum dy * xhat
-    float *dgamma, *dbeta;
-    __device__ void operator()(int c, double s0, double s1) const { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
-};
-struct FinalColsum {     // bias gradient of a conv: column sums of dY (first sum only)
-    float* out;
-    __device__ void operator()(int c, double s0, double) const { out[c] = (float)s0; }
-};
 
 // sums[q][C] = sum over chunks: block = 8 channels x 32 lanes; lane l adds chunks l, l+32, ... in order, then the 32 lane sums are added
 // pairwise (a fixed tree) -- bit-reproducible; `fin` then turns the two sums of a channel into the op's per-channel outputs
@@ -640,17 +700,36 @@ l1_loss_kernel(const float* __restrict__ pred, const float* __restrict__ gt, lon
 }
 
 // ---- Adam (torch.optim.Adam defaults: no weight decay, no amsgrad) on a flat parameter buffer -------------------------------------
+// One element; every product / sum / quotient rounds once (no contraction), so an element's bits do not depend on whether the four-wide
+// body or the scalar tail of the launch handled it (the flat layout -- and with it an element's position -- differs between the grouped
+// and the per-pyramid form of the step, tests/test_training.py compares their stepped parameters bit for bit).
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float b1, float b2, float c1, float c2, float eps, float step_size,
+                                         float bc2_sqrt) {
+    m = __fadd_rn(__fmul_rn(m, b1), __fmul_rn(g, c1));
+    v = __fadd_rn(__fmul_rn(v, b2), __fmul_rn(__fmul_rn(g, g), c2));
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), bc2_sqrt), eps);
+    p = __fsub_rn(p, __fmul_rn(step_size, __fdiv_rn(m, denom)));
+}
+// 28 bytes per parameter (p, g, m, v in; p, m, v out): one thread per four consecutive parameters (16-byte accesses), the n % 4 tail scalar
 __global__ void __launch_bounds__(TT)
 adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n, float lr, float b1, float b2,
             float eps, float bc1, float bc2_sqrt) {
-    const long long i = (long long)blockIdx.x * TT + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * TT + threadIdx.x) * 4;
     if (i >= n) return;
-    const float gi = g[i];
-    const float mi = m[i] * b1 + gi * (1.f - b1);
-    const float vi = v[i] * b2 + gi * gi * (1.f - b2);
-    m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - (lr / bc1) * (mi / denom);
+    const float c1 = 1.f - b1, c2 = 1.f - b2, step_size = lr / bc1;
+    if (i + 4 <= n) {
+        float4 pv = *reinterpret_cast<float4*>(p + i), mv = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+        const float4 gv = *reinterpret_cast<const float4*>(g + i);
+        adam_one(pv.x, gv.x, mv.x, vv.x, b1, b2, c1, c2, eps, step_size, bc2_sqrt);
+        adam_one(pv.y, gv.y, mv.y, vv.y, b1, b2, c1, c2, eps, step_size, bc2_sqrt);
+        adam_one(pv.z, gv.z, mv.z, vv.z, b1, b2, c1, c2, eps, step_size, bc2_sqrt);
+        adam_one(pv.w, gv.w, mv.w, vv.w, b1, b2, c1, c2, eps, step_size, bc2_sqrt);
+        *reinterpret_cast<float4*>(m + i) = mv;
+        *reinterpret_cast<float4*>(v + i) = vv;
+        *reinterpret_cast<float4*>(p + i) = pv;
+    } else {
+        for (long long k = i; k < n; ++k) adam_one(p[k], g[k], m[k], v[k], b1, b2, c1, c2, eps, step_size, bc2_sqrt);
+    }
 }
 
 // ---- dgrad helpers -------------------------------------------------------------------------------------------------------------
@@ -1192,7 +1271,7 @@ extern "C" size_t vidc_train_scratch_bytes(long long M, int C) {
 
 extern "C" int vidc_bn_train_forward_add(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
                                          float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
-                                         void* y_bf16, const float* residual, int ldr, void* scratch, vidc_stream_t stream) {
+                                         void* y_bf16, const float* residual, int ldr, void* tickets, void* scratch, vidc_stream_t stream) {
     VIDC_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && scratch, VIDC_ERR_NULL, "vidc_bn_train_forward: null pointer");
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || (ldr >= C && ldr % 4 == 0)),
                  VIDC_ERR_SHAPE, "vidc_bn_train_forward: bad shape");
@@ -1200,16 +1279,17 @@ extern "C" int vidc_bn_train_forward_add(const float* x, float* y, long long M, 
     const int nch = chunks_for(M, C);
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
-    hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, x, (const float*)nullptr, (const float*)nullptr, M, C, ldx, 0, 0,
-                       (const float*)nullptr, (const float*)nullptr, rows_for(M, C), partial);
+    const FinalStats fstats{M, eps, momentum, save_mean, save_rstd, running_mean, running_var};
+    unsigned* tk = fold_bn(M, C) ? nullptr : reinterpret_cast<unsigned*>(tickets);
+    hipLaunchKernelGGL((chan_partial_kernel<0, FinalStats>), dim3((C + 63) / 64, nch), dim3(TT), 0, st, x, (const float*)nullptr, (const float*)nullptr, M, C,
+                       ldx, 0, 0, (const float*)nullptr, (const float*)nullptr, rows_for(M, C), partial, sums, tk, fstats);
     if (fold_bn(M, C)) {
         hipLaunchKernelGGL(bn_apply_fold_kernel, dim3((unsigned)((M + 63) / 64), (C + 63) / 64), dim3(256), 0, st, x, y, (int)M, C, ldx, ldy, partial, nch, eps,
                            momentum, save_mean, save_rstd, running_mean, running_var, gamma, beta, relu, reinterpret_cast<unsigned short*>(y_bf16), residual, ldr);
         VIDC_CHECK_LAUNCH("bn_train_forward (folded)");
         return VIDC_OK;
     }
-    hipLaunchKernelGGL(chan_final_kernel<FinalStats>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums,
-                       FinalStats{M, eps, momentum, save_mean, save_rstd, running_mean, running_var});
+    if (!tk) hipLaunchKernelGGL(chan_final_kernel<FinalStats>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, fstats);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, x, y, M, C, ldx, ldy, save_mean, save_rstd, gamma, beta, relu,
                        reinterpret_cast<unsigned short*>(y_bf16), residual, ldr);
     VIDC_CHECK_LAUNCH("bn_train_forward");
@@ -1240,12 +1320,12 @@ extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int 
                                      float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
                                      void* y_bf16, void* scratch, vidc_stream_t stream) {
     return vidc_bn_train_forward_add(x, y, M, C, ldx, ldy, gamma, beta, running_mean, running_var, eps, momentum, relu, save_mean, save_rstd, y_bf16, nullptr, 0,
-                                     scratch, stream);
+                                     nullptr, scratch, stream);
 }
 
 extern "C" int vidc_bn_train_backward_t(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
                                         int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
-                                        void* dx_bf16, void* dx_bf16_t, int Mp, void* scratch, vidc_stream_t stream) {
+                                        void* dx_bf16, void* dx_bf16_t, int Mp, void* tickets, void* scratch, vidc_stream_t stream) {
     VIDC_REQUIRE(dy && x && gamma && save_mean && save_rstd && dgamma && dbeta && scratch, VIDC_ERR_NULL, "vidc_bn_train_backward: null pointer");
     VIDC_REQUIRE(dx || (dx_bf16 && dx_bf16_t), VIDC_ERR_NULL, "vidc_bn_train_backward: dx may be NULL only when both bf16 forms are written");
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!y_relu || ldy % 4 == 0), VIDC_ERR_SHAPE,
@@ -1256,7 +1336,9 @@ extern "C" int vidc_bn_train_backward_t(const float* dy, const float* x, const f
     const int nch = chunks_for(M, C);
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
-    hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean, save_rstd, rows_for(M, C), partial);
+    unsigned* tk = fold_bn(M, C) ? nullptr : reinterpret_cast<unsigned*>(tickets);
+    hipLaunchKernelGGL((chan_partial_kernel<1, FinalParamGrad>), dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean,
+                       save_rstd, rows_for(M, C), partial, sums, tk, FinalParamGrad{dgamma, dbeta});
     if (fold_bn(M, C)) {
         const int mp = dx_bf16_t ? Mp : (int)((M + 63) / 64 * 64);
         hipLaunchKernelGGL(bn_bwd_apply_t64_kernel<true>, dim3(mp / 64, (C + 63) / 64), dim3(256), 0, st, dy, x, y_relu, dx, (int)M, C, lddy, ldx, ldy, lddx,
@@ -1265,7 +1347,7 @@ extern "C" int vidc_bn_train_backward_t(const float* dy, const float* x, const f
         VIDC_CHECK_LAUNCH("bn_train_backward (folded)");
         return VIDC_OK;
     }
-    hipLaunchKernelGGL(chan_final_kernel<FinalParamGrad>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, FinalParamGrad{dgamma, dbeta});
+    if (!tk) hipLaunchKernelGGL(chan_final_kernel<FinalParamGrad>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, FinalParamGrad{dgamma, dbeta});
     if (dx_bf16_t)
         hipLaunchKernelGGL(bn_bwd_apply_t64_kernel<false>, dim3(Mp / 64, (C + 63) / 64), dim3(256), 0, st, dy, x, y_relu, dx, (int)M, C, lddy, ldx, ldy, lddx, save_mean,
                            save_rstd, gamma, sums, reinterpret_cast<unsigned short*>(dx_bf16), reinterpret_cast<unsigned short*>(dx_bf16_t), Mp, 0,
@@ -1280,19 +1362,21 @@ extern "C" int vidc_bn_train_backward_t(const float* dy, const float* x, const f
 extern "C" int vidc_bn_train_backward(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
                                       int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                                       void* dx_bf16, void* scratch, vidc_stream_t stream) {
-    return vidc_bn_train_backward_t(dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, gamma, save_mean, save_rstd, dgamma, dbeta, dx_bf16, nullptr, 0, scratch, stream);
+    return vidc_bn_train_backward_t(dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, gamma, save_mean, save_rstd, dgamma, dbeta, dx_bf16, nullptr, 0, nullptr, scratch,
+                                    stream);
 }
 
-extern "C" int vidc_colsum(const float* dy, long long M, int C, int ld, float* out, void* scratch, vidc_stream_t stream) {
+extern "C" int vidc_colsum(const float* dy, long long M, int C, int ld, float* out, void* tickets, void* scratch, vidc_stream_t stream) {
     VIDC_REQUIRE(dy && out && scratch, VIDC_ERR_NULL, "vidc_colsum: null pointer");
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0, VIDC_ERR_SHAPE, "vidc_colsum: bad shape (C and ld multiples of 4)");
     hipStream_t st = vidc::as_stream(stream);
     const int nch = chunks_for(M, C);
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
-    hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, (const float*)nullptr, (const float*)nullptr, M, C, ld, 0, 0,
-                       (const float*)nullptr, (const float*)nullptr, rows_for(M, C), partial);
-    hipLaunchKernelGGL(chan_final_kernel<FinalColsum>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, FinalColsum{out});
+    unsigned* tk = reinterpret_cast<unsigned*>(tickets);
+    hipLaunchKernelGGL((chan_partial_kernel<0, FinalColsum>), dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, (const float*)nullptr, (const float*)nullptr, M, C, ld,
+                       0, 0, (const float*)nullptr, (const float*)nullptr, rows_for(M, C), partial, sums, tk, FinalColsum{out});
+    if (!tk) hipLaunchKernelGGL(chan_final_kernel<FinalColsum>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, FinalColsum{out});
     VIDC_CHECK_LAUNCH("colsum");
     return VIDC_OK;
 }
@@ -1394,7 +1478,9 @@ extern "C" int vidc_adam_step(float* p, const float* g, float* m, float* v, long
     VIDC_REQUIRE(p && g && m && v, VIDC_ERR_NULL, "vidc_adam_step: null pointer");
     VIDC_REQUIRE(n > 0 && step >= 1, VIDC_ERR_SHAPE, "vidc_adam_step: bad arguments");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks(n)), dim3(TT), 0, vidc::as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1,
+    VIDC_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0,
+                 VIDC_ERR_SHAPE, "vidc_adam_step: the four buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks((n + 3) / 4)), dim3(TT), 0, vidc::as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1,
                        (float)sqrt(bc2));
     VIDC_CHECK_LAUNCH("adam_kernel");
     return VIDC_OK;
