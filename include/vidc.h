@@ -472,12 +472,7 @@ int vidc_bn_train_forward(const float* x, float* y, long long M, int C, int ldx,
  * the BatchNorm value is rounded to fp32 before the sum, so the result equals vidc_bn_train_forward followed by vidc_add_rows. */
 int vidc_bn_train_forward_add(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
-                              void* y_bf16, const float* residual, int ldr, void* tickets, void* scratch, vidc_stream_t stream);
-/* `tickets` (vidc_bn_train_forward_add, vidc_bn_train_backward_t, vidc_colsum; may be NULL): (C + 63) / 64 unsigned counters, ZERO before
- * the first call and left at zero by every call, owned by the caller's stream (two launches in flight at the same time need two arrays).
- * With it the per-channel sums are finished by the last workgroup of each 64-channel column of the partial-sum kernel (a ticket per
- * column, as the split-K tiles of vidc_conv2d_bn_act are) instead of by a launch of their own: one launch less per call, the same numbers
- * added in the same order -- results are bit-identical with and without. */
+                              void* y_bf16, const float* residual, int ldr, void* scratch, vidc_stream_t stream);
 /* vidc_bn_train_forward_add for an x that is the output of a conv launched with VIDC_STATS_OUT: `conv_stats` = that conv's partials
  * (ceil(M / 32) x 2 x C doubles); the partial-sum pass over x is skipped.  scratch: 2 * C doubles. */
 int vidc_bn_train_forward_stats(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
@@ -494,9 +489,9 @@ int vidc_bn_train_backward(const float* dy, const float* x, const float* y_relu,
  * both bf16 forms are written (a stride-1 conv without bias reads its dY only through them). */
 int vidc_bn_train_backward_t(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
                              int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
-                             void* dx_bf16, void* dx_bf16_t, int Mp, void* tickets, void* scratch, vidc_stream_t stream);
+                             void* dx_bf16, void* dx_bf16_t, int Mp, void* scratch, vidc_stream_t stream);
 /* out[c] = sum over rows of dy[.][c]: the bias gradient of a convolution. */
-int vidc_colsum(const float* dy, long long M, int C, int ld, float* out, void* tickets, void* scratch, vidc_stream_t stream);
+int vidc_colsum(const float* dy, long long M, int C, int ld, float* out, void* scratch, vidc_stream_t stream);
 /* y = a + b, ReLU optional (Bottleneck: relu(bn3(conv3(.)) + identity); decoder: z1 + z2 + z3 + z4). */
 int vidc_add_rows(const float* a, const float* b, float* y, long long M, int C, int lda, int ldb, int ldy, int relu, vidc_stream_t stream);
 /* The same; y_bf16 (may be NULL): additionally the result rounded to bf16 as dense rows of C values (the operand copy the next convs of a

@@ -85,11 +85,11 @@ SIGNATURES = {
     "vidc_conv2d_plan": (C.c_int, [C.POINTER(ConvDesc)]),
     "vidc_train_scratch_bytes": (C.c_size_t, [C.c_longlong, _i]),
     "vidc_bn_train_forward": (C.c_int, [_vp, _vp, C.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
-    "vidc_bn_train_forward_add": (C.c_int, [_vp, _vp, C.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "vidc_bn_train_forward_add": (C.c_int, [_vp, _vp, C.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "vidc_bn_train_forward_stats": (C.c_int, [_vp, _vp, C.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "vidc_bn_train_backward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "vidc_bn_train_backward_t": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
-    "vidc_colsum": (C.c_int, [_vp, C.c_longlong, _i, _i, _vp, _vp, _vp, _vp]),
+    "vidc_bn_train_backward_t": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "vidc_colsum": (C.c_int, [_vp, C.c_longlong, _i, _i, _vp, _vp, _vp]),
     "vidc_add_rows": (C.c_int, [_vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp]),
     "vidc_add_rows_bf16": (C.c_int, [_vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp, _vp]),
     "vidc_relu_backward": (C.c_int, [_vp, _vp, _vp, C.c_longlong, _i, _i, _i, _i, _i, _vp]),

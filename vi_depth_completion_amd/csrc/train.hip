@@ -54,22 +54,52 @@ struct FinalColsum {     // bias gradient of a conv: column sums of dY (first su
     __device__ void operator()(int c, double s0, double) const { out[c] = (float)s0; }
 };
 
+// The chunk sums of a 64-channel column added up exactly as chan_final_kernel adds them -- lane j takes chunks j, j + 32, ... in order,
+// then the fixed pairwise tree over the 32 lanes -- by the 256 threads of ONE workgroup: thread = channel l x 8 of the 32 lanes, the 16
+// loads of a round issued together, the tree through LDS.  Result: red[q][0][l].  Used by the kernels that fold the final reduction into
+// their prologue (bn_apply_fold_kernel, bn_bwd_apply_t64_kernel<true>).  Bit-identical to chan_final_kernel.
+__device__ __forceinline__ void column_sums(const double* __restrict__ partial, int n_chunks, int C, int c0, double (*red)[32][64]) {
+    const int l = threadIdx.x & 63, j0 = (threadIdx.x >> 6) * 8, cc = c0 + l;
+    double t0[8], t1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { t0[j] = 0.0; t1[j] = 0.0; }
+    if (cc < C)
+        for (int k0 = 0; k0 < n_chunks; k0 += 32) {
+            double u0[8], u1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = min(k0 + j0 + j, n_chunks - 1);
+                const double* src = partial + ((size_t)k * 2) * C + cc;
+                u0[j] = src[0];
+                u1[j] = src[C];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j0 + j < n_chunks) { t0[j] += u0[j]; t1[j] += u1[j]; }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][j0 + j][l] = t0[j]; red[1][j0 + j][l] = t1[j]; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {            // chan_final_kernel's tree: lane j += lane j + w for j < w
+        for (int i = threadIdx.x; i < w * 64; i += TT) {
+            const int j = i >> 6, ll = i & 63;
+            red[0][j][ll] += red[0][j + w][ll];
+            red[1][j][ll] += red[1][j + w][ll];
+        }
+        __syncthreads();
+    }
+}
+
 // ---- per-channel sums over rows: partial[chunk][q][C] (fp64) -------------------------------------------------------------------------
 // block = 256 threads = 64 channels x 4 row-lanes; grid = (C/64 rounded up, n_chunks).  MODE 0: sum x, sum x^2.  MODE 1 (BN backward):
 // sum dy', sum dy' * xhat with dy' = dy * (y > 0) when y != NULL (the ReLU that followed the BatchNorm).
-// `tickets` != NULL (round 5): no chan_final launch behind this kernel.  The workgroups of a 64-channel column take a ticket on the
-// column's counter after their chunk sums are out (relaxed agent-scope stores: coherent across the XCDs' L2s without a fence, like the
-// split-K partial tiles of csrc/conv_mfma.hip); the LAST one to arrive adds all chunks of the column up exactly as chan_final_kernel
-// does -- lane l takes chunks l, l + 32, ... in order, then the fixed pairwise tree over the 32 lanes -- applies `fin` and leaves the
-// counter at zero.  Same numbers in the same order: bit-identical to the two-launch form, whichever workgroup arrives last.
-template <int MODE, typename Final>
+template <int MODE>
 __global__ void __launch_bounds__(TT)
 chan_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ y, long long M, int C, int lda, int ldb,
-                    int ldy, const float* __restrict__ mean, const float* __restrict__ rstd, int rows_per_chunk, double* __restrict__ partial,
-                    double* __restrict__ sums, unsigned* __restrict__ tickets, Final fin) {
+                    int ldy, const float* __restrict__ mean, const float* __restrict__ rstd, int rows_per_chunk, double* __restrict__ partial) {
     // block = 16 channel quads (64 channels, one float4 per thread and row) x 16 row-lanes; C % 4 == 0 and the strides % 4 == 0 (host-checked)
-    __shared__ double red[2][32][64];      // (the partial phase uses [2][16][64]; the ticket tail all of it)
-    __shared__ int last_s;
+    __shared__ double red[2][16][64];
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + cq * 4;
     const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
@@ -112,60 +142,7 @@ chan_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, co
             double t = 0.0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) t += red[q][j][l];
-            double* dst = partial + ((size_t)blockIdx.y * 2 + q) * C + cc;
-            if (tickets) __hip_atomic_store(dst, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else *dst = t;
-        }
-    }
-    if (!tickets) return;                          // (uniform over the launch)
-    // ---- ticket: ordering by completion -- every chunk-sum store of this workgroup has been acknowledged before the barrier in front of the ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int n_chunks = (int)gridDim.y;
-    if (threadIdx.x == 0) {
-        const unsigned t = atomicAdd(tickets + blockIdx.x, 1u);
-        const bool last = t == (unsigned)(n_chunks - 1);
-        if (last) atomicExch(tickets + blockIdx.x, 0u);
-        last_s = last ? 1 : 0;
-    }
-    __syncthreads();
-    if (!*reinterpret_cast<volatile int*>(&last_s)) return;
-    {   // thread = channel l x 8 of chan_final's 32 lanes; lane j adds chunks j, j + 32, ... in order
-        const int l = threadIdx.x & 63, j0 = (threadIdx.x >> 6) * 8, cc = blockIdx.x * 64 + l;
-        double t0[8], t1[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { t0[j] = 0.0; t1[j] = 0.0; }
-        if (cc < C)
-            for (int k0 = 0; k0 < n_chunks; k0 += 32) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = k0 + j0 + j;
-                    if (k < n_chunks) {
-                        t0[j] += __hip_atomic_load(partial + ((size_t)k * 2 + 0) * C + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        t1[j] += __hip_atomic_load(partial + ((size_t)k * 2 + 1) * C + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { red[0][j0 + j][l] = t0[j]; red[1][j0 + j][l] = t1[j]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int w = 16; w >= 1; w >>= 1) {            // chan_final_kernel's tree: lane j += lane j + w for j < w
-        for (int i = threadIdx.x; i < w * 64; i += TT) {
-            const int j = i >> 6, l = i & 63;
-            red[0][j][l] += red[0][j + w][l];
-            red[1][j][l] += red[1][j + w][l];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < 64) {
-        const int cc = blockIdx.x * 64 + threadIdx.x;
-        if (cc < C) {
-            const double a0 = red[0][0][threadIdx.x], a1 = red[1][0][threadIdx.x];
-            sums[cc] = a0;
-            sums[C + cc] = a1;
-            fin(cc, a0, a1);
+            partial[((size_t)blockIdx.y * 2 + q) * C + cc] = t;
         }
     }
 }
@@ -196,44 +173,22 @@ __global__ void __launch_bounds__(TT) chan_final_kernel(const double* __restrict
     }
 }
 
-// The chunk sums of one channel added up exactly as chan_final_kernel adds them (lane l takes chunks l, l + 32, ... in order, then the
-// fixed pairwise tree over the 32 lanes), by ONE thread: the kernels below fold that reduction into their prologue -- every workgroup
-// redoes it for its 64 channels from the L2-resident partials -- which removes the chan_final launch between the partial-sum kernel and
-// its consumer (a 5 us kernel at its launch floor, twice per BatchNorm and step) without any cross-workgroup hand-off.  Bit-identical.
-__device__ inline double fold_chunk_sums(const double* __restrict__ partial, int n_chunks, int C, int q, int c) {
-    double lane[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) lane[i] = 0.0;
-    for (int k0 = 0; k0 < n_chunks; k0 += 32) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i)
-            if (k0 + i < n_chunks) lane[i] += partial[((size_t)(k0 + i) * 2 + q) * C + c];
-    }
-#pragma unroll
-    for (int w = 16; w >= 1; w >>= 1) {
-#pragma unroll
-        for (int i = 0; i < w; ++i) lane[i] += lane[i + w];
-    }
-    return lane[0];
-}
-
+// The kernels below fold the final reduction into their prologue -- every workgroup redoes it for its 64 channels from the L2-resident
+// chunk sums (column_sums) -- which removes the chan_final launch between the partial-sum kernel and its consumer without any
+// cross-workgroup hand-off.  Bit-identical.
 // chan_final<FinalStats> + bn_apply_kernel in one launch: 64 pixels x 64 channels per workgroup (the layout of bn_bwd_apply_t64_kernel).
 __global__ void __launch_bounds__(256)
 bn_apply_fold_kernel(const float* __restrict__ x, float* __restrict__ y, int M, int C, int ldx, int ldy, const double* __restrict__ partial, int n_chunks,
                      float eps, float momentum, float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ running_mean,
                      float* __restrict__ running_var, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
                      unsigned short* __restrict__ y_bf16, const float* __restrict__ res, int ldr) {
-    __shared__ double sum_s[2][64];
+    __shared__ double red[2][32][64];
     __shared__ float mean_s[64], rstd_s[64];
     const int c0 = blockIdx.y * 64, m0 = blockIdx.x * 64;
-    if (threadIdx.x < 128) {
-        const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
-        sum_s[q][l] = c0 + l < C ? fold_chunk_sums(partial, n_chunks, C, q, c0 + l) : 0.0;
-    }
-    __syncthreads();
+    column_sums(partial, n_chunks, C, c0, red);
     if (threadIdx.x < 64) {
         const int l = threadIdx.x, cc = c0 + l;
-        const BnMoments mo = bn_moments(sum_s[0][l], sum_s[1][l], (long long)M, eps);
+        const BnMoments mo = bn_moments(red[0][0][l], red[1][0][l], (long long)M, eps);
         mean_s[l] = mo.mean; rstd_s[l] = mo.rstd;
         if (blockIdx.x == 0 && cc < C) {         // one workgroup per channel block publishes what the backward and the module keep
             save_mean[cc] = mo.mean; save_rstd[cc] = mo.rstd;
@@ -339,7 +294,7 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, c
 // (vidc_im2col_transposed(..., KH = KW = 1, split = 2) -- one launch and one pass over dY per conv that this kernel makes unnecessary).
 // LDS tile [pixel][channel], pitch 65 floats, both phases as in im2col_t64_kernel; every value is rounded once, from the fp32 result.
 // FOLD: `sums` holds the CHUNK sums of chan_partial_kernel<1> (n_chunks of them) and the workgroup adds them up itself for its 64 channels
-// (fold_chunk_sums: chan_final's order); the workgroups of the first pixel block write dgamma / dbeta.  dx_bf16_t may then be NULL (no
+// (column_sums: chan_final's order); the workgroups of the first pixel block write dgamma / dbeta.  dx_bf16_t may then be NULL (no
 // transposed copy wanted): the kernel is the folded form of bn_bwd_apply_kernel as well.
 template <bool FOLD>
 __global__ void __launch_bounds__(256)
@@ -347,16 +302,20 @@ bn_bwd_apply_t64_kernel(const float* __restrict__ dy, const float* __restrict__ 
                         int lddy, int ldx, int ldy, int lddx, const float* __restrict__ mean, const float* __restrict__ rstd,
                         const float* __restrict__ gamma, const double* __restrict__ sums, unsigned short* __restrict__ dx_bf16,
                         unsigned short* __restrict__ dx_bf16_t, int Mp, int n_chunks, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float tile[64][65];
+    // (FOLD: the reduction scratch [2][32][64] doubles and the transpose tile [64][65] floats share the same LDS, one after the other)
+    __shared__ __attribute__((aligned(16))) unsigned char raw_s[FOLD ? 2 * 32 * 64 * 8 : 64 * 65 * 4];
     __shared__ double sum_s[2][64];
+    float (*tile)[65] = reinterpret_cast<float (*)[65]>(raw_s);
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int c = c0 + tx * 4;
     const double invM = 1.0 / (double)M;
     if (FOLD) {
+        double (*red)[32][64] = reinterpret_cast<double (*)[32][64]>(raw_s);
+        column_sums(sums, n_chunks, C, c0, red);
         if (threadIdx.x < 128) {
             const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
-            const double t = c0 + l < C ? fold_chunk_sums(sums, n_chunks, C, q, c0 + l) : 0.0;
+            const double t = c0 + l < C ? red[q][0][l] : 0.0;
             sum_s[q][l] = t;
             if (blockIdx.x == 0 && c0 + l < C) (q ? dgamma : dbeta)[c0 + l] = (float)t;      // FinalParamGrad: dbeta = sum dy', dgamma = sum dy' * xhat
         }
@@ -700,15 +659,17 @@ l1_loss_kernel(const float* __restrict__ pred, const float* __restrict__ gt, lon
 }
 
 // ---- Adam (torch.optim.Adam defaults: no weight decay, no amsgrad) on a flat parameter buffer -------------------------------------
-// One element; every product / sum / quotient rounds once (no contraction), so an element's bits do not depend on whether the four-wide
-// body or the scalar tail of the launch handled it (the flat layout -- and with it an element's position -- differs between the grouped
-// and the per-pyramid form of the step, tests/test_training.py compares their stepped parameters bit for bit).
+// One element; every product / sum / quotient rounds once (contraction off: HIP's __fmul_rn / __fadd_rn are plain operators that hipcc
+// may still fuse), so an element's bits do not depend on whether the four-wide body or the scalar tail of the launch handled it (the flat
+// layout -- and with it an element's position -- differs between the grouped and the per-pyramid form of the step, and
+// tests/test_training.py compares their stepped parameters bit for bit).
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float b1, float b2, float c1, float c2, float eps, float step_size,
                                          float bc2_sqrt) {
-    m = __fadd_rn(__fmul_rn(m, b1), __fmul_rn(g, c1));
-    v = __fadd_rn(__fmul_rn(v, b2), __fmul_rn(__fmul_rn(g, g), c2));
-    const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), bc2_sqrt), eps);
-    p = __fsub_rn(p, __fmul_rn(step_size, __fdiv_rn(m, denom)));
+#pragma clang fp contract(off)
+    m = m * b1 + g * c1;
+    v = v * b2 + (g * g) * c2;
+    const float denom = __fsqrt_rn(v) / bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
 }
 // 28 bytes per parameter (p, g, m, v in; p, m, v out): one thread per four consecutive parameters (16-byte accesses), the n % 4 tail scalar
 __global__ void __launch_bounds__(TT)
@@ -1248,11 +1209,12 @@ inline unsigned blocks(long long n) { return (unsigned)((n + TT - 1) / TT); }
 // The final reduction of a BatchNorm's chunk sums inside the consuming kernel's prologue (bn_apply_fold_kernel, bn_bwd_apply_t64_kernel<true>)
 // instead of a chan_final launch: every 64 x 64 workgroup re-reads n_chunks x 64 x 2 doubles, so it is only offered where pixel blocks x
 // chunks is small -- the ResNet-101 layer-3 / layer-4 maps and the coarse decoder levels, three quarters of a step's BatchNorms.  Same sums,
-// same order, same bits (tests/test_training.py), and MEASURED SLOWER on MI355X: 29.2 against 27.5 ms per batch-8 bf16 step, 70.9 against
-// 69.0 in fp32 (round 4, same box, alternating runs).  The chunk sums were written by workgroups on all eight XCDs, so the prologue's reads
-// miss the consumer's own L2 and wait on the fabric (~2 us per dependent batch of loads, three batches for 75 chunks) -- more than the 5 us
-// launch they replace, and every workgroup of the consumer pays it instead of the one small kernel.  Hence OFF by default; the switch
-// (vidc_train_bn_fold, VIDC_TRAIN_BN_FOLD=1) stays for measurements.
+// same order, same bits (tests/test_training.py).  Round 4 (one thread per channel, 32 dependent loads each): 29.2 against 27.5 ms per
+// batch-8 bf16 step.  Round 5 (column_sums: all 256 threads, 16 loads in flight per thread): 26.2-26.3 against 26.15 ms with per-pyramid
+// lanes, 27.2 against 27.3 ms grouped -- level, as is finishing the sums by the last workgroup of each channel column of the partial-sum
+// kernel (a ticket per column, tried and removed: 26.6-26.7 / 27.8 ms).  A captured step hides the 5 us chan_final launches; nothing is
+// gained by removing them (profiles/r5_train_reduction_forms_ab.txt).  Hence OFF by default; the switch (vidc_train_bn_fold,
+// VIDC_TRAIN_BN_FOLD=1) stays for measurements.
 int g_bn_fold = 0;
 inline bool fold_bn(long long M, int C) {
     return g_bn_fold && M < (1ll << 31) && ((M + 63) / 64) * (long long)chunks_for(M, C) <= 4096;
@@ -1271,7 +1233,7 @@ extern "C" size_t vidc_train_scratch_bytes(long long M, int C) {
 
 extern "C" int vidc_bn_train_forward_add(const float* x, float* y, long long M, int C, int ldx, int ldy, const float* gamma, const float* beta,
                                          float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
-                                         void* y_bf16, const float* residual, int ldr, void* tickets, void* scratch, vidc_stream_t stream) {
+                                         void* y_bf16, const float* residual, int ldr, void* scratch, vidc_stream_t stream) {
     VIDC_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && scratch, VIDC_ERR_NULL, "vidc_bn_train_forward: null pointer");
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || (ldr >= C && ldr % 4 == 0)),
                  VIDC_ERR_SHAPE, "vidc_bn_train_forward: bad shape");
@@ -1279,17 +1241,16 @@ extern "C" int vidc_bn_train_forward_add(const float* x, float* y, long long M, 
     const int nch = chunks_for(M, C);
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
-    const FinalStats fstats{M, eps, momentum, save_mean, save_rstd, running_mean, running_var};
-    unsigned* tk = fold_bn(M, C) ? nullptr : reinterpret_cast<unsigned*>(tickets);
-    hipLaunchKernelGGL((chan_partial_kernel<0, FinalStats>), dim3((C + 63) / 64, nch), dim3(TT), 0, st, x, (const float*)nullptr, (const float*)nullptr, M, C,
-                       ldx, 0, 0, (const float*)nullptr, (const float*)nullptr, rows_for(M, C), partial, sums, tk, fstats);
+    hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, x, (const float*)nullptr, (const float*)nullptr, M, C, ldx, 0, 0,
+                       (const float*)nullptr, (const float*)nullptr, rows_for(M, C), partial);
     if (fold_bn(M, C)) {
         hipLaunchKernelGGL(bn_apply_fold_kernel, dim3((unsigned)((M + 63) / 64), (C + 63) / 64), dim3(256), 0, st, x, y, (int)M, C, ldx, ldy, partial, nch, eps,
                            momentum, save_mean, save_rstd, running_mean, running_var, gamma, beta, relu, reinterpret_cast<unsigned short*>(y_bf16), residual, ldr);
         VIDC_CHECK_LAUNCH("bn_train_forward (folded)");
         return VIDC_OK;
     }
-    if (!tk) hipLaunchKernelGGL(chan_final_kernel<FinalStats>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, fstats);
+    hipLaunchKernelGGL(chan_final_kernel<FinalStats>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums,
+                       FinalStats{M, eps, momentum, save_mean, save_rstd, running_mean, running_var});
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks(M * (C / 4))), dim3(TT), 0, st, x, y, M, C, ldx, ldy, save_mean, save_rstd, gamma, beta, relu,
                        reinterpret_cast<unsigned short*>(y_bf16), residual, ldr);
     VIDC_CHECK_LAUNCH("bn_train_forward");
@@ -1320,12 +1281,12 @@ extern "C" int vidc_bn_train_forward(const float* x, float* y, long long M, int 
                                      float* running_mean, float* running_var, float eps, float momentum, int relu, float* save_mean, float* save_rstd,
                                      void* y_bf16, void* scratch, vidc_stream_t stream) {
     return vidc_bn_train_forward_add(x, y, M, C, ldx, ldy, gamma, beta, running_mean, running_var, eps, momentum, relu, save_mean, save_rstd, y_bf16, nullptr, 0,
-                                     nullptr, scratch, stream);
+                                     scratch, stream);
 }
 
 extern "C" int vidc_bn_train_backward_t(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
                                         int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
-                                        void* dx_bf16, void* dx_bf16_t, int Mp, void* tickets, void* scratch, vidc_stream_t stream) {
+                                        void* dx_bf16, void* dx_bf16_t, int Mp, void* scratch, vidc_stream_t stream) {
     VIDC_REQUIRE(dy && x && gamma && save_mean && save_rstd && dgamma && dbeta && scratch, VIDC_ERR_NULL, "vidc_bn_train_backward: null pointer");
     VIDC_REQUIRE(dx || (dx_bf16 && dx_bf16_t), VIDC_ERR_NULL, "vidc_bn_train_backward: dx may be NULL only when both bf16 forms are written");
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!y_relu || ldy % 4 == 0), VIDC_ERR_SHAPE,
@@ -1336,9 +1297,7 @@ extern "C" int vidc_bn_train_backward_t(const float* dy, const float* x, const f
     const int nch = chunks_for(M, C);
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
-    unsigned* tk = fold_bn(M, C) ? nullptr : reinterpret_cast<unsigned*>(tickets);
-    hipLaunchKernelGGL((chan_partial_kernel<1, FinalParamGrad>), dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean,
-                       save_rstd, rows_for(M, C), partial, sums, tk, FinalParamGrad{dgamma, dbeta});
+    hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, x, y_relu, M, C, lddy, ldx, ldy, save_mean, save_rstd, rows_for(M, C), partial);
     if (fold_bn(M, C)) {
         const int mp = dx_bf16_t ? Mp : (int)((M + 63) / 64 * 64);
         hipLaunchKernelGGL(bn_bwd_apply_t64_kernel<true>, dim3(mp / 64, (C + 63) / 64), dim3(256), 0, st, dy, x, y_relu, dx, (int)M, C, lddy, ldx, ldy, lddx,
@@ -1347,7 +1306,7 @@ extern "C" int vidc_bn_train_backward_t(const float* dy, const float* x, const f
         VIDC_CHECK_LAUNCH("bn_train_backward (folded)");
         return VIDC_OK;
     }
-    if (!tk) hipLaunchKernelGGL(chan_final_kernel<FinalParamGrad>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, FinalParamGrad{dgamma, dbeta});
+    hipLaunchKernelGGL(chan_final_kernel<FinalParamGrad>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, FinalParamGrad{dgamma, dbeta});
     if (dx_bf16_t)
         hipLaunchKernelGGL(bn_bwd_apply_t64_kernel<false>, dim3(Mp / 64, (C + 63) / 64), dim3(256), 0, st, dy, x, y_relu, dx, (int)M, C, lddy, ldx, ldy, lddx, save_mean,
                            save_rstd, gamma, sums, reinterpret_cast<unsigned short*>(dx_bf16), reinterpret_cast<unsigned short*>(dx_bf16_t), Mp, 0,
@@ -1362,21 +1321,19 @@ extern "C" int vidc_bn_train_backward_t(const float* dy, const float* x, const f
 extern "C" int vidc_bn_train_backward(const float* dy, const float* x, const float* y_relu, float* dx, long long M, int C, int lddy, int ldx, int ldy,
                                       int lddx, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                                       void* dx_bf16, void* scratch, vidc_stream_t stream) {
-    return vidc_bn_train_backward_t(dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, gamma, save_mean, save_rstd, dgamma, dbeta, dx_bf16, nullptr, 0, nullptr, scratch,
-                                    stream);
+    return vidc_bn_train_backward_t(dy, x, y_relu, dx, M, C, lddy, ldx, ldy, lddx, gamma, save_mean, save_rstd, dgamma, dbeta, dx_bf16, nullptr, 0, scratch, stream);
 }
 
-extern "C" int vidc_colsum(const float* dy, long long M, int C, int ld, float* out, void* tickets, void* scratch, vidc_stream_t stream) {
+extern "C" int vidc_colsum(const float* dy, long long M, int C, int ld, float* out, void* scratch, vidc_stream_t stream) {
     VIDC_REQUIRE(dy && out && scratch, VIDC_ERR_NULL, "vidc_colsum: null pointer");
     VIDC_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0, VIDC_ERR_SHAPE, "vidc_colsum: bad shape (C and ld multiples of 4)");
     hipStream_t st = vidc::as_stream(stream);
     const int nch = chunks_for(M, C);
     double* partial = reinterpret_cast<double*>(scratch);
     double* sums = partial + (size_t)nch * 2 * C;
-    unsigned* tk = reinterpret_cast<unsigned*>(tickets);
-    hipLaunchKernelGGL((chan_partial_kernel<0, FinalColsum>), dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, (const float*)nullptr, (const float*)nullptr, M, C, ld,
-                       0, 0, (const float*)nullptr, (const float*)nullptr, rows_for(M, C), partial, sums, tk, FinalColsum{out});
-    if (!tk) hipLaunchKernelGGL(chan_final_kernel<FinalColsum>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, FinalColsum{out});
+    hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, nch), dim3(TT), 0, st, dy, (const float*)nullptr, (const float*)nullptr, M, C, ld, 0, 0,
+                       (const float*)nullptr, (const float*)nullptr, rows_for(M, C), partial);
+    hipLaunchKernelGGL(chan_final_kernel<FinalColsum>, dim3((C + 7) / 8), dim3(TT), 0, st, partial, nch, C, sums, FinalColsum{out});
     VIDC_CHECK_LAUNCH("colsum");
     return VIDC_OK;
 }

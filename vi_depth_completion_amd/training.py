@@ -256,10 +256,6 @@ class DepthCompletionTrainer:
         # Round 4: the train-mode BatchNorm behind a conv takes its per-channel sums from the conv's epilogue (VIDC_STATS_OUT, plain-bf16 mode)
         # instead of a partial-sum pass of its own over the conv output: one launch and one read of the tensor less per conv + BatchNorm.
         self.conv_stats = os.environ.get("VIDC_TRAIN_CONV_STATS", "1") == "1"
-        # Round 5: the per-channel sums of the BatchNorm backward (and of the BatchNorms / bias gradients without conv statistics) are finished
-        # by the last workgroup of each channel column of the partial-sum kernel (a ticket per column) instead of by a chan_final launch
-        self.bn_tickets = os.environ.get("VIDC_TRAIN_BN_TICKETS", "1") == "1"
-        self._ticket_bufs = {}
         self.conv_stats_max_m = int(os.environ.get("VIDC_TRAIN_CONV_STATS_MAX_M", str(1 << 30)))
         if "VIDC_TRAIN_BN_FOLD" in os.environ:   # (A/B runs) the BatchNorm chunk sums reduced in the consumer's prologue (default) or by a launch of their own
             L.lib().vidc_train_bn_fold(int(os.environ["VIDC_TRAIN_BN_FOLD"] != "0"))
@@ -327,16 +323,6 @@ class DepthCompletionTrainer:
         if self._lanes is None:
             self._lanes = [torch.cuda.Stream(device=self.device) for _ in range(4)]
         return self._lanes
-
-    def _tickets(self):
-        """The lane's column counters of the per-channel reductions (include/vidc.h `tickets`: zero before the first call, left at zero by
-        every call; one array per stream lane because the lanes' launches are in flight together).  None: the two-launch form."""
-        if not self.bn_tickets:
-            return None
-        t = self._ticket_bufs.get(self._cur)
-        if t is None:
-            t = self._ticket_bufs[self._cur] = torch.zeros(1024, dtype=torch.int32, device=self.device)      # up to 65536 channels
-        return L.ptr(t)
 
     def _train_scratch(self, M, Cc):
         return self._scratch_bytes(L.lib().vidc_train_scratch_bytes(M, Cc))
@@ -591,8 +577,8 @@ class DepthCompletionTrainer:
                         L.check(lib.vidc_conv_wgrad(L.ptr(g[..., gi * co:(gi + 1) * co]), L.ptr(x.t[..., gi * ci:(gi + 1) * ci]), L.ptr(self.grad[k + ".weight"]), B, H, W,
                                                     ci, x.ld, Ho, Wo, co, _ld(g), kh, kw, stride, pad, L.ptr(sc), L.current_stream()), "wgrad")
                 if bias is not None:
-                    L.check(lib.vidc_colsum(L.ptr(g), y.rows, co, _ld(g), L.ptr(self.grad[keys[0] + ".bias"]), self._tickets(),
-                                            L.ptr(self._train_scratch(y.rows, co)), L.current_stream()), "colsum")
+                    L.check(lib.vidc_colsum(L.ptr(g), y.rows, co, _ld(g), L.ptr(self.grad[keys[0] + ".bias"]), L.ptr(self._train_scratch(y.rows, co)),
+                                            L.current_stream()), "colsum")
 
             self._beside(weight_and_bias_gradient)
             if x.grad is False:                              # network input: no data gradient wanted
@@ -643,8 +629,7 @@ class DepthCompletionTrainer:
             L.check(L.lib().vidc_bn_train_forward_add(L.ptr(x.t), L.ptr(y.t), x.rows, Cc, x.ld, y.ld, L.ptr(gamma), L.ptr(beta), L.ptr(run_mean),
                                                       L.ptr(run_var), BN_EPS, BN_MOMENTUM, int(relu), L.ptr(mean), L.ptr(rstd),
                                                       L.ptr(y.bf) if y.bf is not None else None, L.ptr(residual.t) if residual is not None else None,
-                                                      residual.ld if residual is not None else 0, self._tickets(), L.ptr(self._train_scratch(x.rows, Cc)),
-                                                      L.current_stream()), "bn_forward")
+                                                      residual.ld if residual is not None else 0, L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_forward")
         self._nbt += [self.buf[k + ".num_batches_tracked"] for k in keys]
         y_in = y               # what the BatchNorm part of the backward takes dy from
         if residual is not None:
@@ -677,7 +662,7 @@ class DepthCompletionTrainer:
                                                      x.rows, Cc, _ld(y_in.grad), x.ld, y.ld,
                                                      Cc, L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(g_gamma), L.ptr(g_beta),
                                                      L.ptr(tbf) if tbf is not None else None, L.ptr(tbt) if tbt is not None else None, Mp,
-                                                     self._tickets(), L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_backward")
+                                                     L.ptr(self._train_scratch(x.rows, Cc)), L.current_stream()), "bn_backward")
             if acc:
                 self._accumulate(x, target)
             else:
