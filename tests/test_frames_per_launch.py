@@ -85,6 +85,24 @@ def test_item_bits_do_not_depend_on_partner_slot_lanes_or_tail(pipe_mode, F):
         pipe.rng = saved
 
 
+def test_split_launches_of_their_own_in_the_grouped_stream(seeded_weights, monkeypatch):
+    """VIDC_FUSE_SPLIT=0 (the split-bf16 operand images written by split launches instead of by the producing kernels' epilogues): the
+    first / drain ticks of a lane (engine.Program.group_variant) must still build the images of the groups they compute -- same bits
+    as the default form, ragged tail and two lanes included."""
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    monkeypatch.setenv("VIDC_PRECISION", "mixed")
+    frames = _frames(380, 5)
+    outs = {}
+    for fs in ("1", "0"):
+        monkeypatch.setenv("VIDC_FUSE_SPLIT", fs)
+        p = DepthCompletionPipeline(enriched_samples=200)        # (a pipeline of its own: programs are recorded once per pipeline)
+        p.load_state_dicts(seeded_weights["sn"], seeded_weights["dc"])
+        p.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(240, 320))
+        outs[fs] = [o.cpu() for o in p.run_interleaved(iter(frames), lanes=2, frames_per_launch=2, frame_rng=lambda i: np.random.RandomState(40 + i))]
+        del p
+    assert len(outs["0"]) == 5 and all(torch.equal(a, b) for a, b in zip(outs["1"], outs["0"]))
+
+
 def test_three_items_per_launch_and_batched_items(seeded_weights, monkeypatch):
     """F = 3 (a program of batch 3) and items that are batches themselves (B = 2, F = 2: a program of batch 4): same properties."""
     monkeypatch.setenv("VIDC_PRECISION", "mixed")

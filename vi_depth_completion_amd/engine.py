@@ -942,7 +942,8 @@ class Program:
                     picked.append(i)
                 continue
             grouped = (kind in ("conv", "wino_out") and len(kw["keys"]) == groups) or (kind in ("maxpool", "wino_in") and kw["x"].G == groups)
-            if grouped or keep_ungrouped:
+            # (a split launch of its own -- VIDC_FUSE_SPLIT=0 -- over a grouped tensor has no row stride for its image: it runs whole in every variant)
+            if grouped or keep_ungrouped or (kind == "split" and kw["x"].G == groups):
                 picked.append(i)
         ops = (L.Op * len(picked))()
         for j, i in enumerate(picked):
