@@ -314,14 +314,18 @@ def measure(args, dev, rank, world, precision):
         n_long = args.steady_frames if args.steady_frames > 0 else 16 * grp
         n_long = max(6 * grp, n_long // grp * grp)
         evs = []
+        from vi_depth_completion_amd import ops as _ops
+        stamps = _ops.clock_stamps(n_long, dev)
         for _out in pipe.run_interleaved(frames(n_long), copy_outputs=False, lanes=lanes, frames_per_launch=args.frames_per_launch):
             e = torch.cuda.Event(enable_timing=True)
             e.record()                                  # the caller's stream has just been made to wait for this item's result
+            _ops.clock_stamp(stamps, len(evs))          # ... and a (shader cycles, 100 MHz ticks) stamp behind it: the clock under this load
             evs.append(e)
         torch.cuda.synchronize()
         i0, i1 = 2 * grp - 1, n_long - 2 * grp - 1      # last items of two groups, two groups away from either end
         ms = evs[i0].elapsed_time(evs[i1])
-        steady = {"frames_per_s": round((i1 - i0) * B / (ms * 1e-3), 2), "frames": n_long,
+        ghz = _ops.shader_clock_ghz(stamps, i0, i1)
+        steady = {"frames_per_s": round((i1 - i0) * B / (ms * 1e-3), 2), "frames": n_long, "shader_clock_ghz": (round(ghz, 3) if ghz else None),
                   "what": "device time stamps (HIP events on the caller's stream behind every item's result) of one untimed stream of %d items: items "
                           "%d..%d / elapsed device time -- the K-step regions above additionally contain the fill and the drain of the pipeline" % (n_long, i0, i1)}
 
@@ -705,6 +709,19 @@ def main():
             "roofline": lead["roofline"], "cpu_baseline": cpu_baseline,
         }
         line.update(lead["extra"])
+        if main_mode == "fp32" and (lead["steady"] or {}).get("shader_clock_ghz"):
+            # The nominal fp32 MFMA peak assumes 2.4 GHz; under the stream's mix of MFMA, LDS and HBM traffic the chip clocks lower (stamps behind
+            # every item of the steady-state stream, include/vidc.h vidc_clock_stamp).  `roofline.frac` stays against the nominal peak; this is
+            # the executed conv FLOP/s against the peak any kernel could reach at the clock the chip actually held.
+            ghz = lead["steady"]["shader_clock_ghz"]
+            peak_s = PEAK_F32_MFMA_TFLOPS * ghz / 2.4
+            ex = lead["extra"]["conv_stack"]["at_measured_frame_rate"]["tflops_executed"]
+            line["sustained_clock"] = {
+                "shader_clock_ghz": ghz, "nominal_ghz": 2.4, "fp32_mfma_peak_at_that_clock_tflops": round(peak_s, 1),
+                "conv_stack_frac_of_that_peak": round(ex / peak_s, 4),
+                "conv_stack_frac_of_that_peak_steady_state": round(lead["extra"]["conv_stack"]["executed_gflop_per_frame"] * lead["steady"]["frames_per_s"] / 1e3 / peak_s, 4),
+                "note": "average shader clock between the two items that bound the steady-state window (an idle XCD's counter hardly advances, so gaps pull it down): difference of the shader-cycle counter over the "
+                        "difference of the 100 MHz wall clock, written per XCD by a stamp kernel behind each item's result (median over the XCDs)"}
         for m in legs[1:]:
             jm, rm = jobs[m], res[m]
             line.update({

@@ -37,6 +37,13 @@ enum vidc_status {
 int vidc_version(void);               /* ABI version, currently 1 */
 const char* vidc_last_error(void);    /* thread-local, never NULL */
 int vidc_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
+/* Measurement aid (bench.py; no reference counterpart): VIDC_CLOCK_STAMP_WGS single-thread workgroups (one per XCD of a fresh dispatch)
+ * each write out[4 * wg + 0..3] = {XCC id it ran on, shader-clock cycle counter, 100 MHz wall clock, 1} (device buffer of
+ * 4 * VIDC_CLOCK_STAMP_WGS int64).  The cycle counters of the XCDs have unrelated offsets, so two stamps are compared per XCC id:
+ * (cycles_b - cycles_a) / (ticks_b - ticks_a) x 0.1 = the average shader clock in GHz between them -- what the nominal MFMA peak (quoted
+ * at 2.4 GHz) scales by under load. */
+#define VIDC_CLOCK_STAMP_WGS 8
+int vidc_clock_stamp(long long* out, vidc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 2-DoF gravity-aligned warp        (networks/warping_2dof_alignment.py)

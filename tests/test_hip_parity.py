@@ -1080,3 +1080,24 @@ def test_use_mask_branch(golden_dir, seeded_weights):
     sn.use_mask = False
     sn._invalidate()
     assert float((sn(b["image"].to(DEV), g.to(DEV), a.to(DEV)).cpu() - n).abs().max()) > 0.5      # the branch matters on this frame
+
+
+def test_clock_stamps_give_a_plausible_shader_clock():
+    """vidc_clock_stamp (bench.py's roofline context): two stamps around a stretch of GPU work give a shader clock between 0.5 GHz and the
+    2.4 GHz the nominal MFMA peak assumes (+ boost margin); bad buffers are refused."""
+    from vi_depth_completion_amd import ops
+    stamps = ops.clock_stamps(2, DEV)
+    x = torch.randn(4096, 4096, device=DEV)
+    for _ in range(3):                       # (library start-up outside the window: an idle XCD's counter hardly advances)
+        x = x @ x * 1e-3
+    torch.cuda.synchronize()
+    ops.clock_stamp(stamps, 0)
+    for _ in range(20):
+        x = x @ x * 1e-3
+    ops.clock_stamp(stamps, 1)
+    torch.cuda.synchronize()
+    ghz = ops.shader_clock_ghz(stamps, 0, 1)
+    assert ghz is not None and 0.5 < ghz < 2.6, ghz
+    assert sorted(int(v) for v in stamps[0, :, 0].cpu()) == list(range(8)), "one stamp workgroup per XCD"
+    with pytest.raises(RuntimeError):
+        ops.clock_stamp(torch.zeros((2, 2), dtype=torch.int64), 0)

@@ -16,6 +16,7 @@ MAX_HYP = 300
 PLANE_RECORD = 16
 MAX_STREAMS = 4
 MAX_SEGMENTS = 4
+CLOCK_STAMP_WGS = 8      # VIDC_CLOCK_STAMP_WGS
 
 # vidc_conv_flags / vidc_up_flags / vidc_op_kind / vidc_conv_tile
 RELU1, AFFINE2, RELU2, RESIDUAL, RELU3, ACCUM, SPLIT_OUT, NO_F32_OUT, STATS_OUT, X_PLANAR_GROUPS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
@@ -98,6 +99,7 @@ SIGNATURES = {
     "vidc_head_backward_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "vidc_head_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vidc_masked_l1_loss": (C.c_int, [_vp, _vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vidc_clock_stamp": (C.c_int, [_vp, _vp]),
     "vidc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, _f, _f, _f, _f, _i, _vp]),
     "vidc_train_bn_fold": (C.c_int, [_i]),
     "vidc_grad_narrow_bf16": (C.c_int, [_vp, _vp, C.c_longlong, _vp]),

@@ -262,3 +262,25 @@ def conv3x3_winograd(x, w_oihw_groups, scale1, shift1, m, relu1=False, scale2=No
         d.workspace = L.ptr(ws)
     L.check(L.lib().vidc_conv2d_bn_act(C.byref(d), L.current_stream()), "conv2d_bn_act (winograd GEMMs)")
     return winograd_output_transform(mm, B, H, W, cout, m, scale1, shift1, relu1, scale2, shift2, relu2, split_out, no_f32_out)
+
+
+def clock_stamps(n, device=None):
+    """Buffer for n stamps of `clock_stamp`."""
+    return torch.zeros((n, L.CLOCK_STAMP_WGS, 4), dtype=torch.int64, device=device if device is not None else "cuda")
+
+
+def clock_stamp(stamps, i):
+    """Enqueues stamp i on the current stream (include/vidc.h vidc_clock_stamp): per XCD the shader-clock cycle counter and the 100 MHz wall
+    clock.  `shader_clock_ghz(stamps, a, b)` turns two stamps into the average shader clock between them."""
+    if not stamps.is_cuda or stamps.dtype != torch.int64 or tuple(stamps.shape[1:]) != (L.CLOCK_STAMP_WGS, 4) or not stamps.is_contiguous():
+        raise RuntimeError("clock_stamp: a buffer made by ops.clock_stamps is required")
+    L.check(L.lib().vidc_clock_stamp(stamps.data_ptr() + 8 * 4 * L.CLOCK_STAMP_WGS * int(i), L.current_stream()), "clock_stamp")
+
+
+def shader_clock_ghz(stamps, a, b):
+    """Median over the XCDs present in both stamps of (cycle difference) / (100 MHz tick difference) x 0.1; None if they share no XCD."""
+    h = stamps.cpu()
+    sa = {int(r[0]): (int(r[1]), int(r[2])) for r in h[a] if int(r[3]) == 1}
+    sb = {int(r[0]): (int(r[1]), int(r[2])) for r in h[b] if int(r[3]) == 1}
+    ghz = sorted((sb[x][0] - sa[x][0]) / (sb[x][1] - sa[x][1]) * 0.1 for x in sa if x in sb and sb[x][1] > sa[x][1] and sb[x][0] > sa[x][0])
+    return ghz[len(ghz) // 2] if ghz else None
