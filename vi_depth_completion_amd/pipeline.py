@@ -6,6 +6,7 @@ same input-batch dictionary (dataset.py:515-520), same output (B,1,H,W) depth te
 (network_run.py:319-323, main.py:256-259).  See INTEGRATION.md for how the unchanged main.py/network_run.py bind to it.
 """
 import argparse
+import os
 import weakref
 
 import numpy as np
@@ -533,7 +534,8 @@ def _lane_stream(device, index):
     key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), index)
     st = _LANE_STREAMS.get(key)
     if st is None:
-        st = _LANE_STREAMS[key] = torch.cuda.Stream(device=device)
+        pr = [int(v) for v in os.environ.get("VIDC_LANE_PRIORITIES", "").split(",") if v.strip()]      # (experiment: HIP stream priority per lane)
+        st = _LANE_STREAMS[key] = torch.cuda.Stream(device=device, priority=(pr[index] if index < len(pr) else 0))
     return st
 
 
