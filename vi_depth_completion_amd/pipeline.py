@@ -534,8 +534,9 @@ def _lane_stream(device, index):
     key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), index)
     st = _LANE_STREAMS.get(key)
     if st is None:
-        pr = [int(v) for v in os.environ.get("VIDC_LANE_PRIORITIES", "").split(",") if v.strip()]      # (experiment: HIP stream priority per lane)
-        st = _LANE_STREAMS[key] = torch.cuda.Stream(device=device, priority=(pr[index] if index < len(pr) else 0))
+        # (HIP stream priorities per lane -- a favoured first lane to shorten the fill of a short stream -- measured: the 20-step rate is
+        #  unchanged and the steady-state rate drops 658 -> 594-629 frames/s, profiles/r5_lane_priorities.txt; all lanes at the default priority)
+        st = _LANE_STREAMS[key] = torch.cuda.Stream(device=device)
     return st
 
 
