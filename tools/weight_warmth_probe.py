@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--top", type=int, default=12)
     ap.add_argument("--precision", default="mixed")
     ap.add_argument("--copies", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="program batch (4 = what bench.py's stream mode records)")
+    ap.add_argument("--sigs", default="", help="comma-separated substrings: only signatures containing one of them")
     a = ap.parse_args()
     os.environ["VIDC_PRECISION"] = a.precision
     dev = torch.device("cuda")
@@ -39,7 +41,7 @@ def main():
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)
     st = side.cuda_stream
-    prog = build_frame_program(pipe.surface_normal_cnn, pipe.cnn, 1, H, W, dev)
+    prog = build_frame_program(pipe.surface_normal_cnn, pipe.cnn, a.batch, H, W, dev)
     prog.run()
     torch.cuda.synchronize()
     _total, per = prog.time(iters=5, use_graph=False, per_op=True)
@@ -48,6 +50,8 @@ def main():
         if op.kind != L.OP_CONV:
             continue
         sig = name.split(" ")[1]
+        if a.sigs and not any(pt in sig for pt in a.sigs.split(",") if pt):
+            continue
         e = by_sig.setdefault(sig, [0.0, 0, op, name])
         e[0] += t
         e[1] += 1
