@@ -24,6 +24,12 @@
 extern "C" {
 #endif
 
+/* libvidc.so is built with -fvisibility=hidden: the entry points declared between this push and the pop at the end of the file are the
+ * library's ONLY dynamic symbols (tests/test_abi.py compares `nm -D` with this file). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 typedef void* vidc_stream_t; /* hipStream_t */
 
 enum vidc_status {
@@ -631,6 +637,10 @@ int vidc_program_launch_segment(vidc_program* p, vidc_stream_t stream, int segme
  * and (if per_op_ms != NULL, eager mode) per-op average durations. */
 int vidc_program_time(vidc_program* p, vidc_stream_t stream, int iters, int use_graph, float* ms_out, float* per_op_ms);
 int vidc_program_destroy(vidc_program* p);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

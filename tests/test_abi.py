@@ -28,6 +28,12 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, name), name
     assert lib.vidc_version() == 1
     assert lib.vidc_last_error() is not None
+    # ... and NOTHING else: the library is linked with -fvisibility=hidden and csrc/vidc.map, so template instantiations, kernel handles and
+    # the per-TU hip symbols stay local (VERDICT r5 hygiene: `_ZNSt6vectorI7vidc_op...` used to be a dynamic symbol)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "vi_depth_completion_amd", "libvidc.so")], capture_output=True, text=True, check=True)
+    exported = {ln.split()[-1] for ln in nm.stdout.splitlines() if ln.strip()}
+    assert exported == declared, sorted(exported ^ declared)
 
 
 def test_struct_layout_matches_header():
@@ -169,7 +175,9 @@ def test_opt_in_warp_fusion_rewrites_the_program(lib, monkeypatch):
     stems = [kw for k, _, _, kw in fp.ops if k == "stem"]
     assert [kw.get("warp") is not None for kw in stems] == [True, False, False, False] and stems[0]["key"].startswith("sn/")
     i = kinds.index("stem")
-    assert fp.c_ops[i].u.g.p[4] != 0 or True      # (dry run: buffers are planned, the record pointer is set)
+    g, wf = fp.c_ops[i].u.g, stems[0]["warp"]      # engine.finalize -> program.hip launch_op: the record pointer, the principal point, the convention
+    assert g.p[4] == fp.storage[wf["p"].buf].data_ptr() + 4 * wf["p"].ch_off and g.p[0] == fp.storage[wf["x"].buf].data_ptr() + 4 * wf["x"].ch_off
+    assert (g.f[0], g.f[1], g.i[8]) == (np.float32(wf["intr"].cx), np.float32(wf["intr"].cy), int(wf["ac"]))
 
 
 def test_frame_program_structure(recorded_frame_program, recorded_programs):

@@ -2,6 +2,7 @@
 // upsample, and the prediction-head tail (1x1 conv with few outputs as a wavefront reduction + final upsample).
 // All NHWC fp32 with 16-byte per-lane accesses where the layout allows.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -12,7 +13,7 @@ namespace {
 // surface_normal.py:163) and the patch loader gathers it on the fly -- one projective map and one bilinear tap set per patch pixel, shared
 // by the CIN channels, the very code of warp_fwd_kernel (vidc::warp_fwd_taps / vidc::sample), so the patch holds the bits that kernel would
 // have stored.  The warped image is never written: one launch and a 2 x 3HW x 4 byte round trip less per frame.
-template <int CIN, bool WARP>
+template <int CIN, bool WARP, int LOADS = 0>
 __global__ void __launch_bounds__(256)
 stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int H, int W, int Ho, int Wo,
                  int Cout, int ldy, int relu, unsigned short* __restrict__ ysp, int ch0, const float* __restrict__ warp_params, float wcx, float wcy,
@@ -32,7 +33,18 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
         // computed with the last frame's homography, nondeterministically, only with >= 2 lanes, never eagerly) -- the scalar cache is not
         // reliably invalidated between two kernel nodes of a captured graph.
         __shared__ float wp[VIDC_WARP_PARAMS];
-        if (tid < VIDC_WARP_PARAMS) wp[tid] = __builtin_nontemporal_load(warp_params + (size_t)b * VIDC_WARP_PARAMS + tid);
+        // LOADS (debug builds of the launch only, VIDC_DBG_STEM_LOADS): bit 0 = the record through wave-uniform plain reads (s_load), bit 1 = the
+        // image through plain loads, bit 2 = an explicit buffer_inv sc0 sc1 first.  0 is what ships; 3 is the round-5 form.
+        if constexpr (LOADS & 4) asm volatile("buffer_inv sc0 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (LOADS & 1) {
+            const float* rp = warp_params + (size_t)b * VIDC_WARP_PARAMS;
+            if (tid < VIDC_WARP_PARAMS) {
+                float v = 0.f;
+#pragma unroll
+                for (int k = 0; k < VIDC_WARP_PARAMS; ++k) v = (tid == k) ? rp[k] : v;
+                wp[tid] = v;
+            }
+        } else if (tid < VIDC_WARP_PARAMS) wp[tid] = __builtin_nontemporal_load(warp_params + (size_t)b * VIDC_WARP_PARAMS + tid);
         __syncthreads();
         for (int e = tid; e < 3 * PW; e += 256) {
             const int r = e / PW, i = e - r * PW;
@@ -45,7 +57,7 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
             // nondeterministic 1e-3 differences in the depth map of one frame in ten, traced to 400-800 wrong words of this kernel's output;
             // the image is rewritten by a device-to-device copy before every launch; 8 of 8 runs clean with these loads, 6 of 8 dirty
             // without).  The stand-alone warp kernel reading the same buffer has never shown it (its reads are banded per XCD).
-#if 1
+            if constexpr (!(LOADS & 2)) {
 #pragma unroll
             for (int c = 0; c < CIN; ++c) {
                 float v = 0.f;
@@ -57,17 +69,38 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
                 }
                 patch[c][r][i] = v;
             }
-#else
+            } else if constexpr ((LOADS >> 3) == 0) {
 #pragma unroll
             for (int c = 0; c < CIN; ++c) patch[c][r][i] = in ? vidc::sample(xb + c * plane, t) : 0.f;
-#endif
+            } else {
+            // (experiments of round 6, profiles/EXPERIMENTS.md: other flavours of the four tap loads -- LOADS >> 3 = 1 nontemporal, 2 plain with a
+            //  full vmcnt wait behind every channel, 3 agent-scope atomic, 4 volatile)
+            constexpr int FL = LOADS >> 3;
+            auto ld = [](const float* p) -> float {
+                if constexpr (FL == 1) return __builtin_nontemporal_load(p);
+                else if constexpr (FL == 3) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if constexpr (FL == 4) return *reinterpret_cast<const volatile float*>(p);
+                else return *p;
+            };
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                float v = 0.f;
+                if (in) {
+                    const float* pl = xb + c * plane;
+                    const float a00 = ld(pl + t.o00), a01 = ld(pl + t.o01), a10 = ld(pl + t.o10), a11 = ld(pl + t.o11);
+                    if constexpr (FL == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    v = fmaf(a11, t.w11, fmaf(a10, t.w10, fmaf(a01, t.w01, a00 * t.w00)));
+                }
+                patch[c][r][i] = v;
+            }
+            }
         }
     } else {
         for (int e = tid; e < CIN * 3 * PW; e += 256) {
             int c = e / (3 * PW), r = (e / PW) % 3, i = e % PW;
             int iy = iy_base + r, ix = ix_base + i;
             float v = 0.f;
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[c * plane + (size_t)iy * W + ix];
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = __builtin_nontemporal_load(xb + c * plane + (size_t)iy * W + ix);      // (rewritten every tick: common.h sample_nt)
             patch[c][r][i] = v;
         }
     }
@@ -341,7 +374,19 @@ int stem_launch(const float* x, const float* w_oihw, float* y, int B, int Cin, i
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     dim3 grid(vidc::cdiv(Wo, 64), Ho, B);
     hipStream_t st = vidc::as_stream(stream);
-    if (warp_params)
+    // VIDC_DBG_STEM_LOADS (debug / test control only; bits as in the kernel): 3 = the round-5 form with plain loads, 7 = that behind a buffer_inv
+    static const int dbg_loads = [] { const char* e = getenv("VIDC_DBG_STEM_LOADS"); return e ? atoi(e) : 0; }();
+#define VIDC_STEM_DBG(L_) hipLaunchKernelGGL((stem_conv_kernel<3, true, L_>), grid, dim3(256), 0, st, x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0, warp_params, cx, cy, align_corners)
+    if (warp_params && dbg_loads == 1) VIDC_STEM_DBG(1);
+    else if (warp_params && dbg_loads == 2) VIDC_STEM_DBG(2);
+    else if (warp_params && dbg_loads == 3) VIDC_STEM_DBG(3);
+    else if (warp_params && dbg_loads == 7) VIDC_STEM_DBG(7);
+    else if (warp_params && dbg_loads == 10) VIDC_STEM_DBG(10);
+    else if (warp_params && dbg_loads == 18) VIDC_STEM_DBG(18);
+    else if (warp_params && dbg_loads == 26) VIDC_STEM_DBG(26);
+    else if (warp_params && dbg_loads == 34) VIDC_STEM_DBG(34);
+#undef VIDC_STEM_DBG
+    else if (warp_params)
         hipLaunchKernelGGL((stem_conv_kernel<3, true>), grid, dim3(256), 0, st, x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0, warp_params, cx, cy, align_corners);
     else if (Cin == 3)
         hipLaunchKernelGGL((stem_conv_kernel<3, false>), grid, dim3(256), 0, st, x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0, warp_params, cx, cy, align_corners);

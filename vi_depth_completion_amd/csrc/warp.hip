@@ -115,7 +115,7 @@ warp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ params, f
     const size_t plane = (size_t)H * W;
     const float* xb = x + (size_t)b * C * plane;
     float* yb = y + (size_t)b * C * plane + pix;
-    for (int c = 0; c < C; ++c) yb[c * plane] = sample(xb + c * plane, t);
+    for (int c = 0; c < C; ++c) yb[c * plane] = vidc::sample_nt(xb + c * plane, t);      // (x: rewritten by a copy before every launch -- common.h)
 }
 
 __global__ void __launch_bounds__(256)
@@ -141,7 +141,7 @@ warp_inv_rot_norm_kernel(const float* __restrict__ x, const float* __restrict__ 
     Taps t = make_taps(u, v, cx, cy, W, H, align_corners);
     const size_t plane = (size_t)H * W;
     const float* xb = x + (size_t)b * 3 * plane;
-    float y0 = sample(xb, t), y1 = sample(xb + plane, t), y2 = sample(xb + 2 * plane, t);
+    float y0 = vidc::sample_nt(xb, t), y1 = vidc::sample_nt(xb + plane, t), y2 = vidc::sample_nt(xb + 2 * plane, t);      // (x: the head's output of this tick)
     // z = R^T y  (C_R_Cg.bmm(y), warping_2dof_alignment.py:253)
     float z0 = p[9] * y0 + p[12] * y1 + p[15] * y2;
     float z1 = p[10] * y0 + p[13] * y1 + p[16] * y2;

@@ -196,8 +196,8 @@ def _capped_tile(tile, cap_kb):
 
 def winograd_mode():
     """VIDC_WINOGRAD=auto : (default) 3x3 / stride 1 / pad 1 convs with >= 128 input channels run as Winograd F(m x m, 3x3) GEMMs
-                             (csrc/winograd.hip): the entry "W:<direct signature>" of the measured table picks m in {0, 2, 4}, else
-                             m = 4 on maps of at least 24 rows and columns and m = 2 below.
+                             (csrc/winograd.hip): the entry "W:<direct signature>" of the measured table picks m in {0, 2, 4}, else (fp32 mode
+                             only) m = 4 on maps of at least 24 rows and columns and m = 2 below; the mixed mode without a table entry stays direct.
        VIDC_WINOGRAD=0 / 2 / 4 : never / always that m where the layer qualifies (tests, A/B runs)."""
     return os.environ.get("VIDC_WINOGRAD", "auto")
 
@@ -217,7 +217,10 @@ def winograd_choice(B, H, W, co, ci, kh, kw, stride, padding, dilation, G, mode=
                 break
         if ent is not None:
             m = int(ent[1 if precision == "mixed" else 0]) if isinstance(ent, (list, tuple)) else int(ent)
-        elif ci < 128:
+        elif ci < 128 or precision == "mixed":
+            # no measured verdict for this shape.  fp32: the heuristic below.  mixed: the direct form -- in the committed table the bf16x3
+            # direct conv beats the transform + GEMM + transform triple for 73 of 112 layers (three launches and two HBM round trips through
+            # V and M against a conv that is cheap already), so an untuned resolution or batch must not default to the slower form
             m = 0
         else:
             m = 4 if min(H, W) >= 24 else 2
