@@ -155,7 +155,13 @@ enum vidc_conv_tile { VIDC_TILE_AUTO = 0, VIDC_TILE_128x128 = 1, VIDC_TILE_128x6
                        * first k-half of the next stage across the stage barrier (bf16x3 / bf16; fp32 operands run the _L form) */
                       VIDC_TILE_128x128_D4_P = 33, VIDC_TILE_128x128_D3_P = 34, VIDC_TILE_64x64_D4_P = 35, VIDC_TILE_128x64_D4_P = 36,
                       VIDC_TILE_64x64_K2_D4_P = 37, VIDC_TILE_64x32_K2_D5_P = 38, VIDC_TILE_32x64_K2_D5_P = 39,
-                      VIDC_TILE_COUNT = 40 };
+                      /* grouped GEMMs with at most 96 rows (the Winograd-domain products of the small maps): fp32, 1x1 / stride 1, flags <= RELU1,
+                         p_gs == 0, Cin % 64 == 0, Cin >= 128.  One workgroup streams a chunk of consecutive groups of one 32-channel n-tile through a
+                         continuous LDS ring (csrc/wgemm.hip); `splitk` = number of group chunks (<= 1: automatic), no workspace. */
+                      VIDC_TILE_G96x32_STREAM = 40,
+                      /* the same with 64-channel n-tiles, 12 waves and a 3-deep ring: one workgroup per CU with two stages (80 KB) of loads in flight */
+                      VIDC_TILE_G96x64_STREAM3 = 41,
+                      VIDC_TILE_COUNT = 42 };
 
 /* Arithmetic of the contraction.  FP32: v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32, the reference mode).
  * BF16X3: every operand is split as x = hi + lo (bf16 each, round-to-nearest-even) and each product is computed as

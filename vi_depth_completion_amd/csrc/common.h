@@ -39,6 +39,9 @@ inline hipStream_t as_stream(vidc_stream_t s) { return reinterpret_cast<hipStrea
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// csrc/wgemm.hip: the streamed grouped GEMM behind vidc_conv2d_bn_act's tile VIDC_TILE_G96x32_STREAM
+int launch_wgemm_stream(const vidc_conv_desc& d, hipStream_t st);
+
 // ---- split-bf16 ("bf16x3") operand format -------------------------------------------------------------------------
 // x = hi + lo with hi = bf16(x), lo = bf16(x - hi), round-to-nearest-even like torch's .to(bfloat16) (no NaN inputs here).
 // A tensor with `ld` channels per row keeps every 32-channel unit in place as [32 x hi | 32 x lo] (the same 128 bytes).

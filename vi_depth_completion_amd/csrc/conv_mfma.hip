@@ -854,6 +854,9 @@ constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {
     {64, 64, 2, 2, 2, 4},     // VIDC_TILE_64x64_K2_D4_P 128 KB (16 waves)
     {64, 32, 2, 1, 2, 5},     // VIDC_TILE_64x32_K2_D5_P 120 KB
     {32, 64, 1, 2, 2, 5},     // VIDC_TILE_32x64_K2_D5_P 120 KB
+    // ---- csrc/wgemm.hip: one workgroup streams a chunk of groups of a few-row grouped GEMM through one continuous ring ----
+    {96, 32, 3, 1, 2, 2},     // VIDC_TILE_G96x32_STREAM  77 KB
+    {96, 64, 3, 2, 2, 3},     // VIDC_TILE_G96x64_STREAM3 145 KB
 };
 constexpr int kFirstLoaderTile = VIDC_TILE_32x64_K2_L;
 
@@ -905,7 +908,7 @@ int validate(const vidc_conv_desc* d) {
     VIDC_REQUIRE(d->precision == VIDC_PREC_FP32 || d->precision == VIDC_PREC_BF16X3 || d->precision == VIDC_PREC_BF16, VIDC_ERR_SHAPE,
                  "conv: unknown precision %d", d->precision);
     VIDC_REQUIRE(d->precision != VIDC_PREC_BF16 || !(d->flags & VIDC_SPLIT_OUT), VIDC_ERR_SHAPE, "conv: SPLIT_OUT writes the bf16x3 format, not plain bf16");
-    VIDC_REQUIRE(d->splitk == 1 || d->workspace, VIDC_ERR_NULL, "conv: split-K needs a workspace");
+    VIDC_REQUIRE(d->splitk == 1 || d->workspace || d->tile == VIDC_TILE_G96x32_STREAM || d->tile == VIDC_TILE_G96x64_STREAM3, VIDC_ERR_NULL, "conv: split-K needs a workspace");
     VIDC_REQUIRE(!(d->flags & VIDC_SPLIT_OUT) || (d->y_split && d->Cout % 32 == 0 && d->ldy % 32 == 0), VIDC_ERR_NULL,
                  "conv: SPLIT_OUT needs y_split and Cout, ldy multiples of 32");
     VIDC_REQUIRE(!(d->flags & VIDC_NO_F32_OUT) || (d->flags & VIDC_SPLIT_OUT), VIDC_ERR_SHAPE, "conv: NO_F32_OUT without SPLIT_OUT writes nothing");
@@ -984,7 +987,7 @@ extern "C" int vidc_conv2d_plan(vidc_conv_desc* d) {
 }
 
 extern "C" size_t vidc_conv2d_workspace_bytes(const vidc_conv_desc* d) {
-    if (!d || d->splitk <= 1) return 0;
+    if (!d || d->splitk <= 1 || d->tile == VIDC_TILE_G96x32_STREAM || d->tile == VIDC_TILE_G96x64_STREAM3) return 0;      // (streamed tile: splitk = its number of group chunks, no partials)
     return ((size_t)VIDC_SPLITK_COUNTERS + (size_t)d->splitk * d->groups * d->B * d->Ho * d->Wo * d->Cout) * sizeof(float);
 }
 
@@ -1041,6 +1044,8 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         case VIDC_TILE_64x64_K2_D4_P:  rc = launch_tile<64, 64, 2, 2, 2, 4, 2>(a, st, dd.precision); break;
         case VIDC_TILE_64x32_K2_D5_P:  rc = launch_tile<64, 32, 2, 1, 2, 5, 2>(a, st, dd.precision); break;
         case VIDC_TILE_32x64_K2_D5_P:  rc = launch_tile<32, 64, 1, 2, 2, 5, 2>(a, st, dd.precision); break;
+        case VIDC_TILE_G96x32_STREAM:
+        case VIDC_TILE_G96x64_STREAM3: rc = vidc::launch_wgemm_stream(dd, st); break;
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
     return rc;

@@ -87,7 +87,7 @@ def conv2d_bn_act(x, w_packed, scale1, shift1, kh, kw, stride=1, pad=0, relu1=Fa
     d.B, d.H, d.W, d.Cin, d.ldx = B, H, W, cin, ld
     d.Ho, d.Wo, d.Cout, d.ldy = Ho, Wo, cout, G * cout
     d.KH, d.KW, d.stride, d.pad, d.flags, d.groups = kh, kw, stride, pad, flags, G
-    d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, cout * kh * kw * cin, cout, cout
+    d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, cout * kh * kw * cin, cout, (cout if s1.numel() >= G * cout else 0)      # (one affine for all groups: p_gs = 0)
     d.tile, d.splitk, d.precision = tile, splitk, precision
     if tile == 0:
         L.check(L.lib().vidc_conv2d_plan(C.byref(d)), "conv2d_plan")
