@@ -757,10 +757,15 @@ def run_extra_legs(args):
              ("configs[2] 640x480 stream, batch 8, Mask R-CNN plane head every frame", {},
               ["--batch", "8", "--source", "640x480", "--height", "240", "--plane-head", "--steps", "20", "--warmup", "4", "--frames-per-launch", "1",
                "--no-cpu-baseline", "--no-sequential-leg", "--no-extra-legs"]),
+             ("configs[3] 1280x720 stream, one GPU's share of batch 32 = 4 frames per item (plane mask fixed)", {},
+              ["--batch", "4", "--source", "1280x720", "--height", "240", "--steps", "20", "--warmup", "4", "--frames-per-launch", "1",
+               "--no-cpu-baseline", "--no-sequential-leg", "--no-extra-legs"]),
              # the headline runs four items per launch (first depth map of a stream after ~26 ms); this is the same workload at the
              # lower-latency setting of the knob (two items per launch, ~15 ms), in the headline's arithmetic
              ("configs[1] with two items per launch (lower first-item latency), fp32", {},
               ["--steps", "20", "--warmup", "5", "--frames-per-launch", "2", "--no-mixed-leg", "--no-cpu-baseline", "--no-sequential-leg", "--no-extra-legs"]),
+             ("configs[1] with eight items per launch (the throughput end of the knob: 48 frames in flight), fp32", {},
+              ["--steps", "40", "--warmup", "8", "--frames-per-launch", "8", "--no-mixed-leg", "--no-cpu-baseline", "--no-sequential-leg", "--no-extra-legs"]),
              ("configs[1] with one item per launch (every launch is one batch-1 frame), fp32", {},
               ["--steps", "20", "--warmup", "5", "--frames-per-launch", "1", "--no-mixed-leg", "--no-cpu-baseline", "--no-sequential-leg", "--no-extra-legs"])]
     for name, env_add, flags in specs:

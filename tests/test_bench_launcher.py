@@ -93,6 +93,24 @@ def test_bench_two_gloo_ranks_on_one_gpu():
     assert line["steps"] == 4 and abs(line["value"] * line["ms_per_step"] * 1e-3 - 2.0) < 1e-2      # 2 ranks x 4 frames / max time
 
 
+@pytest.mark.gpu
+def test_bench_eight_gloo_ranks_with_real_pipelines_on_one_gpu():
+    """Width-8 rehearsal: the command the driver's scaling run issues, `bench.py --gpus 8`, with eight REAL pipelines -- weights,
+    frame programs, three lanes each -- sharing the one GPU of the box over gloo (8 x ~6 GB).  No scaling claim follows from it; it takes "never ran
+    at width 8 with a pipeline" off the list of things the 8-GPU run can trip over: spawn before any HIP call, rank-staggered GPU start, barriers
+    around the timed regions of eight ranks, the gather, `n_gpus == 8`, one line, eight per-rank logs."""
+    log_dir = os.path.join(ROOT, "gpurun_out", "rank_logs_eight_gloo_ranks")
+    cmd = [sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--regions", "2", "--no-cpu-baseline", "--no-extra-legs", "--no-mixed-leg",
+           "--no-sequential-leg"]
+    r = subprocess.run(cmd, env=_env(VIDC_DIST_BACKEND="gloo", VIDC_RANK_LOG_DIR=log_dir, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, "eight-rank job failed (per-rank logs: %s):\n%s" % (log_dir, (r.stdout + r.stderr)[-8000:])
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0 and line["steps"] == 2
+    assert sum(1 for ln in r.stdout.splitlines() if ln.startswith("{")) == 1
+    logs = [f for _root, _dirs, files in os.walk(log_dir) for f in files]
+    assert len([f for f in logs if "stderr" in f or f.endswith(".log") or f.endswith(".err")]) >= 8 or len(logs) >= 8, logs
+
+
 def _nccl_world1(port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
                       VIDC_DIST_WORLD1="1")       # a world of one still goes through RCCL (sharding.collectives_active)
@@ -182,7 +200,8 @@ def test_extra_legs_can_never_take_the_headline_down(monkeypatch):
         monkeypatch.setenv(k, v)                  # a parent that runs inside a launcher / a world-of-one group: none of it may reach the child
     out = bench.run_extra_legs(argparse.Namespace(extra_legs_budget=75.0))
     names = list(out)
-    assert len(names) == 4 and "configs[4]" in names[0] and "configs[2]" in names[1] and "two items per launch" in names[2] and "one item per launch" in names[3]
+    assert len(names) == 6 and "configs[4]" in names[0] and "configs[2]" in names[1] and "configs[3]" in names[2] and "two items per launch" in names[3]
+    assert "eight items per launch" in names[4] and "one item per launch" in names[5]
     assert out[names[0]]["value"] == 290.4 and out[names[0]]["dtype"] == "bf16" and out[names[0]]["roofline"]["frac"] == 0.0864
     assert "--train" in out[names[0]]["command"] and "VIDC_TRAIN_PRECISION=bf16" in out[names[0]]["command"]
     assert "TimeoutExpired" in out[names[1]]["error"]

@@ -59,9 +59,12 @@ def test_winograd_choice_policy(monkeypatch):
     from vi_depth_completion_amd import engine as E
     monkeypatch.delenv("VIDC_WINOGRAD", raising=False)
     monkeypatch.setattr(E, "_TUNING", {})                   # the heuristic, not the measured per-layer verdicts
-    assert E.winograd_choice(1, 60, 80, 768, 768, 3, 3, 1, 1, 1, 1) == 4          # large map
-    assert E.winograd_choice(1, 15, 20, 1536, 1536, 3, 3, 1, 1, 1, 2) == 2        # small map
-    assert E.winograd_choice(1, 60, 80, 64, 64, 3, 3, 1, 1, 1, 4) == 0            # K = 64 per GEMM: the transforms would dominate
+    assert E.winograd_choice(1, 60, 80, 768, 768, 3, 3, 1, 1, 1, 1, precision="fp32") == 4          # large map
+    assert E.winograd_choice(1, 15, 20, 1536, 1536, 3, 3, 1, 1, 1, 2, precision="fp32") == 2        # small map
+    assert E.winograd_choice(1, 60, 80, 64, 64, 3, 3, 1, 1, 1, 4, precision="fp32") == 0            # K = 64 per GEMM: the transforms would dominate
+    # the mixed mode without a measured verdict stays direct (the table's verdict for 73 of 112 layers; a bf16x3 direct conv is cheap)
+    assert E.winograd_choice(1, 60, 80, 768, 768, 3, 3, 1, 1, 1, 1, precision="mixed") == 0
+    monkeypatch.setenv("VIDC_PRECISION", "fp32")
     assert E.winograd_choice(1, 60, 80, 128, 128, 3, 3, 2, 1, 1, 1) == 0          # stride 2
     assert E.winograd_choice(1, 60, 80, 256, 256, 3, 3, 1, 6, 6, 1) == 0          # dilated (DORN's ASPP)
     assert E.winograd_choice(1, 60, 80, 256, 256, 1, 1, 1, 0, 1, 1) == 0
