@@ -74,7 +74,7 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
             for (int c = 0; c < CIN; ++c) patch[c][r][i] = in ? vidc::sample(xb + c * plane, t) : 0.f;
             } else {
             // (experiments of round 6, profiles/EXPERIMENTS.md: other flavours of the four tap loads -- LOADS >> 3 = 1 nontemporal, 2 plain with a
-            //  full vmcnt wait behind every channel, 3 agent-scope atomic, 4 volatile)
+            //  full vmcnt wait behind every channel, 3 agent-scope atomic, 4 volatile, 5 / 6 the counted-wait schedule in inline asm without / with idle cycles)
             constexpr int FL = LOADS >> 3;
             auto ld = [](const float* p) -> float {
                 if constexpr (FL == 1) return __builtin_nontemporal_load(p);
@@ -87,10 +87,59 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
                 float v = 0.f;
                 if (in) {
                     const float* pl = xb + c * plane;
+                    if constexpr (FL == 7 || FL == 8) {
+                        // hypothesis test (round 6): what hipcc's schedule of the plain form contains and the hand-written FL 5 does not -- the ADDRESS
+                        // register pair of the youngest load is overwritten by the next VALU instruction while older loads of the wave are still queued
+                        // (`global_load_dword v60, v[40:41]; s_waitcnt vmcnt(6); v_mul_f32 v40, ...`).  Here the overwrite is a move of a pointer into the
+                        // weights: a lane whose address was fetched late samples a weight instead of a pixel.  FL 8: four more loads queued ahead.
+                        float a00, a01, a10, a11, j0 = 0.f, j1 = 0.f, j2 = 0.f, j3 = 0.f;
+                        const float *p00 = pl + t.o00, *p01 = pl + t.o01, *p10 = pl + t.o10;
+                        const float* p11 = pl + t.o11;
+                        const float* poison = w + (tid & 63);
+                        if constexpr (FL == 8)
+                            asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dword %3, %7, off"
+                                         : "=&v"(j0), "=&v"(j1), "=&v"(j2), "=&v"(j3) : "v"(p01), "v"(p10), "v"(p00), "v"(p11) : "memory");
+                        asm volatile("global_load_dword %1, %6, off\n\tglobal_load_dword %2, %7, off\n\tglobal_load_dword %3, %8, off\n\tglobal_load_dword %4, %5, off\n\t"
+                                     "v_mov_b64 %5, %13\n\t"
+                                     "s_waitcnt vmcnt(3)\n\tv_mul_f32 %0, %1, %9\n\ts_waitcnt vmcnt(2)\n\tv_fmac_f32 %0, %2, %10\n\t"
+                                     "s_waitcnt vmcnt(1)\n\tv_fmac_f32 %0, %3, %11\n\ts_waitcnt vmcnt(0)\n\tv_fmac_f32 %0, %4, %12"
+                                     : "=&v"(v), "=&v"(a00), "=&v"(a01), "=&v"(a10), "=&v"(a11), "+v"(p11)
+                                     : "v"(p00), "v"(p01), "v"(p10), "v"(t.w00), "v"(t.w01), "v"(t.w10), "v"(t.w11), "v"(poison) : "memory");
+                        if constexpr (FL == 8) v += 0.f * (j0 + j1 + j2 + j3) * 0.f;      // (keeps the extra loads alive; the waits above drained them)
+                        if (p11 == nullptr) v = 0.f;
+                    } else if constexpr (FL == 5 || FL == 6 || FL == 9) {
+                        // the compiler's schedule written out: four plain loads in flight, COUNTED waits, every result consumed by the VALU instruction
+                        // right behind its wait (FL 5) -- and the same with 16 idle cycles between each wait and its consumer (FL 6)
+                        float a00, a01, a10, a11;
+                        const float *p00 = pl + t.o00, *p01 = pl + t.o01, *p10 = pl + t.o10, *p11 = pl + t.o11;
+#define VIDC_NOP_ "s_nop 15\n\t"
+                        if constexpr (FL == 5 || FL == 9)
+                            asm volatile("global_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dword %3, %7, off\n\tglobal_load_dword %4, %8, off\n\t"
+                                         "s_waitcnt vmcnt(3)\n\tv_mul_f32 %0, %1, %9\n\ts_waitcnt vmcnt(2)\n\tv_fmac_f32 %0, %2, %10\n\t"
+                                         "s_waitcnt vmcnt(1)\n\tv_fmac_f32 %0, %3, %11\n\ts_waitcnt vmcnt(0)\n\tv_fmac_f32 %0, %4, %12"
+                                         : "=&v"(v), "=&v"(a00), "=&v"(a01), "=&v"(a10), "=&v"(a11)
+                                         : "v"(p00), "v"(p01), "v"(p10), "v"(p11), "v"(t.w00), "v"(t.w01), "v"(t.w10), "v"(t.w11) : "memory");
+                        else
+                            asm volatile("global_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dword %3, %7, off\n\tglobal_load_dword %4, %8, off\n\t"
+                                         "s_waitcnt vmcnt(3)\n\t" VIDC_NOP_ "v_mul_f32 %0, %1, %9\n\ts_waitcnt vmcnt(2)\n\t" VIDC_NOP_ "v_fmac_f32 %0, %2, %10\n\t"
+                                         "s_waitcnt vmcnt(1)\n\t" VIDC_NOP_ "v_fmac_f32 %0, %3, %11\n\ts_waitcnt vmcnt(0)\n\t" VIDC_NOP_ "v_fmac_f32 %0, %4, %12"
+                                         : "=&v"(v), "=&v"(a00), "=&v"(a01), "=&v"(a10), "=&v"(a11)
+                                         : "v"(p00), "v"(p01), "v"(p10), "v"(p11), "v"(t.w00), "v"(t.w01), "v"(t.w10), "v"(t.w11) : "memory");
+#undef VIDC_NOP_
+                    } else {
                     const float a00 = ld(pl + t.o00), a01 = ld(pl + t.o01), a10 = ld(pl + t.o10), a11 = ld(pl + t.o11);
                     if constexpr (FL == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     v = fmaf(a11, t.w11, fmaf(a10, t.w10, fmaf(a01, t.w01, a00 * t.w00)));
+                    }
                 }
+                if constexpr (FL == 9) {
+                    // hypothesis test (round 6): in hipcc's schedule of the plain form the register that a ds_write_b32 has just been handed as DATA is
+                    // overwritten two instructions later (`ds_write_b32 v36, v38 offset:1584 ... v_lshl_add_u64 v[38:39], ...`).  Here: the LDS write in
+                    // inline asm with the data register overwritten by the very next instruction; a lane whose data was fetched late stores the poison.
+                    const unsigned la = (unsigned)(size_t)((__attribute__((address_space(3))) float*)&patch[c][r][i]);
+                    float poison = 1.0e6f;
+                    asm volatile("ds_write_b32 %0, %1\n\tv_mov_b32 %1, %2\n\tv_mov_b32 %1, %2\n\ts_waitcnt lgkmcnt(0)" : : "v"(la), "v"(v), "v"(poison) : "memory");
+                } else
                 patch[c][r][i] = v;
             }
             }
@@ -385,6 +434,11 @@ int stem_launch(const float* x, const float* w_oihw, float* y, int B, int Cin, i
     else if (warp_params && dbg_loads == 18) VIDC_STEM_DBG(18);
     else if (warp_params && dbg_loads == 26) VIDC_STEM_DBG(26);
     else if (warp_params && dbg_loads == 34) VIDC_STEM_DBG(34);
+    else if (warp_params && dbg_loads == 42) VIDC_STEM_DBG(42);
+    else if (warp_params && dbg_loads == 50) VIDC_STEM_DBG(50);
+    else if (warp_params && dbg_loads == 58) VIDC_STEM_DBG(58);
+    else if (warp_params && dbg_loads == 66) VIDC_STEM_DBG(66);
+    else if (warp_params && dbg_loads == 74) VIDC_STEM_DBG(74);
 #undef VIDC_STEM_DBG
     else if (warp_params)
         hipLaunchKernelGGL((stem_conv_kernel<3, true>), grid, dim3(256), 0, st, x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0, warp_params, cx, cy, align_corners);
