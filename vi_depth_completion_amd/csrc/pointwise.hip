@@ -27,11 +27,9 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
     const float* xb = x + (size_t)b * CIN * plane;
     const int ix_base = ox0 * 2 - 1, iy_base = oy * 2 - 1;
     if constexpr (WARP) {
-        // The record was written by the launch just before this one (warp_params_kernel).  It is read through the VECTOR memory path into
-        // LDS, not with scalar loads: `warp_params + b * 32` is wave-uniform, hipcc turns plain reads of it into s_load (scalar data cache),
-        // and with two or three lanes' graphs in flight those returned the PREVIOUS tick's record now and then (round 5: whole stem outputs
-        // computed with the last frame's homography, nondeterministically, only with >= 2 lanes, never eagerly) -- the scalar cache is not
-        // reliably invalidated between two kernel nodes of a captured graph.
+        // The record (written by warp_params_kernel, the launch before this one) goes through vector loads into LDS.  Round 5 blamed wave-uniform
+        // s_load reads of it for wrong frames ("scalar cache not invalidated between graph nodes"); round 6 measured that form innocent (0 of 3 200
+        // launches beside the trigger, profiles/EXPERIMENTS.md) -- the LDS copy stays because the tap code wants the 32 floats as lane-indexed data anyway.
         __shared__ float wp[VIDC_WARP_PARAMS];
         // LOADS (debug builds of the launch only, VIDC_DBG_STEM_LOADS): bit 0 = the record through wave-uniform plain reads (s_load), bit 1 = the
         // image through plain loads, bit 2 = an explicit buffer_inv sc0 sc1 first.  0 is what ships; 3 is the round-5 form.
@@ -52,11 +50,12 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
             const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;      // (outside: the conv's zero padding, not a warp sample)
             vidc::Taps t;
             if (in) t = vidc::warp_fwd_taps(wp, ix, iy, wcx, wcy, W, H, align_corners);
-            // The image is sampled with system-scope loads (coherent, never served from a stale cache line).  With plain loads a few cache
-            // lines of the image now and then still held the PREVIOUS frame's pixels when two or three lanes' graphs were in flight (round 5:
-            // nondeterministic 1e-3 differences in the depth map of one frame in ten, traced to 400-800 wrong words of this kernel's output;
-            // the image is rewritten by a device-to-device copy before every launch; 8 of 8 runs clean with these loads, 6 of 8 dirty
-            // without).  The stand-alone warp kernel reading the same buffer has never shown it (its reads are banded per XCD).
+            // The image is sampled with system-scope loads.  Round 6 (profiles/EXPERIMENTS.md, tools/stale_read/): hipcc's schedule of THIS loop with
+            // plain tap loads leaves lanes 48-63 of one wave with wrong patch values in 6-15 % of the launches whenever a bf16x3 conv of another hardware
+            // queue shares the chip -- eager or graphs, with or without a kernel-entry buffer_inv, never in fp32, never beside anything else; the
+            // inputs are intact, so it is not a stale line, and counted waits / an address WAR / a DS-data WAR in isolation do not reproduce it.  Every
+            // other form of the same loads -- system-scope (this one), agent-scope, non-temporal, plain with full waits -- is clean in 1 600-4 800
+            // launches each.  The plain form stays reachable (VIDC_DBG_STEM_LOADS=3) as the positive control of tests/test_stale_reads.py.
             if constexpr (!(LOADS & 2)) {
 #pragma unroll
             for (int c = 0; c < CIN; ++c) {
