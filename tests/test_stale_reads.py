@@ -1,14 +1,16 @@
-"""Stress test of the stream mode against wrong / stale reads (the investigation is in profiles/EXPERIMENTS.md, round 6).
+"""Stress test of the stream mode against wrong reads (the whole investigation is in profiles/EXPERIMENTS.md, round 6).
 
-What round 5 saw -- one frame in ten off by 1e-3 with the opt-in fused warp + stem kernel -- is reproduced at will in round 6: the kernel's
-ROUND-5 FORM (plain tap loads, `VIDC_DBG_STEM_LOADS=3`) computes 16 consecutive patch words of one wave (lanes 48-63) wrong in 6-15 % of
-its launches whenever a bf16x3 conv of ANOTHER hardware queue shares the chip (mixed mode, >= 2 lanes; eager or graphs alike; never in fp32,
-never with one lane or one hardware queue).  That form is the positive control here: the same stream, the same comparison, and it MUST
-differ -- so a green run of the default path means the comparison can see the hazard and did not.
+What round 5 saw -- one frame in ten off by 1e-3 with the opt-in fused warp + stem kernel, read as "stale cache lines" -- is reproduced at will in round 6
+and traced to ONE instruction: `v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]`, which hipcc's SLP vectoriser had emitted for the two cross bilinear weights
+in the kernel's plain-load form.  On MI355X a packed-fp32 op whose low half takes the high dword of src1 returns a wrong low half in lanes 48-63 while another
+wave of the SIMD issues v_mfma_f32_32x32x16_bf16 (tools/stale_read/pkmul.hip: 100 lines, no memory) -- i.e. in the mixed mode, beside another lane's bf16x3
+conv, on any number of streams but never in fp32, never alone.  The library no longer contains the encoding (csrc/Makefile, tests/test_isa_audit.py); the
+debug form `VIDC_DBG_STEM_LOADS=3` puts it back ON PURPOSE as an identity multiply and is the positive control here: the same stream, the same comparison,
+and it MUST differ -- so a green run of the default path means the comparison can see the defect and did not.
 
-Every case is a process of its own (tools/stale_read/stress_pipeline.py): the kernel form and the hardware-queue count are read once per
-process.  Reference of every case: the same items through ONE lane executed eagerly by a second pipeline object (no graphs, no overlap).
-Each item has its own image and gravity (per-frame homography: networks/warping_2dof_alignment.py:35-58,108-156).
+Every case is a process of its own (tools/stale_read/stress_pipeline.py): the kernel form and the hardware-queue count are read once per process.
+Reference of every case: the same items through ONE lane executed eagerly by a second pipeline object (no graphs, no overlap).  Each item has its own image
+and gravity (per-frame homography: networks/warping_2dof_alignment.py:35-58,108-156).
 """
 import os
 import re
@@ -56,8 +58,8 @@ def test_default_path_one_item_per_launch_and_two_lanes():
 
 
 def test_positive_control_round5_kernel_form_is_caught():
-    """The opt-in fused stem in its round-5 form (plain tap loads): the stream MUST differ from the reference (measured: 8-15 % of the items
-    per run, i.e. P(no difference in 2 x 800 items) is nil) -- and the form that ships behind VIDC_FUSE_WARP=1 (system-scope tap loads) must not."""
+    """The opt-in fused stem with the defective packed multiply put back (VIDC_DBG_STEM_LOADS=3): the stream MUST differ from the reference (measured:
+    8-15 % of the items per run, i.e. P(no difference in 2 x 800 items) is nil) -- and the form that ships behind VIDC_FUSE_WARP=1 must not."""
     bad, out = _stress({"VIDC_PRECISION": "mixed", "VIDC_FUSE_WARP": "1", "VIDC_DBG_STEM_LOADS": "3"}, items=800, runs=2)
     assert bad > 0, "the positive control did not fail: the stress test cannot see the round-5 hazard on this box\n" + out
     bad, out = _stress({"VIDC_PRECISION": "mixed", "VIDC_FUSE_WARP": "1", "VIDC_DBG_STEM_LOADS": "0"}, items=800, runs=2)

@@ -50,6 +50,19 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
             const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;      // (outside: the conv's zero padding, not a warp sample)
             vidc::Taps t;
             if (in) t = vidc::warp_fwd_taps(wp, ix, iy, wcx, wcy, W, H, align_corners);
+            if constexpr (LOADS == 3) {
+                // THE POSITIVE CONTROL of tests/test_stale_reads.py.  Round 6 delta-debugged hipcc's assembly of this kernel's plain-load form down to one
+                // instruction: `v_pk_mul_f32 v[28:29], v[36:37], v[28:29] op_sel:[0,1] op_sel_hi:[1,0]` (the two cross bilinear weights in one packed multiply).
+                // On MI355X that encoding -- a packed-fp32 op whose LOW half takes the HIGH dword of src1 -- returns a wrong low half in lanes 48-63 while
+                // another wave of the SIMD issues v_mfma_f32_32x32x16_bf16 / _f16 (tools/stale_read/pkmul.hip: 100 lines, no memory involved).  The library is
+                // now built without SLP-vectorised packed fp32 (csrc/Makefile, tools/audit_isa.py), so this debug form puts the instruction back ON PURPOSE,
+                // as an identity multiply of the two weights: correct hardware leaves them unchanged.
+                typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                f32x2_ wa = {t.w01, t.w10}, ones = {1.0f, 1.0f}, wd;
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(wd) : "v"(wa), "v"(ones));
+                t.w01 = wd.x;
+                t.w10 = wd.y;
+            }
             // The image is sampled with system-scope loads.  Round 6 (profiles/EXPERIMENTS.md, tools/stale_read/): hipcc's schedule of THIS loop with
             // plain tap loads leaves lanes 48-63 of one wave with wrong patch values in 6-15 % of the launches whenever a bf16x3 conv of another hardware
             // queue shares the chip -- eager or graphs, with or without a kernel-entry buffer_inv, never in fp32, never beside anything else; the
