@@ -110,11 +110,10 @@ __device__ inline float sample(const float* __restrict__ plane, const Taps& t) {
     // explicit fma chain: the result must not depend on how the compiler unrolls the channel loop
     return fmaf(plane[t.o11], t.w11, fmaf(plane[t.o10], t.w10, fmaf(plane[t.o01], t.w01, plane[t.o00] * t.w00)));
 }
-// The same taps through non-temporal loads (global_load ... nt: streamed past the CU's vector L1).  For tensors that a copy or another
-// kernel of the same tick rewrote just before this launch -- the frame, the normals, the enriched depth: every pixel is read by one or two
-// workgroups, so there is nothing for the L1 to keep, and round 6's bisect of the round-5 hazard (profiles/EXPERIMENTS.md: plain tap loads
-// of the FUSED stem returned wrong data in lanes 48-63 of a wave beside another queue's bf16x3 conv; the nt / scoped forms never did in
-// 1600 launches against 6-8 % of them) makes this the form that is safe by construction.  Same bits as sample().
+// The same taps through non-temporal loads (global_load ... nt: streamed past the CU's vector L1).  For tensors that a copy or another kernel of the
+// same tick rewrote just before this launch -- the frame, the normals, the enriched depth: every pixel is read by one or two workgroups, so there is
+// nothing for the L1 to keep.  (Introduced in round 6 while the round-5 hazard was still read as a cache effect; its cause turned out to be an execution
+// defect of packed fp32 ops, DESIGN 4.5 -- the loads stay because they are the right form for single-use data.)  Same bits as sample().
 __device__ inline float sample_nt(const float* __restrict__ plane, const Taps& t) {
     const float a00 = __builtin_nontemporal_load(plane + t.o00), a01 = __builtin_nontemporal_load(plane + t.o01);
     const float a10 = __builtin_nontemporal_load(plane + t.o10), a11 = __builtin_nontemporal_load(plane + t.o11);

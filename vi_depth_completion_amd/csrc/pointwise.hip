@@ -63,12 +63,10 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
                 t.w01 = wd.x;
                 t.w10 = wd.y;
             }
-            // The image is sampled with system-scope loads.  Round 6 (profiles/EXPERIMENTS.md, tools/stale_read/): hipcc's schedule of THIS loop with
-            // plain tap loads leaves lanes 48-63 of one wave with wrong patch values in 6-15 % of the launches whenever a bf16x3 conv of another hardware
-            // queue shares the chip -- eager or graphs, with or without a kernel-entry buffer_inv, never in fp32, never beside anything else; the
-            // inputs are intact, so it is not a stale line, and counted waits / an address WAR / a DS-data WAR in isolation do not reproduce it.  Every
-            // other form of the same loads -- system-scope (this one), agent-scope, non-temporal, plain with full waits -- is clean in 1 600-4 800
-            // launches each.  The plain form stays reachable (VIDC_DBG_STEM_LOADS=3) as the positive control of tests/test_stale_reads.py.
+            // The image is sampled with system-scope loads (historical: round 5 believed that plain loads read stale lines).  Round 6 traced the wrong
+            // frames to an execution defect of the chip instead -- a packed multiply that hipcc had emitted for the two cross weights in the plain-load form,
+            // see the LOADS == 3 block above and DESIGN 4.5 -- so the load flavour is irrelevant for correctness; the other flavours (LOADS bits, >> 3) remain
+            // as the record of that bisect.
             if constexpr (!(LOADS & 2)) {
 #pragma unroll
             for (int c = 0; c < CIN; ++c) {

@@ -695,9 +695,8 @@ class Program:
     def finalize(self, dry_run=False):
         """Plans buffers and builds the C op array.  dry_run=True stops before any HIP call (host-logic tests on CPU)."""
         lib = L.lib()
-        # Opt-in (VIDC_FUSE_WARP=1): bit-identical, one launch and 2 x 3HW x 4 bytes less per frame, no measurable gain (< 0.2 % of the tick); the
-        # fused kernel's plain-load form is the one compiled schedule that round 6 caught computing wrong quads beside bf16x3 convs of other lanes
-        # (csrc/pointwise.hip, DESIGN 4.5) -- the separate warp launch stays the default.
+        # Opt-in (VIDC_FUSE_WARP=1): bit-identical, one launch and 2 x 3HW x 4 bytes less per frame, no measurable gain (< 0.2 % of the tick).  (The wrong
+        # frames round 5 saw with it were an execution defect of a packed-fp32 instruction beside bf16 MFMAs, not this kernel's loads: DESIGN 4.5.)
         if os.environ.get("VIDC_FUSE_WARP", "0") == "1":
             self._fuse_warp_into_stem()
         else:
