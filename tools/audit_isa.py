@@ -19,7 +19,7 @@ import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 # the one kernel that carries the encoding on purpose: the debug form behind VIDC_DBG_STEM_LOADS=3, the positive control of tests/test_stale_reads.py
-ALLOWED = ("stem_conv_kernelILi3ELb1ELi3EEE",)
+ALLOWED = ("stem_conv_kernelILi3ELb1ELb1EEE",)
 PAT = re.compile(r"\b(v_pk_(?:mul|add|fma|min|max)_f32)\b[^\n]*?op_sel:\[([01,]+)\]")
 
 

@@ -13,7 +13,7 @@ namespace {
 // surface_normal.py:163) and the patch loader gathers it on the fly -- one projective map and one bilinear tap set per patch pixel, shared
 // by the CIN channels, the very code of warp_fwd_kernel (vidc::warp_fwd_taps / vidc::sample), so the patch holds the bits that kernel would
 // have stored.  The warped image is never written: one launch and a 2 x 3HW x 4 byte round trip less per frame.
-template <int CIN, bool WARP, int LOADS = 0>
+template <int CIN, bool WARP, bool CONTROL = false>
 __global__ void __launch_bounds__(256)
 stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int H, int W, int Ho, int Wo,
                  int Cout, int ldy, int relu, unsigned short* __restrict__ ysp, int ch0, const float* __restrict__ warp_params, float wcx, float wcy,
@@ -27,22 +27,10 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
     const float* xb = x + (size_t)b * CIN * plane;
     const int ix_base = ox0 * 2 - 1, iy_base = oy * 2 - 1;
     if constexpr (WARP) {
-        // The record (written by warp_params_kernel, the launch before this one) goes through vector loads into LDS.  Round 5 blamed wave-uniform
-        // s_load reads of it for wrong frames ("scalar cache not invalidated between graph nodes"); round 6 measured that form innocent (0 of 3 200
-        // launches beside the trigger, profiles/EXPERIMENTS.md) -- the LDS copy stays because the tap code wants the 32 floats as lane-indexed data anyway.
+        // The record (written by warp_params_kernel, the launch before this one) goes through vector loads into LDS: the tap code wants the 32 floats
+        // as lane-indexed data.  (Round 5 blamed wave-uniform s_load reads of it for wrong frames; round 6 measured that form innocent)
         __shared__ float wp[VIDC_WARP_PARAMS];
-        // LOADS (debug builds of the launch only, VIDC_DBG_STEM_LOADS): bit 0 = the record through wave-uniform plain reads (s_load), bit 1 = the
-        // image through plain loads, bit 2 = an explicit buffer_inv sc0 sc1 first.  0 is what ships; 3 is the round-5 form.
-        if constexpr (LOADS & 4) asm volatile("buffer_inv sc0 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (LOADS & 1) {
-            const float* rp = warp_params + (size_t)b * VIDC_WARP_PARAMS;
-            if (tid < VIDC_WARP_PARAMS) {
-                float v = 0.f;
-#pragma unroll
-                for (int k = 0; k < VIDC_WARP_PARAMS; ++k) v = (tid == k) ? rp[k] : v;
-                wp[tid] = v;
-            }
-        } else if (tid < VIDC_WARP_PARAMS) wp[tid] = __builtin_nontemporal_load(warp_params + (size_t)b * VIDC_WARP_PARAMS + tid);
+        if (tid < VIDC_WARP_PARAMS) wp[tid] = __builtin_nontemporal_load(warp_params + (size_t)b * VIDC_WARP_PARAMS + tid);
         __syncthreads();
         for (int e = tid; e < 3 * PW; e += 256) {
             const int r = e / PW, i = e - r * PW;
@@ -50,24 +38,21 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
             const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;      // (outside: the conv's zero padding, not a warp sample)
             vidc::Taps t;
             if (in) t = vidc::warp_fwd_taps(wp, ix, iy, wcx, wcy, W, H, align_corners);
-            if constexpr (LOADS == 3) {
-                // THE POSITIVE CONTROL of tests/test_stale_reads.py.  Round 6 delta-debugged hipcc's assembly of this kernel's plain-load form down to one
-                // instruction: `v_pk_mul_f32 v[28:29], v[36:37], v[28:29] op_sel:[0,1] op_sel_hi:[1,0]` (the two cross bilinear weights in one packed multiply).
-                // On MI355X that encoding -- a packed-fp32 op whose LOW half takes the HIGH dword of src1 -- returns a wrong low half in lanes 48-63 while
-                // another wave of the SIMD issues v_mfma_f32_32x32x16_bf16 / _f16 (tools/stale_read/pkmul.hip: 100 lines, no memory involved).  The library is
-                // now built without SLP-vectorised packed fp32 (csrc/Makefile, tools/audit_isa.py), so this debug form puts the instruction back ON PURPOSE,
-                // as an identity multiply of the two weights: correct hardware leaves them unchanged.
+            if constexpr (CONTROL) {
+                // THE POSITIVE CONTROL of tests/test_stale_reads.py (VIDC_DBG_STEM_LOADS=3).  Round 6 delta-debugged hipcc's assembly of this kernel's then
+                // plain-load form down to one instruction: `v_pk_mul_f32 v[28:29], v[36:37], v[28:29] op_sel:[0,1] op_sel_hi:[1,0]` (the two cross bilinear
+                // weights in one packed multiply).  On MI355X that encoding -- a packed-fp32 op whose LOW half takes the HIGH dword of src1 -- returns a
+                // wrong low half in lanes 48-63 while another wave of the SIMD issues v_mfma_f32_32x32x16_bf16 / _f16 (tools/stale_read/pkmul.hip: 100 lines,
+                // no memory involved).  This file is built without SLP-vectorised packed fp32 (csrc/Makefile, tools/audit_isa.py), so the debug
+                // form puts the instruction back ON PURPOSE, as an identity multiply of the two weights: correct hardware leaves them unchanged.
                 typedef float f32x2_ __attribute__((ext_vector_type(2)));
                 f32x2_ wa = {t.w01, t.w10}, ones = {1.0f, 1.0f}, wd;
                 asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(wd) : "v"(wa), "v"(ones));
                 t.w01 = wd.x;
                 t.w10 = wd.y;
             }
-            // The image is sampled with system-scope loads (historical: round 5 believed that plain loads read stale lines).  Round 6 traced the wrong
-            // frames to an execution defect of the chip instead -- a packed multiply that hipcc had emitted for the two cross weights in the plain-load form,
-            // see the LOADS == 3 block above and DESIGN 4.5 -- so the load flavour is irrelevant for correctness; the other flavours (LOADS bits, >> 3) remain
-            // as the record of that bisect.
-            if constexpr (!(LOADS & 2)) {
+            // (system-scope tap loads: a leftover of round 5's stale-line theory, harmless -- 3 MB per launch; the other load flavours and the hand-written
+            //  schedules of round 6's bisect lived here until commit 5f9fbb5 and are described in profiles/EXPERIMENTS.md)
 #pragma unroll
             for (int c = 0; c < CIN; ++c) {
                 float v = 0.f;
@@ -78,80 +63,6 @@ stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float
                     v = fmaf(a11, t.w11, fmaf(a10, t.w10, fmaf(a01, t.w01, a00 * t.w00)));
                 }
                 patch[c][r][i] = v;
-            }
-            } else if constexpr ((LOADS >> 3) == 0) {
-#pragma unroll
-            for (int c = 0; c < CIN; ++c) patch[c][r][i] = in ? vidc::sample(xb + c * plane, t) : 0.f;
-            } else {
-            // (experiments of round 6, profiles/EXPERIMENTS.md: other flavours of the four tap loads -- LOADS >> 3 = 1 nontemporal, 2 plain with a
-            //  full vmcnt wait behind every channel, 3 agent-scope atomic, 4 volatile, 5 / 6 the counted-wait schedule in inline asm without / with idle cycles)
-            constexpr int FL = LOADS >> 3;
-            auto ld = [](const float* p) -> float {
-                if constexpr (FL == 1) return __builtin_nontemporal_load(p);
-                else if constexpr (FL == 3) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else if constexpr (FL == 4) return *reinterpret_cast<const volatile float*>(p);
-                else return *p;
-            };
-#pragma unroll
-            for (int c = 0; c < CIN; ++c) {
-                float v = 0.f;
-                if (in) {
-                    const float* pl = xb + c * plane;
-                    if constexpr (FL == 7 || FL == 8) {
-                        // hypothesis test (round 6): what hipcc's schedule of the plain form contains and the hand-written FL 5 does not -- the ADDRESS
-                        // register pair of the youngest load is overwritten by the next VALU instruction while older loads of the wave are still queued
-                        // (`global_load_dword v60, v[40:41]; s_waitcnt vmcnt(6); v_mul_f32 v40, ...`).  Here the overwrite is a move of a pointer into the
-                        // weights: a lane whose address was fetched late samples a weight instead of a pixel.  FL 8: four more loads queued ahead.
-                        float a00, a01, a10, a11, j0 = 0.f, j1 = 0.f, j2 = 0.f, j3 = 0.f;
-                        const float *p00 = pl + t.o00, *p01 = pl + t.o01, *p10 = pl + t.o10;
-                        const float* p11 = pl + t.o11;
-                        const float* poison = w + (tid & 63);
-                        if constexpr (FL == 8)
-                            asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dword %3, %7, off"
-                                         : "=&v"(j0), "=&v"(j1), "=&v"(j2), "=&v"(j3) : "v"(p01), "v"(p10), "v"(p00), "v"(p11) : "memory");
-                        asm volatile("global_load_dword %1, %6, off\n\tglobal_load_dword %2, %7, off\n\tglobal_load_dword %3, %8, off\n\tglobal_load_dword %4, %5, off\n\t"
-                                     "v_mov_b64 %5, %13\n\t"
-                                     "s_waitcnt vmcnt(3)\n\tv_mul_f32 %0, %1, %9\n\ts_waitcnt vmcnt(2)\n\tv_fmac_f32 %0, %2, %10\n\t"
-                                     "s_waitcnt vmcnt(1)\n\tv_fmac_f32 %0, %3, %11\n\ts_waitcnt vmcnt(0)\n\tv_fmac_f32 %0, %4, %12"
-                                     : "=&v"(v), "=&v"(a00), "=&v"(a01), "=&v"(a10), "=&v"(a11), "+v"(p11)
-                                     : "v"(p00), "v"(p01), "v"(p10), "v"(t.w00), "v"(t.w01), "v"(t.w10), "v"(t.w11), "v"(poison) : "memory");
-                        if constexpr (FL == 8) v += 0.f * (j0 + j1 + j2 + j3) * 0.f;      // (keeps the extra loads alive; the waits above drained them)
-                        if (p11 == nullptr) v = 0.f;
-                    } else if constexpr (FL == 5 || FL == 6 || FL == 9) {
-                        // the compiler's schedule written out: four plain loads in flight, COUNTED waits, every result consumed by the VALU instruction
-                        // right behind its wait (FL 5) -- and the same with 16 idle cycles between each wait and its consumer (FL 6)
-                        float a00, a01, a10, a11;
-                        const float *p00 = pl + t.o00, *p01 = pl + t.o01, *p10 = pl + t.o10, *p11 = pl + t.o11;
-#define VIDC_NOP_ "s_nop 15\n\t"
-                        if constexpr (FL == 5 || FL == 9)
-                            asm volatile("global_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dword %3, %7, off\n\tglobal_load_dword %4, %8, off\n\t"
-                                         "s_waitcnt vmcnt(3)\n\tv_mul_f32 %0, %1, %9\n\ts_waitcnt vmcnt(2)\n\tv_fmac_f32 %0, %2, %10\n\t"
-                                         "s_waitcnt vmcnt(1)\n\tv_fmac_f32 %0, %3, %11\n\ts_waitcnt vmcnt(0)\n\tv_fmac_f32 %0, %4, %12"
-                                         : "=&v"(v), "=&v"(a00), "=&v"(a01), "=&v"(a10), "=&v"(a11)
-                                         : "v"(p00), "v"(p01), "v"(p10), "v"(p11), "v"(t.w00), "v"(t.w01), "v"(t.w10), "v"(t.w11) : "memory");
-                        else
-                            asm volatile("global_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dword %3, %7, off\n\tglobal_load_dword %4, %8, off\n\t"
-                                         "s_waitcnt vmcnt(3)\n\t" VIDC_NOP_ "v_mul_f32 %0, %1, %9\n\ts_waitcnt vmcnt(2)\n\t" VIDC_NOP_ "v_fmac_f32 %0, %2, %10\n\t"
-                                         "s_waitcnt vmcnt(1)\n\t" VIDC_NOP_ "v_fmac_f32 %0, %3, %11\n\ts_waitcnt vmcnt(0)\n\t" VIDC_NOP_ "v_fmac_f32 %0, %4, %12"
-                                         : "=&v"(v), "=&v"(a00), "=&v"(a01), "=&v"(a10), "=&v"(a11)
-                                         : "v"(p00), "v"(p01), "v"(p10), "v"(p11), "v"(t.w00), "v"(t.w01), "v"(t.w10), "v"(t.w11) : "memory");
-#undef VIDC_NOP_
-                    } else {
-                    const float a00 = ld(pl + t.o00), a01 = ld(pl + t.o01), a10 = ld(pl + t.o10), a11 = ld(pl + t.o11);
-                    if constexpr (FL == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    v = fmaf(a11, t.w11, fmaf(a10, t.w10, fmaf(a01, t.w01, a00 * t.w00)));
-                    }
-                }
-                if constexpr (FL == 9) {
-                    // hypothesis test (round 6): in hipcc's schedule of the plain form the register that a ds_write_b32 has just been handed as DATA is
-                    // overwritten two instructions later (`ds_write_b32 v36, v38 offset:1584 ... v_lshl_add_u64 v[38:39], ...`).  Here: the LDS write in
-                    // inline asm with the data register overwritten by the very next instruction; a lane whose data was fetched late stores the poison.
-                    const unsigned la = (unsigned)(size_t)((__attribute__((address_space(3))) float*)&patch[c][r][i]);
-                    float poison = 1.0e6f;
-                    asm volatile("ds_write_b32 %0, %1\n\tv_mov_b32 %1, %2\n\tv_mov_b32 %1, %2\n\ts_waitcnt lgkmcnt(0)" : : "v"(la), "v"(v), "v"(poison) : "memory");
-                } else
-                patch[c][r][i] = v;
-            }
             }
         }
     } else {
@@ -433,23 +344,10 @@ int stem_launch(const float* x, const float* w_oihw, float* y, int B, int Cin, i
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     dim3 grid(vidc::cdiv(Wo, 64), Ho, B);
     hipStream_t st = vidc::as_stream(stream);
-    // VIDC_DBG_STEM_LOADS (debug / test control only; bits as in the kernel): 3 = the round-5 form with plain loads, 7 = that behind a buffer_inv
+    // VIDC_DBG_STEM_LOADS=3 (test control only): the form that carries the defective packed multiply on purpose (see the kernel)
     static const int dbg_loads = [] { const char* e = getenv("VIDC_DBG_STEM_LOADS"); return e ? atoi(e) : 0; }();
-#define VIDC_STEM_DBG(L_) hipLaunchKernelGGL((stem_conv_kernel<3, true, L_>), grid, dim3(256), 0, st, x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0, warp_params, cx, cy, align_corners)
-    if (warp_params && dbg_loads == 1) VIDC_STEM_DBG(1);
-    else if (warp_params && dbg_loads == 2) VIDC_STEM_DBG(2);
-    else if (warp_params && dbg_loads == 3) VIDC_STEM_DBG(3);
-    else if (warp_params && dbg_loads == 7) VIDC_STEM_DBG(7);
-    else if (warp_params && dbg_loads == 10) VIDC_STEM_DBG(10);
-    else if (warp_params && dbg_loads == 18) VIDC_STEM_DBG(18);
-    else if (warp_params && dbg_loads == 26) VIDC_STEM_DBG(26);
-    else if (warp_params && dbg_loads == 34) VIDC_STEM_DBG(34);
-    else if (warp_params && dbg_loads == 42) VIDC_STEM_DBG(42);
-    else if (warp_params && dbg_loads == 50) VIDC_STEM_DBG(50);
-    else if (warp_params && dbg_loads == 58) VIDC_STEM_DBG(58);
-    else if (warp_params && dbg_loads == 66) VIDC_STEM_DBG(66);
-    else if (warp_params && dbg_loads == 74) VIDC_STEM_DBG(74);
-#undef VIDC_STEM_DBG
+    if (warp_params && dbg_loads == 3)
+        hipLaunchKernelGGL((stem_conv_kernel<3, true, true>), grid, dim3(256), 0, st, x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0, warp_params, cx, cy, align_corners);
     else if (warp_params)
         hipLaunchKernelGGL((stem_conv_kernel<3, true>), grid, dim3(256), 0, st, x, w_oihw, y, H, W, Ho, Wo, Cout, ldy, relu, ysp, split_ch0, warp_params, cx, cy, align_corners);
     else if (Cin == 3)
