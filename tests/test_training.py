@@ -693,6 +693,18 @@ def test_training_loop_on_pipeline_inputs(seeded_weights):
     pipe.rng = np.random.RandomState(3)
     after = pipe._call_cnn(batch)
     assert torch.isfinite(after).all() and float((after - before).abs().mean()) > 1e-4      # the trained weights are the ones that run
+    # the layout travels with the optimizer state, and a network whose tensors were rebound after the trainer was built is refused at the next step
+    # instead of being read through stale base pointers
+    st = tr.flat_state()
+    assert st["layout"] == tr.layout == "per_pyramid" and st["order"][0] == tr.named[0][0]
+    tr.load_flat_state(st)
+    with pytest.raises(RuntimeError, match="layout"):
+        tr.load_flat_state(dict(st, layout="grouped"))
+    pipe.cnn.train()
+    first = tr.named[0][1]
+    first.data = first.data.clone()            # what cnn.float() / .to() do: a new storage behind the same Parameter
+    with pytest.raises(RuntimeError, match="rebound"):
+        tr.step(rgb, normals, depth_in, gt)
 
 
 @gpu

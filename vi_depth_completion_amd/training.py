@@ -156,6 +156,11 @@ class GradientBuckets:
 
 
 class DepthCompletionTrainer:
+    """Build the trainer AFTER `torch.distributed.init_process_group` (and after the network is on its GPU): the flat layout of parameters, gradients, Adam
+    moments and BatchNorm running statistics is chosen here (`self.layout`: "grouped" = the three pyramids interleaved per parameter name, the multi-rank
+    default; "per_pyramid" otherwise) and every launch of the step addresses tensors as base + offset into those buffers.  A later `cnn.to()` / `.float()` /
+    `.cuda()` that rebinds `p.data` is caught at the next `step()` (`_check_bindings`), not silently read through stale pointers."""
+
     def __init__(self, cnn, learning_rate=1e-4, betas=(0.9, 0.999), eps=1e-8):
         if not torch.cuda.is_available():
             raise RuntimeError("DepthCompletionTrainer needs a GPU: the HIP path has no CPU fallback")
@@ -222,6 +227,11 @@ class DepthCompletionTrainer:
                     b.data = self.flat_b[o:o + b.numel()].view(b.shape)
                     o += b.numel()
         self._adjacent = {}
+        self.layout = "grouped" if self.grouped else "per_pyramid"      # (exported with `flat_state()`: moments of one layout are not another's)
+        self._bind_probe = [(self.named[i][1], self.param[self.named[i][0]].data_ptr(), self.grad[self.named[i][0]].data_ptr()) for i in (0, len(self.named) - 1)]
+        if self.grouped:
+            fb = [k for k in self.buf if self.buf[k].dtype == torch.float32 and any(k.startswith(pn + ".") for pn in PYRAMIDS)]
+            self._bind_probe += [(self.buf[k], self.buf[k].data_ptr(), None) for k in (fb[0], fb[-1])] if fb else []
         self.buckets = GradientBuckets(n, compress=("bf16" if os.environ.get("VIDC_TRAIN_GRAD_BF16", "0") == "1" else None))
         # the decoder's parameters (feature*_upsamping, feature_concat) form the tail of the flat buffers (named_parameters order): their
         # gradients are complete when the decoder's backward is, long before the pyramids' -- they are all-reduced while those still run
@@ -439,6 +449,25 @@ class DepthCompletionTrainer:
                 dev, blocks, n = self._pack_table
                 L.check(L.lib().vidc_pack_conv_weights_batched(L.ptr(dev), n, blocks, L.current_stream()), "pack")
         self._packed_fresh = True
+
+    def _check_bindings(self):
+        """O(1) per step: the first and last parameter (and, grouped, running statistic) still live where the flat buffers put them.  `cnn.to()`,
+        `.float()`, `.cuda()` or a `load_state_dict(assign=True)` after construction rebind `.data`; the captured graphs and the grouped launches
+        (base + g * numel) would then read the old storage."""
+        for t, p_ptr, g_ptr in self._bind_probe:
+            if t.data_ptr() != p_ptr or (g_ptr is not None and (t.grad is None or t.grad.data_ptr() != g_ptr)):
+                raise RuntimeError("DepthCompletionTrainer: a parameter / buffer of the network was rebound after the trainer was built (layout %r); "
+                                   "build a new trainer after moving or casting the network" % self.layout)
+
+    def flat_state(self):
+        """Optimizer state for a checkpoint: the flat Adam moments with the layout they belong to and the parameter order that defines the offsets."""
+        return {"layout": self.layout, "order": [k for k, _ in self.named], "m": self.m, "v": self.v, "step_count": self.step_count}
+
+    def load_flat_state(self, st):
+        if st["layout"] != self.layout or list(st["order"]) != [k for k, _ in self.named]:
+            raise RuntimeError("optimizer state of layout %r / another parameter order cannot be loaded into a trainer of layout %r (build the trainer under the "
+                               "same VIDC_TRAIN_GROUPED setting and process-group state)" % (st["layout"], self.layout))
+        self.m.copy_(st["m"]); self.v.copy_(st["v"]); self.step_count = int(st["step_count"])
 
     def _adjacent_base(self, store, keys, suffix):
         """The G tensors `store[k + suffix]` of a grouped layer as ONE contiguous run (group g at base + g * numel): the first one's
@@ -1011,6 +1040,7 @@ class DepthCompletionTrainer:
         by value) stay outside the graphs.  Across ranks the backward is cut where the decoder's part ends: the all-reduce of the
         decoder's gradients (59 % of the 1.24 GB) is started there and runs under the pyramids' backward, the rest follows."""
         multi = self._distributed()
+        self._check_bindings()
         if self.use_graph:
             loss, waits = self._graphed_forward_backward(image, normal, depth_in, depth_gt, multi)
         else:
