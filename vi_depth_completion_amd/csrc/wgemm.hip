@@ -119,20 +119,30 @@ wgemm_stream_kernel(const WArgs a) {
     }
     // stage st (0 .. nst-1) = K units 2 (st % KS) + {0, 1} of group g0 + st / KS; stages beyond nst are issued zero-sourced, so that every wave has
     // exactly LPS loads per stage in flight and the counted waits below need no tail cases
-    int i_gi = 0, i_ku = 0;                           // (group, K stage) of the next stage to issue: advanced by issue(), no division in the stream
-    auto issue = [&](int st, int slot) {
-        const int ku = i_ku;
-        const bool live = st < nst;
-        const long long g = g0 + i_gi;
+    int i_gi = 0, i_ku = 0;                           // (group, K stage) of the next stage to issue: advanced by issue_begin(), no division in the stream
+    long long is_g = 0;                               // the stage being issued: its group, K stage, liveness and ring slot
+    int is_ku = 0, is_slot = 0;
+    bool is_live = false;
+    auto issue_begin = [&](int st, int slot) {
+        is_ku = i_ku;
+        is_live = st < nst;
+        is_g = g0 + i_gi;
+        is_slot = slot;
         if (++i_ku == KS) { i_ku = 0; ++i_gi; }
+    };
+    // one of the stage's LPS instructions; the main loop places them BETWEEN its MFMA groups: issued in one burst at the top of a stage the twelve
+    // waves' DMA instructions queue up in the CU's one address path while the matrix pipes wait (attribution runs: loads + skeleton and MFMAs added up)
+    auto issue_one = [&](int j) {
+        const unsigned add = (unsigned)(((j < LA ? is_g * a.a_gs : is_g * a.b_gs) + (long long)(is_ku * WK + kslice[j]) * BK) * 4);
+        const unsigned voff = (is_live && !(a.dbg & (j < LA ? 4 : 2))) ? off[j] + add : OOB;      // (OOB + add stays >= 2^31: add < 2^31 by validate())
+        float* d = smem + dst[j] + is_slot * smul[j];
+        if (j < LA) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void_t*)d, 16, (int)voff, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void_t*)d, 16, (int)voff, 0, 0, 0);
+    };
+    auto issue = [&](int st, int slot) {
+        issue_begin(st, slot);
 #pragma unroll
-        for (int j = 0; j < LPS; ++j) {
-            const unsigned add = (unsigned)(((j < LA ? g * a.a_gs : g * a.b_gs) + (long long)(ku * WK + kslice[j]) * BK) * 4);
-            const unsigned voff = (live && !(a.dbg & (j < LA ? 4 : 2))) ? off[j] + add : OOB;      // (OOB + add stays >= 2^31: add < 2^31 by validate())
-            float* d = smem + dst[j] + slot * smul[j];
-            if (j < LA) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void_t*)d, 16, (int)voff, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void_t*)d, 16, (int)voff, 0, 0, 0);
-        }
+        for (int j = 0; j < LPS; ++j) issue_one(j);
     };
     // epilogue operands (identity for the Winograd products; one affine + ReLU supported), fetched before the first DMA so that the counted
     // waits below see DMA loads only
@@ -187,7 +197,7 @@ wgemm_stream_kernel(const WArgs a) {
         {
             int fill = slot + NSR - 1;
             if (fill >= NSR) fill -= NSR;             // the slot read in iteration st - 1: free since the barrier
-            issue(st + NSR - 1, fill);
+            issue_begin(st + NSR - 1, fill);          // (its LPS instructions follow one by one behind the MFMA groups below)
         }
         if (kq == 0 && ku == 0 && st > 0) {
             finish(gi - 1);
@@ -216,6 +226,8 @@ wgemm_stream_kernel(const WArgs a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].z, fb[cur].z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].w, fb[cur].w, acc, 0, 0, 0);
+#pragma unroll
+            for (int j = sub; j < LPS; j += BK / 8) issue_one(j);      // behind MFMA group `sub`: instructions sub, sub + 4, ... of the look-ahead stage
             __builtin_amdgcn_sched_barrier(0);
         }
         if (++ku == KS) {                             // the group's last stage: slice 1 publishes its partial (visible behind the next barrier) and starts over
