@@ -407,7 +407,7 @@ def measure(args, dev, rank, world, precision):
                  "ms_per_frame": round(ms / fpt, 3),
                  "timing_note": "per-launch durations are taken on ONE stream (the frame program alone, HIP events between ops, rescaled to its graph replay time); "
                                 "with several lanes launches of the streams overlap and a kernel trace of the run shows longer per-kernel durations: "
-                                "profiles/r5_kernel_stats_fp32.csv / r5_kernel_stats_mixed.csv (--lanes 1) are the traces these numbers agree with",
+                                "profiles/r6_kernel_stats_fp32.csv / r6_kernel_stats_mixed.csv (--lanes 1) are the traces these numbers agree with",
                  "traffic_note": "no PMC pass on file for this instantiation in profiles/pmc_traffic.json (tools/evidence_r5.sh collects them on "
                                  "tools/frame_replay.py: rocprofv3 --pmc on the whole bench process segfaults in rocprofv3 on this pool)"}
             if prec:

@@ -5,7 +5,7 @@
 // the products that differ bit for bit.  Noise: a register-only MFMA loop (bf16 32x32x16 / fp32 32x32x2 / none) on a second stream.
 //
 // Build:  hipcc --offload-arch=gfx950 -O2 -o tools/stale_read/pkmul tools/stale_read/pkmul.hip
-// Run:    tools/stale_read/pkmul [noise: 0 none | 1 bf16 32x32x16 MFMA | 2 fp32 MFMA | 3 plain VALU fma | 4 bf16 32x32x8 MFMA | 5 f16 32x32x16 MFMA] [form 0..9] [seconds]
+// Run:    tools/stale_read/pkmul [noise: 0 none | 1 bf16 32x32x16 MFMA | 2 fp32 MFMA | 3 plain VALU fma | 4 bf16 32x32x8 MFMA | 5 f16 32x32x16 MFMA | 6 bf16 16x16x32 MFMA | 7 fp8 32x32x16 MFMA] [form 0..9] [seconds]
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -100,6 +100,17 @@ __global__ void __launch_bounds__(256) noise(float* __restrict__ sink, int iters
             const h8 a8 = __builtin_bit_cast(h8, fa), b8 = __builtin_bit_cast(h8, fb);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b8, a8, acc1, 0, 0, 0);
+        } else if constexpr (MODE == 6) {      // 16x16x32 bf16 (the other 16-k-class bf16 MFMA of gfx950)
+            typedef float f32x4a __attribute__((ext_vector_type(4)));
+            const bf16x8 a = __builtin_bit_cast(bf16x8, fa), b = __builtin_bit_cast(bf16x8, fb);
+            f32x4a c0 = {acc0[0], acc0[1], acc0[2], acc0[3]}, c1 = {acc1[0], acc1[1], acc1[2], acc1[3]};
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c1, 0, 0, 0);
+            acc0[0] = c0[0]; acc0[1] = c0[1]; acc0[2] = c0[2]; acc0[3] = c0[3]; acc1[0] = c1[0]; acc1[1] = c1[1]; acc1[2] = c1[2]; acc1[3] = c1[3];
+        } else if constexpr (MODE == 7) {      // fp8 32x32x16 (gfx940 already has it)
+            const long a8 = 0x3838383838383838L, b8 = 0x3C3C3C3C3C3C3C3CL;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a8, b8, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b8, a8, acc1, 0, 0, 0);
         } else if constexpr (MODE == 2) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc1, 0, 0, 0);
@@ -127,6 +138,8 @@ static void run(int nmode, double seconds) {
         else if (nmode == 3) hipLaunchKernelGGL(noise<3>, dim3(2048), dim3(256), 0, sn, sink, 200000);
         else if (nmode == 4) hipLaunchKernelGGL(noise<4>, dim3(2048), dim3(256), 0, sn, sink, 4000);
         else if (nmode == 5) hipLaunchKernelGGL(noise<5>, dim3(2048), dim3(256), 0, sn, sink, 4000);
+        else if (nmode == 6) hipLaunchKernelGGL(noise<6>, dim3(2048), dim3(256), 0, sn, sink, 8000);
+        else if (nmode == 7) hipLaunchKernelGGL(noise<7>, dim3(2048), dim3(256), 0, sn, sink, 4000);
     };
     nz(); CK(hipEventRecord(ev[0], sn)); nz(); CK(hipEventRecord(ev[1], sn));
     int turn = 0;
