@@ -182,7 +182,7 @@ _lib = None
 
 def build(force=False, verbose=False):
     """Compile libvidc.so in-tree: hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".map")) or f == "Makefile"]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "vidc.h"))
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
         return LIB_PATH
