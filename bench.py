@@ -86,7 +86,7 @@ def parse():
     ap.add_argument("--no-mixed-leg", action="store_true", help="only the headline leg (every conv in exact fp32 MFMA arithmetic)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short child-process runs of BASELINE configs[4] (training step, bf16) and "
                                                                  "configs[2] (640x480 stream, batch 8, plane head) that the default N=1 run appends as `extra_legs`")
-    ap.add_argument("--extra-legs-budget", type=float, default=100.0, help="seconds of wall clock since the start of this process after which no further extra leg is started")
+    ap.add_argument("--extra-legs-budget", type=float, default=130.0, help="seconds of wall clock since the start of this process after which no further extra leg is started")
     ap.add_argument("--no-sequential-leg", action="store_true", help="skip the short back-to-back _call_cnn measurement (per-frame latency and the "
                                                                        "rate of the operator the reference's harness calls, network_run.py:294-296)")
     ap.add_argument("--sequential-frames", type=int, default=20)
