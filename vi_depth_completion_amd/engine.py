@@ -170,6 +170,9 @@ def tuning_table():
     if _TUNING is None:
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tuning.json")
         _TUNING = json.load(open(path)) if os.path.exists(path) else {}
+        if os.environ.get("VIDC_TUNING_OVERRIDE"):          # experiment knob: '{"M80_N256_K256_k1s1_G144": [40, 64]}' replaces / adds entries (A-B runs of one signature)
+            _TUNING = dict(_TUNING)
+            _TUNING.update(json.loads(os.environ["VIDC_TUNING_OVERRIDE"]))
     return _TUNING
 
 
