@@ -161,7 +161,13 @@ enum vidc_conv_tile { VIDC_TILE_AUTO = 0, VIDC_TILE_128x128 = 1, VIDC_TILE_128x6
                       VIDC_TILE_G96x32_STREAM = 40,
                       /* the same with 64-channel n-tiles, 12 waves and a 3-deep ring: one workgroup per CU with two stages (80 KB) of loads in flight */
                       VIDC_TILE_G96x64_STREAM3 = 41,
-                      VIDC_TILE_COUNT = 42 };
+                      /* Winograd F(4x4, 3x3) in one launch (csrc/wfused.hip): the descriptor of a 3x3 / stride 1 / pad 1 conv in fp32, flags within
+                         RELU1 | AFFINE2 | RELU2, Cin % 64 == 0 -- except that `w` holds U = G g G^T of vidc_winograd_weight_transform(m = 4),
+                         [36][Cout][Cin] per group (w_gs = 36 * Cout * Cin).  Input transform, the 36 products and the output transform + epilogue of a
+                         block of 16 tiles x 32 output channels run in one workgroup: no V / M tensors, no workspace.  For the small maps
+                         (a workgroup multiplies for 36 * Cin / 32 stages: a few hundred workgroups should cover the layer). */
+                      VIDC_TILE_WINO4_FUSED = 42,
+                      VIDC_TILE_COUNT = 43 };
 
 /* Arithmetic of the contraction.  FP32: v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32, the reference mode).
  * BF16X3: every operand is split as x = hi + lo (bf16 each, round-to-nearest-even) and each product is computed as

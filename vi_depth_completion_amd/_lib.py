@@ -27,8 +27,9 @@ TILE_NAMES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: 
               9: "32x32k8", 10: "32x64k2d5", 11: "32x32k4d4", 12: "32x128d6", 13: "64x64k2d4", 14: "32x64k2L", 15: "32x64k2d5L", 16: "32x32k4d4L", 17: "64x64L", 18: "64x64k2d4L",
               19: "64x128L", 20: "128x64L", 21: "64x32k2", 22: "64x32k2d5", 23: "64x32k2d5L", 24: "128x128d3", 25: "128x128d3L", 26: "256x128", 27: "128x256",
               28: "32x64k2d2", 29: "64x64d2", 30: "32x32k4d2", 31: "64x128d2", 32: "64x32k2d2",
-              33: "128x128d4P", 34: "128x128d3P", 35: "64x64d4P", 36: "128x64d4P", 37: "64x64k2d4P", 38: "64x32k2d5P", 39: "32x64k2d5P", 40: "g96x32s", 41: "g96x64s3"}
-TILE_COUNT = 42
+              33: "128x128d4P", 34: "128x128d3P", 35: "64x64d4P", 36: "128x64d4P", 37: "64x64k2d4P", 38: "64x32k2d5P", 39: "32x64k2d5P", 40: "g96x32s", 41: "g96x64s3", 42: "wino4f"}
+TILE_COUNT = 43
+TILE_WINO4_FUSED = 42
 PREC_FP32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 SPLITK_COUNTERS = 16384            # VIDC_SPLITK_COUNTERS: ticket counters at the head of a split-K workspace
 

@@ -41,6 +41,8 @@ __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // csrc/wgemm.hip: the streamed grouped GEMM behind vidc_conv2d_bn_act's tile VIDC_TILE_G96x32_STREAM
 int launch_wgemm_stream(const vidc_conv_desc& d, hipStream_t st);
+// csrc/wfused.hip: Winograd F(4x4, 3x3) in one launch behind the tile VIDC_TILE_WINO4_FUSED
+int launch_wino4_fused(const vidc_conv_desc& d, hipStream_t st);
 
 // ---- split-bf16 ("bf16x3") operand format -------------------------------------------------------------------------
 // x = hi + lo with hi = bf16(x), lo = bf16(x - hi), round-to-nearest-even like torch's .to(bfloat16) (no NaN inputs here).

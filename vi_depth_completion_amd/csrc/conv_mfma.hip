@@ -857,6 +857,7 @@ constexpr TileInfo kTiles[VIDC_TILE_COUNT] = {
     // ---- csrc/wgemm.hip: one workgroup streams a chunk of groups of a few-row grouped GEMM through one continuous ring ----
     {96, 32, 3, 1, 2, 2},     // VIDC_TILE_G96x32_STREAM  77 KB
     {96, 64, 3, 2, 2, 3},     // VIDC_TILE_G96x64_STREAM3 145 KB
+    {16, 32, 1, 2, 1, 2},     // VIDC_TILE_WINO4_FUSED    144 KB (16 tiles x 32 channels x all 36 positions: csrc/wfused.hip)
 };
 constexpr int kFirstLoaderTile = VIDC_TILE_32x64_K2_L;
 
@@ -1046,6 +1047,7 @@ extern "C" int vidc_conv2d_bn_act(const vidc_conv_desc* d, vidc_stream_t stream)
         case VIDC_TILE_32x64_K2_D5_P:  rc = launch_tile<32, 64, 1, 2, 2, 5, 2>(a, st, dd.precision); break;
         case VIDC_TILE_G96x32_STREAM:
         case VIDC_TILE_G96x64_STREAM3: rc = vidc::launch_wgemm_stream(dd, st); break;
+        case VIDC_TILE_WINO4_FUSED:    rc = vidc::launch_wino4_fused(dd, st); break;
         default: VIDC_REQUIRE(false, VIDC_ERR_SHAPE, "conv: bad tile");
     }
     return rc;

@@ -264,6 +264,38 @@ def conv3x3_winograd(x, w_oihw_groups, scale1, shift1, m, relu1=False, scale2=No
     return winograd_output_transform(mm, B, H, W, cout, m, scale1, shift1, relu1, scale2, shift2, relu2, split_out, no_f32_out)
 
 
+def conv3x3_winograd_fused(x, w_oihw_groups, scale1, shift1, relu1=False, scale2=None, shift2=None, relu2=False, u=None):
+    """The same layer as conv3x3_winograd(m = 4) in ONE launch (csrc/wfused.hip, tile VIDC_TILE_WINO4_FUSED): input transform, the 36 products
+    and the output transform + epilogue per block of 16 tiles x 32 output channels; no V / M tensors.  fp32 only.
+    x NHWC (B,H,W,G*cin); w_oihw_groups: list of G (cout,cin,3,3) tensors (or `u`: their transformed weights (G*36,cout,cin)); scale / shift: (G, cout)."""
+    _dev(x, scale1, shift1)
+    x = x.contiguous()
+    G = len(w_oihw_groups) if u is None else u.shape[0] // 36
+    B, H, W, Cc = x.shape
+    cin = Cc // G
+    if u is None:
+        u = torch.cat([winograd_weight_transform(w, 4) for w in w_oihw_groups], 0)          # (G*36, cout, cin): group gg's 36 positions together
+    cout = u.shape[1]
+    y = torch.empty((B, H, W, G * cout), dtype=torch.float32, device=x.device)
+    d = L.ConvDesc()
+    s1, b1 = scale1.contiguous().float().view(-1), shift1.contiguous().float().view(-1)
+    d.x, d.w, d.y, d.scale1, d.shift1 = L.ptr(x), L.ptr(u), L.ptr(y), L.ptr(s1), L.ptr(b1)
+    flags = (L.RELU1 if relu1 else 0)
+    keep = [s1, b1]
+    if scale2 is not None:
+        s2, b2 = scale2.contiguous().float().view(-1), shift2.contiguous().float().view(-1)
+        d.scale2, d.shift2 = L.ptr(s2), L.ptr(b2)
+        keep += [s2, b2]
+        flags |= L.AFFINE2 | (L.RELU2 if relu2 else 0)
+    d.B, d.H, d.W, d.Cin, d.ldx = B, H, W, cin, Cc
+    d.Ho, d.Wo, d.Cout, d.ldy = H, W, cout, G * cout
+    d.KH, d.KW, d.stride, d.pad, d.flags, d.groups = 3, 3, 1, 1, flags, G
+    d.x_gs, d.w_gs, d.y_gs, d.p_gs = cin, 36 * cout * cin, cout, (cout if s1.numel() >= G * cout else 0)
+    d.tile, d.splitk, d.precision = L.TILE_WINO4_FUSED, 1, L.PREC_FP32
+    L.check(L.lib().vidc_conv2d_bn_act(C.byref(d), L.current_stream()), "conv2d_bn_act (fused Winograd)")
+    return y
+
+
 def clock_stamps(n, device=None):
     """Buffer for n stamps of `clock_stamp`."""
     return torch.zeros((n, L.CLOCK_STAMP_WGS, 4), dtype=torch.int64, device=device if device is not None else "cuda")
