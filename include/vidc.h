@@ -162,8 +162,8 @@ enum vidc_conv_tile { VIDC_TILE_AUTO = 0, VIDC_TILE_128x128 = 1, VIDC_TILE_128x6
                       /* the same with 64-channel n-tiles, 12 waves and a 3-deep ring: one workgroup per CU with two stages (80 KB) of loads in flight */
                       VIDC_TILE_G96x64_STREAM3 = 41,
                       /* Winograd F(4x4, 3x3) in one launch (csrc/wfused.hip): the descriptor of a 3x3 / stride 1 / pad 1 conv in fp32, flags within
-                         RELU1 | AFFINE2 | RELU2, Cin % 64 == 0 -- except that `w` holds U = G g G^T of vidc_winograd_weight_transform(m = 4),
-                         [36][Cout][Cin] per group (w_gs = 36 * Cout * Cin).  Input transform, the 36 products and the output transform + epilogue of a
+                         RELU1 | AFFINE2 | RELU2, Cin % 32 == 0 -- except that `w` holds U = G g G^T of vidc_winograd_weight_transform(m = 4) re-ordered by
+                         vidc_winograd_weight_pack_fused, 36 * Cout * Cin floats per group (= w_gs).  Input transform, the 36 products and the output transform + epilogue of a
                          block of 16 tiles x 32 output channels run in one workgroup: no V / M tensors, no workspace.  For the small maps
                          (a workgroup multiplies for 36 * Cin / 32 stages: a few hundred workgroups should cover the layer). */
                       VIDC_TILE_WINO4_FUSED = 42,
@@ -207,6 +207,10 @@ int vidc_winograd_weight_transform(const float* w_oihw, float* u, int Cout, int 
 /* x NHWC [B][H][W][ldx] (C = G * Cin channels) -> V = B^T d B, zero padding 1.  split != 0: V is written as the split-bf16 image
  * (the operand format of VIDC_PREC_BF16X3; Cin % 32 == 0) instead of fp32.  ldv: values per row of V (0 = dense, a*a*C; larger when
  * x / v address a contiguous range of the groups of a wider tensor). */
+/* U of vidc_winograd_weight_transform(m = 4) ([36][Cout][Cin], one group) -> the order the fused kernel (VIDC_TILE_WINO4_FUSED) streams it in:
+ * [36][Cout / 32][Cin / 32][2][2][64 lanes][4] with lane = 16 kq + n holding U[pos][32 nb + 16 nblk + n][32 kc + 8 kq + 4 h + 0..3] -- every load
+ * instruction of a product wave is 1 KiB contiguous.  Same size; not in place.  Cout % 32 == 0, Cin % 32 == 0. */
+int vidc_winograd_weight_pack_fused(const float* u, float* u_packed, int Cout, int Cin, vidc_stream_t stream);
 int vidc_winograd_input_transform(const float* x, void* v, int B, int H, int W, int C, int ldx, int Cin, int m, int split, int ldv,
                                   vidc_stream_t stream);
 /* M -> y NHWC [B][Ho][Wo][ldy] = epilogue(A^T M A): flags = VIDC_RELU1 | VIDC_AFFINE2 | VIDC_RELU2 | VIDC_SPLIT_OUT | VIDC_NO_F32_OUT with the

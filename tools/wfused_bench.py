@@ -40,7 +40,7 @@ def main():
     for (B, H, W, cin, cout, G, label, tile) in SHAPES:
         x = torch.randn(B, H, W, G * cin, device=DEV)
         copies = max(2, min(16, (1 << 29) // (G * 36 * cout * cin * 4)))
-        us = [torch.randn(G * 36, cout, cin, device=DEV) * 0.05 for _ in range(copies)]
+        us = [torch.randn(G * 36, cout, cin, device=DEV) * 0.05 for _ in range(copies)]      # (random values: the fused launch reads them in its packed order, the GEMM as [pos][Cout][Cin])
         s1, b1 = torch.rand(G, cout, device=DEV) + 0.5, torch.randn(G, cout, device=DEV) * 0.1
         t_f = timed(lambda i: ops.conv3x3_winograd_fused(x, None, s1, b1, relu1=True, u=us[i % copies]), a.iters)
         # the three launches separately (the python wrappers allocate; time each kernel family on its own)

@@ -121,6 +121,7 @@ SIGNATURES = {
     "vidc_stem_wgrad": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vidc_winograd_tiles": (C.c_int, [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vidc_winograd_weight_transform": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
+    "vidc_winograd_weight_pack_fused": (C.c_int, [_vp, _vp, _i, _i, _vp]),
     "vidc_winograd_input_transform": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_winograd_output_transform": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vidc_stem_conv3x3s2": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),

@@ -264,17 +264,28 @@ def conv3x3_winograd(x, w_oihw_groups, scale1, shift1, m, relu1=False, scale2=No
     return winograd_output_transform(mm, B, H, W, cout, m, scale1, shift1, relu1, scale2, shift2, relu2, split_out, no_f32_out)
 
 
+def winograd_weight_pack_fused(u):
+    """U (36, Cout, Cin) of winograd_weight_transform(w, 4) -> the fragment order the fused kernel streams (same shape / bytes, another order)."""
+    _dev(u)
+    u = u.contiguous().float()
+    a2, co, ci = u.shape
+    assert a2 == 36
+    out = torch.empty_like(u)
+    L.check(L.lib().vidc_winograd_weight_pack_fused(L.ptr(u), L.ptr(out), co, ci, L.current_stream()), "winograd_weight_pack_fused")
+    return out
+
+
 def conv3x3_winograd_fused(x, w_oihw_groups, scale1, shift1, relu1=False, scale2=None, shift2=None, relu2=False, u=None):
     """The same layer as conv3x3_winograd(m = 4) in ONE launch (csrc/wfused.hip, tile VIDC_TILE_WINO4_FUSED): input transform, the 36 products
     and the output transform + epilogue per block of 16 tiles x 32 output channels; no V / M tensors.  fp32 only.
-    x NHWC (B,H,W,G*cin); w_oihw_groups: list of G (cout,cin,3,3) tensors (or `u`: their transformed weights (G*36,cout,cin)); scale / shift: (G, cout)."""
+    x NHWC (B,H,W,G*cin); w_oihw_groups: list of G (cout,cin,3,3) tensors (or `u`: their transformed AND packed weights, (G*36,cout,cin) floats); scale / shift: (G, cout)."""
     _dev(x, scale1, shift1)
     x = x.contiguous()
     G = len(w_oihw_groups) if u is None else u.shape[0] // 36
     B, H, W, Cc = x.shape
     cin = Cc // G
     if u is None:
-        u = torch.cat([winograd_weight_transform(w, 4) for w in w_oihw_groups], 0)          # (G*36, cout, cin): group gg's 36 positions together
+        u = torch.cat([winograd_weight_pack_fused(winograd_weight_transform(w, 4)) for w in w_oihw_groups], 0)      # (G*36, cout, cin) floats, fragment order
     cout = u.shape[1]
     y = torch.empty((B, H, W, G * cout), dtype=torch.float32, device=x.device)
     d = L.ConvDesc()
