@@ -110,3 +110,41 @@ def test_refusals():
     x, w, s1, b1 = _case(49, 1, 8, 8, 48, 32, 1)          # Cin % 32 != 0
     with pytest.raises(RuntimeError, match="Cin"):
         ops.conv3x3_winograd_fused(nhwc(x).to(DEV), [t.to(DEV) for t in w], s1.to(DEV), b1.to(DEV))
+
+
+def test_engine_records_one_launch_per_layer_and_the_stream_keeps_its_properties(seeded_weights, monkeypatch):
+    """Behind VIDC_WINO_FUSED the engine records the small-map F(4x4) layers as ONE conv op on the fused tile (no wino_in / wino_out around them);
+    the whole path stays within the fp32 bar of the default recording, and an item's depth map is bit-identical whatever partner, slot or lane count it
+    had -- including the first / drain ticks, which run the layer with one and three of its four groups (engine.Program.group_variant)."""
+    from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
+    monkeypatch.setenv("VIDC_PRECISION", "fp32")
+    frames = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in S.synthetic_batch(1, 240, 320, 1234, frame0=500 + i).items()} for i in range(7)]
+    rng_of = lambda f: np.random.RandomState(7000 + f)      # noqa: E731
+
+    def pipe():
+        p = DepthCompletionPipeline(enriched_samples=200)
+        p.load_state_dicts(seeded_weights["sn"], seeded_weights["dc"])
+        p.plane_masks_extraction = FixedPlaneMask(S.plane_id_map(240, 320))
+        return p
+
+    def run(p, first, last, lanes, F=4):
+        return [o.cpu() for o in p.run_interleaved(iter(frames[first:last]), lanes=lanes, frames_per_launch=F, frame_rng=lambda i: rng_of(first + i))]
+
+    monkeypatch.delenv("VIDC_WINO_FUSED", raising=False)
+    base = run(pipe(), 0, 7, 1)
+    monkeypatch.setenv("VIDC_WINO_FUSED", "320")
+    p = pipe()
+    ref = run(p, 0, 7, 1)
+    names = p.frame_program(4, 240, 320).op_names          # (lane 0 runs the pipeline's own cached program of that batch)
+    assert sum("@wino4f" in n for n in names) >= 22, "the layer-3 conv2 layers were not recorded on the fused tile"
+    assert sum(n.startswith("wino_in") for n in names) < 38
+    for f, (a, b) in enumerate(zip(base, ref)):
+        assert float((a - b).pow(2).mean().sqrt()) < 2e-5, f
+    assert any(not torch.equal(a, b) for a, b in zip(base, ref)), "the fused layers did not run"
+    for lanes in (2, 3):
+        got = run(p, 0, 7, lanes)
+        for f, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a, b), "frame %d differs with %d lanes" % (f, lanes)
+    got = run(p, 1, 7, 2)
+    for f, b in zip(range(1, 7), got):
+        assert torch.equal(ref[f], b), "frame %d differs when grouped with other frames" % f

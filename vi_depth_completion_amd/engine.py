@@ -114,6 +114,20 @@ class WeightStore:
             self._cache[ck] = out
         return self._cache[ck]
 
+    def packed_winograd_fused(self, keys, dry_run=False):
+        """U of F(4 x 4, 3x3) in the fragment order of the one-launch kernel (vidc_winograd_weight_pack_fused): 36 Cout Cin floats per group."""
+        ck = ("winof",) + tuple(keys)
+        if ck not in self._cache:
+            u = self.packed_winograd(keys, 4, dry_run, 0)
+            out = torch.empty_like(u)
+            if dry_run:
+                return out
+            co, ci = u.shape[1], u.shape[2]
+            for g in range(len(keys)):
+                L.check(L.lib().vidc_winograd_weight_pack_fused(L.ptr(u[g * 36]), L.ptr(out[g * 36]), co, ci, L.current_stream()), "winograd weights (fused order)")
+            self._cache[ck] = out
+        return self._cache[ck]
+
     def identity_affine(self, co, device):
         ck = ("id", co, str(device))
         if ck not in self._cache:
@@ -330,6 +344,9 @@ class Program:
         if wm:
             self.ref_flops += int(round(flops * ref_flops_scale))
             self.direct_flops += flops
+            fuse_max = int(os.environ.get("VIDC_WINO_FUSED", "0"))      # experiment knob: F(4x4) layers of at most this many tiles as ONE launch
+            if wm == 4 and self.mode == "fp32" and fuse_max and self.B * (-(-Ho // 4)) * (-(-Wo // 4)) <= fuse_max and ci % 32 == 0 and ci <= int(os.environ.get("VIDC_WINO_FUSED_MAXC", "256")) and not (flags & ~(L.RELU1 | L.AFFINE2 | L.RELU2)):
+                return self._conv_winograd_fused(x, y, keys, bn, bn2, flags, (co, ci, Ho, Wo))
             return self._conv_winograd(x, y, keys, bn, bn2, flags, wm, (co, ci, Ho, Wo))
         self.flops += flops
         self.direct_flops += flops
@@ -367,6 +384,17 @@ class Program:
                    geom=(co, ci, 1, 1, 1, tiles), dilation=1, wino=m)
         self._emit("wino_out", [Mm], [y], mm=Mm, y=y, keys=keys, bn=_keys(bn) if bn is not None else None,
                    bn2=_keys(bn2) if bn2 is not None else None, flags=flags, m=m, cout=co)
+        return y
+
+    def _conv_winograd_fused(self, x, y, keys, bn, bn2, flags, geom):
+        """The same layer as ONE launch (csrc/wfused.hip, tile VIDC_TILE_WINO4_FUSED): fp32, F(4 x 4), no V / M buffers.  Only behind VIDC_WINO_FUSED
+        (measured equal to the three launches alone)."""
+        co, ci, Ho, Wo = geom
+        tiles = self.B * (-(-Ho // 4)) * (-(-Wo // 4))
+        self.flops += 2 * tiles * 36 * len(keys) * co * ci
+        self._emit("conv", [x], [y], x=x, y=y, keys=keys, precision=L.PREC_FP32, bn=_keys(bn) if bn is not None else None,
+                   bn2=_keys(bn2) if bn2 is not None else None, residual=None, flags=flags, stride=1, pad=1, geom=(co, ci, 3, 3, Ho, Wo), dilation=1,
+                   wino_fused=tiles)
         return y
 
     def split(self, x):
@@ -612,9 +640,13 @@ class Program:
         co, ci, kh, kwid, Ho, Wo = kw["geom"]
         prec = kw["precision"]
         wm = kw.get("wino", 0)
+        wf = kw.get("wino_fused", 0)
         if wm:
             wp = self.ws.packed_winograd([k for k in keys], wm, dry_run, prec)
             s1, b1 = self.ws.identity_affine(co, wp.device)
+        elif wf:
+            wp = self.ws.packed_winograd_fused([k for k in keys], dry_run)
+            s1, b1 = self.ws.affine(list(keys), list(kw["bn"]) if kw["bn"] is not None else None)
         else:
             wp = self.ws.packed([k for k in keys], dry_run, prec)
             s1, b1 = self.ws.affine(list(keys), list(kw["bn"]) if kw["bn"] is not None else None)
@@ -639,6 +671,10 @@ class Program:
             d.groups, d.p_gs = len(keys) * (wm + 2) * (wm + 2), 0
         d.tile, d.splitk, d.precision = 0, 1, prec
         sig = conv_signature(d)
+        if wf:          # one launch: the transformed weights of a group are 36 Cout Cin floats; shown with the signature of the products it executes
+            d.w_gs, d.tile = 36 * co * ci, L.TILE_WINO4_FUSED
+            self._keep += [wp, s1, b1]
+            return "conv:%s@wino4f:%s:sk1:fp32 M%d_N%d_K%d_k1s1_G%d flags=0x%x" % (keys[0], L.TILE_NAMES[d.tile], wf, co, ci, 36 * len(keys), d.flags)
         if os.environ.get("VIDC_FORCE_TILE"):           # (tests / A-B runs: one tiling for every conv)
             d.tile, d.splitk = int(os.environ["VIDC_FORCE_TILE"]), 1
         else:
