@@ -113,7 +113,8 @@ def test_refusals():
 
 
 def test_engine_records_one_launch_per_layer_and_the_stream_keeps_its_properties(seeded_weights, monkeypatch):
-    """Behind VIDC_WINO_FUSED the engine records the small-map F(4x4) layers as ONE conv op on the fused tile (no wino_in / wino_out around them);
+    """Where the measured table says 5 (or behind VIDC_WINO_FUSED) the engine records an F(4x4) layer as ONE conv op on the fused tile (no wino_in /
+    wino_out around it);
     the whole path stays within the fp32 bar of the default recording, and an item's depth map is bit-identical whatever partner, slot or lane count it
     had -- including the first / drain ticks, which run the layer with one and three of its four groups (engine.Program.group_variant)."""
     from vi_depth_completion_amd.pipeline import DepthCompletionPipeline, FixedPlaneMask
@@ -130,14 +131,19 @@ def test_engine_records_one_launch_per_layer_and_the_stream_keeps_its_properties
     def run(p, first, last, lanes, F=4):
         return [o.cpu() for o in p.run_interleaved(iter(frames[first:last]), lanes=lanes, frames_per_launch=F, frame_rng=lambda i: rng_of(first + i))]
 
-    monkeypatch.delenv("VIDC_WINO_FUSED", raising=False)
+    from vi_depth_completion_amd import engine as E
+    monkeypatch.setenv("VIDC_WINO_FUSED", "0")               # the three launches everywhere, whatever the table says
     base = run(pipe(), 0, 7, 1)
-    monkeypatch.setenv("VIDC_WINO_FUSED", "320")
+    # the way a measured table adopts it: verdict 5 (= F(4 x 4) in one launch) for the layer-3 conv2 of the four-pyramid launch at program batch 4
+    monkeypatch.delenv("VIDC_WINO_FUSED", raising=False)
+    monkeypatch.setenv("VIDC_TUNING_OVERRIDE", '{"W:M1200_N256_K2304_k3s1_G4": [5, 0]}')      # (240 x 320 frames: 15 x 20 maps in layer 3)
+    monkeypatch.setattr(E, "_TUNING", None)
     p = pipe()
     ref = run(p, 0, 7, 1)
     names = p.frame_program(4, 240, 320).op_names          # (lane 0 runs the pipeline's own cached program of that batch)
-    assert sum("@wino4f" in n for n in names) >= 22, "the layer-3 conv2 layers were not recorded on the fused tile"
-    assert sum(n.startswith("wino_in") for n in names) < 38
+    assert sum("@wino4f" in n for n in names) == 22, "the layer-3 conv2 layers were not recorded on the fused tile"
+    assert sum(n.startswith("wino_in") for n in names) == sum("@wino" in n and "@wino4f" not in n for n in names)      # transforms only around the other Winograd layers
+    monkeypatch.setattr(E, "_TUNING", None)                # (later tests read the committed table again)
     for f, (a, b) in enumerate(zip(base, ref)):
         assert float((a - b).pow(2).mean().sqrt()) < 2e-5, f
     assert any(not torch.equal(a, b) for a, b in zip(base, ref)), "the fused layers did not run"

@@ -76,6 +76,21 @@ def test_winograd_choice_policy(monkeypatch):
     assert E.winograd_choice(32, 720, 1280, 768, 768, 3, 3, 1, 1, 1, 1) == 0
 
 
+def test_winograd_choice_verdict_5_is_for_its_own_group_count_only(monkeypatch):
+    """Table verdict 5 = F(4 x 4) in ONE launch (csrc/wfused.hip): measured for one group count; programs that borrow the entry of another group
+    count (stand-alone 1- / 3-group programs) get the three-launch F(4 x 4)."""
+    from vi_depth_completion_amd import engine as E
+    monkeypatch.delenv("VIDC_WINOGRAD", raising=False)
+    monkeypatch.setenv("VIDC_TUNING_OVERRIDE", '{"W:M1280_N256_K2304_k3s1_G4": [5, 0]}')
+    monkeypatch.setattr(E, "_TUNING", None)
+    try:
+        assert E.winograd_choice(4, 16, 20, 256, 256, 3, 3, 1, 1, 1, 4, precision="fp32") == 5
+        assert E.winograd_choice(4, 16, 20, 256, 256, 3, 3, 1, 1, 1, 2, precision="fp32") == 4       # no entry of its own: borrows G4's, as three launches
+        assert E.winograd_choice(4, 16, 20, 256, 256, 3, 3, 1, 1, 1, 4, precision="mixed") == 0
+    finally:
+        E._TUNING = None
+
+
 def test_recorded_program_has_winograd_triples(monkeypatch):
     """Dry-run recording (no HIP call): every qualifying 3x3 conv becomes wino_in -> grouped 1x1 GEMM -> wino_out; executed FLOPs drop,
     the reference-formulation FLOPs do not."""

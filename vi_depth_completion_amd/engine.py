@@ -213,7 +213,7 @@ def _capped_tile(tile, cap_kb):
 
 def winograd_mode():
     """VIDC_WINOGRAD=auto : (default) 3x3 / stride 1 / pad 1 convs with >= 128 input channels run as Winograd F(m x m, 3x3) GEMMs
-                             (csrc/winograd.hip): the entry "W:<direct signature>" of the measured table picks m in {0, 2, 4}, else (fp32 mode
+                             (csrc/winograd.hip): the entry "W:<direct signature>" of the measured table picks m in {0, 2, 4} (5 = m 4 in ONE launch, fp32 only), else (fp32 mode
                              only) m = 4 on maps of at least 24 rows and columns and m = 2 below; the mixed mode without a table entry stays direct.
        VIDC_WINOGRAD=0 / 2 / 4 : never / always that m where the layer qualifies (tests, A/B runs)."""
     return os.environ.get("VIDC_WINOGRAD", "auto")
@@ -234,6 +234,8 @@ def winograd_choice(B, H, W, co, ci, kh, kw, stride, padding, dilation, G, mode=
                 break
         if ent is not None:
             m = int(ent[1 if precision == "mixed" else 0]) if isinstance(ent, (list, tuple)) else int(ent)
+            if m == 5 and gg != G:                 # 5 = F(4 x 4) in ONE launch (csrc/wfused.hip): measured for exactly that group count
+                m = 4
         elif ci < 128 or precision == "mixed":
             # no measured verdict for this shape.  fp32: the heuristic below.  mixed: the direct form -- in the committed table the bf16x3
             # direct conv beats the transform + GEMM + transform triple for 73 of 112 layers (three launches and two HBM round trips through
@@ -242,9 +244,10 @@ def winograd_choice(B, H, W, co, ci, kh, kw, stride, padding, dilation, G, mode=
         else:
             m = 4 if min(H, W) >= 24 else 2
     if m:
-        a2 = (m + 2) * (m + 2)
-        tiles = B * (-(-H // m)) * (-(-W // m))
-        if tiles * a2 * G * max(ci, co) * 4 >= 2 ** 31 or B * (-(-H // m)) > 65535:     # 32-bit buffer offsets in the GEMM kernel / grid.y
+        mt = 4 if m == 5 else m
+        a2 = (mt + 2) * (mt + 2)
+        tiles = B * (-(-H // mt)) * (-(-W // mt))
+        if tiles * a2 * G * max(ci, co) * 4 >= 2 ** 31 or B * (-(-H // mt)) > 65535:     # 32-bit buffer offsets in the GEMM kernel / grid.y
             return 0
     return m
 
@@ -344,10 +347,15 @@ class Program:
         if wm:
             self.ref_flops += int(round(flops * ref_flops_scale))
             self.direct_flops += flops
-            fuse_max = int(os.environ.get("VIDC_WINO_FUSED", "0"))      # experiment knob: F(4x4) layers of at most this many tiles as ONE launch
-            if wm == 4 and self.mode == "fp32" and fuse_max and self.B * (-(-Ho // 4)) * (-(-Wo // 4)) <= fuse_max and ci % 32 == 0 and ci <= int(os.environ.get("VIDC_WINO_FUSED_MAXC", "256")) and not (flags & ~(L.RELU1 | L.AFFINE2 | L.RELU2)):
+            # F(4 x 4) in ONE launch (csrc/wfused.hip): where the measured table says 5, or -- VIDC_WINO_FUSED=<tiles>, A-B runs -- every fp32
+            # F(4 x 4) layer of at most that many tiles and VIDC_WINO_FUSED_MAXC (256) input channels; VIDC_WINO_FUSED=0 keeps the three launches everywhere
+            knob = os.environ.get("VIDC_WINO_FUSED")
+            fusable = self.mode == "fp32" and ci % 16 == 0 and not (flags & ~(L.RELU1 | L.AFFINE2 | L.RELU2))
+            forced = (wm in (4, 5) and knob is not None and int(knob) > 0 and self.B * (-(-Ho // 4)) * (-(-Wo // 4)) <= int(knob)
+                      and ci <= int(os.environ.get("VIDC_WINO_FUSED_MAXC", "256")))
+            if fusable and (forced or (wm == 5 and knob is None)):
                 return self._conv_winograd_fused(x, y, keys, bn, bn2, flags, (co, ci, Ho, Wo))
-            return self._conv_winograd(x, y, keys, bn, bn2, flags, wm, (co, ci, Ho, Wo))
+            return self._conv_winograd(x, y, keys, bn, bn2, flags, 4 if wm == 5 else wm, (co, ci, Ho, Wo))
         self.flops += flops
         self.direct_flops += flops
         self.ref_flops += int(round(flops * ref_flops_scale))
