@@ -1,7 +1,7 @@
 """CPU: the BUILT libvidc.so carries no instance of the instruction encoding that round 6 isolated as defective on MI355X -- packed-fp32 VALU arithmetic
 whose LOW result half selects the HIGH dword of src1 (`v_pk_mul_f32 ... op_sel:[0,1]`): wrong low halves in lanes 48-63 beside a wave issuing the 16-k
 bf16 / f16 MFMAs (tools/stale_read/pkmul.hip; profiles/EXPERIMENTS.md).  hipcc's SLP vectoriser had put it into the fused stem's plain-load form (the
-round-5 "stale read") and into warp_params_kernel (live lanes 48-63 from program batch 49 on); those two files are built with -fno-slp-vectorize
+round-5 "stale read") and into warp_params_kernel (live lanes 48-63 from program batch 49 on); those files (and, since, wfused.hip, where this test caught it) are built with -fno-slp-vectorize
 (csrc/Makefile: everywhere else packed fp32 stays, it is worth 2.6 % of the conv kernels) and this test disassembles what was built.  The one allowed instance is the debug kernel that carries it on purpose (the stress test's positive control)."""
 import os
 import sys
