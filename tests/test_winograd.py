@@ -119,6 +119,42 @@ def test_recorded_program_has_winograd_triples(monkeypatch):
             assert desc.ldx == a2 * kwargs["x"].C * kwargs["x"].G and w.c_ops[i].u.g.i[8] == desc.ldx and w.c_ops[i + 2].u.g.i[8] == desc.ldy
 
 
+def test_recorded_program_with_one_launch_layers(monkeypatch):
+    """Dry-run recording with VIDC_WINO_FUSED (no HIP call): a qualifying F(4 x 4) layer is ONE conv op on the fused tile -- the descriptor of the 3x3
+    conv with the real affine, w_gs = 36 Cout Cin -- and no transform ops around it; executed / reference FLOPs are those of the three-launch form."""
+    import vi_depth_completion_amd._lib as L
+    if not os.path.exists(L.LIB_PATH):
+        pytest.skip("libvidc.so not built")
+    from vi_depth_completion_amd.networks.surface_normal import SurfaceNormalPrediction
+    monkeypatch.setenv("VIDC_PRECISION", "fp32")
+    monkeypatch.setenv("VIDC_WINOGRAD", "4")
+    progs = {}
+    for knob in ("0", "100000"):
+        monkeypatch.setenv("VIDC_WINO_FUSED", knob)
+        monkeypatch.setenv("VIDC_WINO_FUSED_MAXC", "4096")
+        sn = SurfaceNormalPrediction(fc_img=np.array([202.0, 202.0])).eval()
+        progs[knob] = sn.build_program(1, torch.device("cpu"), dry_run=True)
+    t, f = progs["0"], progs["100000"]
+    kt, kf = [k for k, *_ in t.ops], [k for k, *_ in f.ops]
+    assert kt.count("wino_in") > 0 and kf.count("wino_in") == 0 and kf.count("wino_out") == 0
+    assert kf.count("conv") == kt.count("conv") and len(kf) == len(kt) - 2 * kt.count("wino_in")
+    assert (f.flops, f.ref_flops, f.direct_flops) == (t.flops, t.ref_flops, t.direct_flops)
+    n = 0
+    for i, (kind, _r, _w, kwargs) in enumerate(f.ops):
+        if kind == "conv" and kwargs.get("wino_fused"):
+            d = f.c_ops[i].u.conv
+            assert d.tile == L.TILE_WINO4_FUSED and (d.KH, d.KW, d.stride, d.pad) == (3, 3, 1, 1) and d.precision == L.PREC_FP32
+            assert d.w_gs == 36 * d.Cout * d.Cin and d.p_gs == d.Cout and not (d.flags & ~(L.RELU1 | L.AFFINE2 | L.RELU2))
+            assert "@wino4f" in f.op_names[i]
+            n += 1
+    assert n == kt.count("wino_in")
+    # the mixed mode never records it
+    monkeypatch.setenv("VIDC_PRECISION", "mixed")
+    sn = SurfaceNormalPrediction(fc_img=np.array([202.0, 202.0])).eval()
+    m = sn.build_program(1, torch.device("cpu"), dry_run=True)
+    assert not any(kw.get("wino_fused") for _k, _r, _w, kw in m.ops)
+
+
 # ---- GPU ------------------------------------------------------------------------------------------------------------------------------
 WINO_SHAPES = [
     # B, H, W, cin, cout, G
