@@ -199,8 +199,8 @@ TILE_TEMPLATE = {"128x128": (128, 128, 2, 2, 1, 2), "128x64": (128, 64, 2, 2, 1,
 
 
 def kernel_name(tile, prec):
-    if tile == "wino4f":          # (only behind VIDC_WINO_FUSED)
-        return "wino4_fused_kernel<0>"
+    if tile == "wino4f":          # Winograd F(4 x 4) in one launch (csrc/wfused.hip); <2, 0> = 32 output channels per workgroup (the full tick's form)
+        return "wino4_fused_kernel<2, 0>"
     if tile in ("g96x32s", "g96x64s3"):          # the streamed few-row tiles of csrc/wgemm.hip (only behind VIDC_TUNING_OVERRIDE: not in the measured table)
         return "wgemm_stream_kernel<%s>" % ("1, 2" if tile == "g96x32s" else "2, 3")
     return "conv_igemm_f32<%s, %d, %d>" % (", ".join(str(v) for v in TILE_TEMPLATE[tile]), prec, 2 if tile.endswith("P") else int(tile.endswith("L")))

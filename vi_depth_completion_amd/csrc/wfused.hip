@@ -27,8 +27,9 @@
 // share L % 8 = one XCD's L2.  Result bits of a tile depend on nothing but the tile (fixed K order, fixed fold): a restriction to fewer groups
 // (engine.Program.group_variant) or another batch leaves an item's bits alone (tests/test_wfused.py).
 //
-// Measured (tools/wfused_bench.py, weights HBM-cold, profiles/r6_wfused_bench.txt): layer 3 (4 groups) 41.9-42.4 us against 7.0 + 28.4 + 9.7 = 45.0 us for
-// the three launches (38.1 against 44.3 inside the frame program); one group alone 35.2 / 28.8, three groups 38.3 / 37.4; layer 2 47.0 / 40.3.  Attribution
+// Measured (tools/wfused_bench.py, weights HBM-cold, profiles/r6_wfused_bench.txt): layer 3 (4 groups) 39.9-42.4 us against 44.1-45.0 us for the three
+// launches (37.5 against 44.3 inside the frame program); one group alone 26.0 / 27.2 and three groups 29.8 / 36.0 on the NB = 1 instantiation (16 output
+// channels per workgroup for launches of few groups; with 32: 33.6 / 37.4); layer 2 44.8 / 39.5.  Attribution
 // builds (make wfused_attrib, tools/wfused_attrib.sh): empty skeleton 10.7 us (= the launch floor), + MFMAs 29.4 (18.7 us of products: 160 workgroups use
 // 160 of 256 CUs and the 16x16 MFMA form reads twice the operand bytes per FLOP of the 32x32 form), + U loads 33.5, + transform 41.8 (of which the fold 4);
 // not waiting for the DMA changes nothing.  Earlier forms (git history): 56 -> 53 -> 46 us.
@@ -55,7 +56,7 @@ static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
 struct FArgs {
     const float* x; const float* u; float* y; const float* s1; const float* b1; const float* s2; const float* b2;
-    int H, W, Cin, ldx, Cout, ldy, th, tw, T, flags, nbn, gn;      // T = B * th * tw tiles; nbn = Cout / 32; gn = groups * nbn
+    int H, W, Cin, ldx, Cout, ldy, th, tw, T, flags, nbn, gn;      // T = B * th * tw tiles; nbn = Cout / (16 NB) channel blocks of a workgroup; gn = groups * nbn
     long long x_gs, w_gs, y_gs, p_gs;
     unsigned x_bytes;
 };
@@ -106,24 +107,26 @@ template <int OFF> __device__ __forceinline__ float lds_read_b32(unsigned addr) 
 }
 template <int OFF> __device__ __forceinline__ void lds_write_b32(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory"); }
 
-// One product wave: positions pos0 .. pos0 + PW - 1, all of K, 16 tiles x 32 output channels.
-template <int PW, int DBG>
+// One product wave: positions pos0 .. pos0 + PW - 1, all of K, 16 tiles x NB blocks of 16 output channels.
+template <int PW, int NB, int DBG>
 __device__ __forceinline__ void product_wave(const FArgs& a, float* smem, unsigned lds0, int lane, int pos0, int g, int nb, int NK) {
     const int n = lane & 15, kq = lane >> 4;
     // U in fragment order (vidc_winograd_weight_pack_fused): [g][pos][nb][kc][nblk][lane][4] -- one load instruction = 1 KiB contiguous
-    const float* ub = a.u + (size_t)g * a.w_gs + ((size_t)pos0 * a.nbn + nb) * ((size_t)NK * 512) + lane * 4;
-    const size_t pos_stride = (size_t)a.nbn * NK * 512;
-    auto load_b = [&](int p, int kc, f32x4 (&dst)[2]) {
+    // (packed per 32 channels: [pos][Cout / 32][kc][nblk 2][lane][4]; a workgroup of one 16-channel block takes nblk = nb & 1 of pair nb >> 1)
+    const int n32 = a.Cout / 32, pair = NB == 2 ? nb : nb >> 1, half = NB == 2 ? 0 : nb & 1;
+    const float* ub = a.u + (size_t)g * a.w_gs + ((size_t)pos0 * n32 + pair) * ((size_t)NK * 512) + half * 256 + lane * 4;
+    const size_t pos_stride = (size_t)n32 * NK * 512;
+    auto load_b = [&](int p, int kc, f32x4 (&dst)[NB]) {
         const float* s = ub + (size_t)p * pos_stride + (size_t)kc * 512;
         dst[0] = *reinterpret_cast<const f32x4*>(s);
-        dst[1] = *reinterpret_cast<const f32x4*>(s + 256);
+        if constexpr (NB == 2) dst[1] = *reinterpret_cast<const f32x4*>(s + 256);
     };
-    f32x4 acc[PW][2];
+    f32x4 acc[PW][NB];
 #pragma unroll
     for (int p = 0; p < PW; ++p)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[p][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 bq[PW][2];                                  // a whole chunk of the wave's U fragments ahead
+        for (int j = 0; j < NB; ++j) acc[p][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bq[PW][NB];                                  // a whole chunk of the wave's U fragments ahead
 #pragma unroll
     for (int p = 0; p < PW; ++p) load_b(p, 0, bq[p]);
     // A fragment of (position, tile m = lane & 15): channels 4 kq .. 4 kq + 3 of the 64-byte row = 16-byte unit kq XOR (m >> 2) & 3
@@ -151,7 +154,7 @@ __device__ __forceinline__ void product_wave(const FArgs& a, float* smem, unsign
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NB; ++j)
                     if constexpr (!(DBG & 1)) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][ks], bq[p][j][ks], acc[p][j], 0, 0, 0);
                     else if (ks == 0) acc[p][j][0] += fa[cur][0] + fa[cur][3] + bq[p][j][0] + bq[p][j][3];
             if constexpr (!(DBG & 2)) load_b(p, kn, bq[p]);
@@ -165,13 +168,15 @@ __device__ __forceinline__ void product_wave(const FArgs& a, float* smem, unsign
 #pragma unroll
     for (int p = 0; p < PW; ++p)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) mx[((pos0 + p) * TB + 4 * kq + i) * MLD + j * 16 + n] = acc[p][j][i];
 }
 
 // DBG (attribution builds, -DVIDC_WFUSED_ATTRIB + VIDC_WFUSED_DBG): 1 no MFMAs, 2 no U loads in the loop, 4 no transform (barriers only), 8 no fold / stores
-template <int DBG>
+// NB = 16-channel blocks per workgroup: 2 (32 output channels) when the layer fills the chip that way, 1 for launches of few groups (the head / tail ticks of
+// a stream: twice the workgroups, half the products each).  A tile's result bits do not depend on NB: the same K order and fold per output element.
+template <int NB, int DBG>
 __global__ void __launch_bounds__(NTHREADS)
 wino4_fused_kernel(const FArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -184,8 +189,8 @@ wino4_fused_kernel(const FArgs a) {
     if (tid < 64 * NPW) {
         // product waves: wave w and wave w + 4 share a SIMD (a workgroup's waves are dealt to the SIMDs in turn); 5 + 4 positions = 9 per SIMD
         const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-        if (w < 4) product_wave<5, DBG>(a, smem, lds0, tid & 63, 5 * w, g, nb, NK);
-        else product_wave<4, DBG>(a, smem, lds0, tid & 63, 20 + 4 * (w - 4), g, nb, NK);
+        if (w < 4) product_wave<5, NB, DBG>(a, smem, lds0, tid & 63, 5 * w, g, nb, NK);
+        else product_wave<4, NB, DBG>(a, smem, lds0, tid & 63, 20 + 4 * (w - 4), g, nb, NK);
     } else {
         // ------------------------------------------------------------------ transform waves: two groups of four, thread = (tile m, channel c of the chunk)
         const int tt = tid - 64 * NPW, lane = tid & 63;
@@ -290,8 +295,8 @@ wino4_fused_kernel(const FArgs a) {
     }
     __syncthreads();
     // ---------------------------------------------------------------------- fold + epilogue: thread = (tile m, channel c)
-    if (tid < TB * NBW) {
-        const int m = tid >> 5, c = tid & 31;
+    if (tid < TB * 16 * NB) {
+        const int m = tid / (16 * NB), c = tid - m * (16 * NB);
         const int t = tb * TB + m;
         if (t >= a.T || (DBG & 8)) return;
         const int tpf = a.th * a.tw;
@@ -307,7 +312,7 @@ wino4_fused_kernel(const FArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) tc[r][s] = o4[r];
         }
-        const int ch = nb * NBW + c;
+        const int ch = nb * 16 * NB + c;
         const float s1 = a.s1[(size_t)g * a.p_gs + ch], b1 = a.b1[(size_t)g * a.p_gs + ch];
         const bool aff2 = a.flags & VIDC_AFFINE2;
         const float s2 = aff2 ? a.s2[(size_t)g * a.p_gs + ch] : 0.f, b2 = aff2 ? a.b2[(size_t)g * a.p_gs + ch] : 0.f;
@@ -348,19 +353,22 @@ wino4_pack_kernel(const float* __restrict__ u, float* __restrict__ o, int Cout, 
     *reinterpret_cast<float4*>(o + i * 4) = v;
 }
 
-template <int DBG>
-int launch_dbg(const FArgs& a, long long wgs, hipStream_t st) {
+template <int NB, int DBG>
+int launch_nb(const FArgs& a, long long wgs, hipStream_t st) {
     static bool attr_set[64] = {};
     int dev = 0;
     VIDC_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        VIDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino4_fused_kernel<DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        VIDC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino4_fused_kernel<NB, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(wino4_fused_kernel<DBG>, dim3((unsigned)wgs), dim3(NTHREADS), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((wino4_fused_kernel<NB, DBG>), dim3((unsigned)wgs), dim3(NTHREADS), LDS_BYTES, st, a);
     VIDC_CHECK_LAUNCH("wino4_fused_kernel");
     return VIDC_OK;
 }
+
+template <int DBG>
+int launch_dbg(const FArgs& a, long long wgs, hipStream_t st) { return a.nbn * 32 == a.Cout ? launch_nb<2, DBG>(a, wgs, st) : launch_nb<1, DBG>(a, wgs, st); }
 
 }  // namespace
 
@@ -380,7 +388,11 @@ int launch_wino4_fused(const vidc_conv_desc& d, hipStream_t st) {
     a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.ldx = d.ldx; a.Cout = d.Cout; a.ldy = d.ldy;
     a.th = (d.H + 3) / 4; a.tw = (d.W + 3) / 4;
     a.T = d.B * a.th * a.tw;
-    a.flags = d.flags; a.nbn = d.Cout / NBW; a.gn = d.groups * a.nbn;
+    // 32 output channels per workgroup when that gives more than half a chip of workgroups, else 16 (VIDC_WFUSED_NB=1 / 2 forces: A-B runs)
+    static const int force_nb = [] { const char* e = getenv("VIDC_WFUSED_NB"); return e ? atoi(e) : 0; }();
+    const long long wgs32 = (long long)((d.B * a.th * a.tw + TB - 1) / TB) * d.groups * (d.Cout / NBW);
+    const int nbk = force_nb == 1 || force_nb == 2 ? force_nb : (wgs32 * 2 <= 256 ? 1 : 2);
+    a.flags = d.flags; a.nbn = d.Cout / (16 * nbk); a.gn = d.groups * a.nbn;
     a.x_gs = d.x_gs; a.w_gs = d.w_gs; a.y_gs = d.y_gs; a.p_gs = d.p_gs;
     VIDC_REQUIRE((long long)d.B * d.H * d.W * d.ldx * 4 < (1ll << 30), VIDC_ERR_SHAPE, "conv (fused Winograd): the input must stay below 1 GiB");
     a.x_bytes = (unsigned)((long long)d.B * d.H * d.W * d.ldx * 4);
